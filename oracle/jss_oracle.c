@@ -1,0 +1,540 @@
+/*
+ * oracle/jss_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see jss_oracle.h).
+ *
+ * A deliberately literal restatement of the reference simulator: it keeps the
+ * sorted event list (next_time_step / next_jobs), the M x J illegal_actions
+ * matrix, the stored nb_legal_actions / nb_machine_legal counters and the
+ * float64 observation written at exactly the points where the reference
+ * writes it.  The HIP path derives all of those from a smaller state, so the
+ * two implementations share no shortcuts.
+ *
+ * Every function cites the reference lines it follows
+ * (paths relative to the reference root, JSSEnv v1.1.0).
+ */
+#include "jss_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+struct OrcEnv {
+    int jobs, machines;
+    int32_t *mach;  /* instance_matrix[j][k][0]  (jss_env.py:85) */
+    int32_t *dur;   /* instance_matrix[j][k][1] */
+    int max_time_op, max_time_jobs, sum_op;
+
+    int current_time_step;
+    int nb_legal_actions, nb_machine_legal;
+    int32_t *next_time_step; /* sorted ascending, distinct */
+    int32_t *next_jobs;
+    int queue_len, queue_cap;
+    uint8_t *legal_actions;        /* [J+1] */
+    int32_t *solution;             /* [J*M] */
+    int32_t *time_until_available_machine;
+    int32_t *time_until_finish_current_op_jobs;
+    int32_t *todo_time_step_job;
+    int32_t *total_perform_op_time_jobs;
+    int32_t *needed_machine_jobs;
+    int32_t *total_idle_time_jobs;
+    int32_t *idle_time_jobs_last_op;
+    uint8_t *illegal_actions;      /* [M*J] */
+    uint8_t *action_illegal_no_op; /* [J]   */
+    uint8_t *machine_legal;        /* [M]   */
+    double *state;                 /* [J*7] */
+    int err;
+    long last_reward_numerator;
+};
+
+#define MACH(e, j, k) ((e)->mach[(j) * (e)->machines + (k)])
+#define DUR(e, j, k) ((e)->dur[(j) * (e)->machines + (k)])
+#define ST(e, j, f) ((e)->state[(j) * 7 + (f)])
+
+static int imax(int a, int b) { return a > b ? a : b; }
+static int imin(int a, int b) { return a < b ? a : b; }
+
+/* jss_env.py:72-95 (constants only; text parsing is host code) */
+OrcEnv *orc_create(int jobs, int machines, const int32_t *machine_jm, const int32_t *duration_jm) {
+    if (jobs < 1 || machines < 2) return NULL;
+    OrcEnv *e = (OrcEnv *)calloc(1, sizeof(OrcEnv));
+    int J = jobs, M = machines;
+    e->jobs = J;
+    e->machines = M;
+    e->mach = (int32_t *)malloc(sizeof(int32_t) * J * M);
+    e->dur = (int32_t *)malloc(sizeof(int32_t) * J * M);
+    memcpy(e->mach, machine_jm, sizeof(int32_t) * J * M);
+    memcpy(e->dur, duration_jm, sizeof(int32_t) * J * M);
+    for (int j = 0; j < J; ++j) {
+        int len = 0;
+        for (int k = 0; k < M; ++k) {
+            e->max_time_op = imax(e->max_time_op, DUR(e, j, k)); /* :86 */
+            len += DUR(e, j, k);                                 /* :87 */
+            e->sum_op += DUR(e, j, k);                           /* :88 */
+        }
+        e->max_time_jobs = imax(e->max_time_jobs, len);          /* :89 */
+    }
+    e->queue_cap = J + M + 4;
+    e->next_time_step = (int32_t *)malloc(sizeof(int32_t) * e->queue_cap);
+    e->next_jobs = (int32_t *)malloc(sizeof(int32_t) * e->queue_cap);
+    e->legal_actions = (uint8_t *)calloc(J + 1, 1);
+    e->solution = (int32_t *)malloc(sizeof(int32_t) * J * M);
+    e->time_until_available_machine = (int32_t *)calloc(M, sizeof(int32_t));
+    e->time_until_finish_current_op_jobs = (int32_t *)calloc(J, sizeof(int32_t));
+    e->todo_time_step_job = (int32_t *)calloc(J, sizeof(int32_t));
+    e->total_perform_op_time_jobs = (int32_t *)calloc(J, sizeof(int32_t));
+    e->needed_machine_jobs = (int32_t *)calloc(J, sizeof(int32_t));
+    e->total_idle_time_jobs = (int32_t *)calloc(J, sizeof(int32_t));
+    e->idle_time_jobs_last_op = (int32_t *)calloc(J, sizeof(int32_t));
+    e->illegal_actions = (uint8_t *)calloc((size_t)M * J, 1);
+    e->action_illegal_no_op = (uint8_t *)calloc(J, 1);
+    e->machine_legal = (uint8_t *)calloc(M, 1);
+    e->state = (double *)calloc((size_t)J * 7, sizeof(double));
+    orc_reset(e);
+    return e;
+}
+
+void orc_destroy(OrcEnv *e) {
+    if (!e) return;
+    free(e->mach); free(e->dur); free(e->next_time_step); free(e->next_jobs);
+    free(e->legal_actions); free(e->solution); free(e->time_until_available_machine);
+    free(e->time_until_finish_current_op_jobs); free(e->todo_time_step_job);
+    free(e->total_perform_op_time_jobs); free(e->needed_machine_jobs);
+    free(e->total_idle_time_jobs); free(e->idle_time_jobs_last_op);
+    free(e->illegal_actions); free(e->action_illegal_no_op); free(e->machine_legal);
+    free(e->state); free(e);
+}
+
+/* jss_env.py:121-134 */
+static void get_current_state_representation(OrcEnv *e) {
+    for (int j = 0; j < e->jobs; ++j) ST(e, j, 0) = e->legal_actions[j] ? 1.0 : 0.0; /* :130 */
+}
+
+/* jss_env.py:145-181 */
+void orc_reset(OrcEnv *e) {
+    int J = e->jobs, M = e->machines;
+    e->current_time_step = 0;                                   /* :154 */
+    e->queue_len = 0;                                           /* :155-156 */
+    e->nb_legal_actions = J;                                    /* :157 */
+    e->nb_machine_legal = 0;                                    /* :158 */
+    memset(e->legal_actions, 1, J);                             /* :160 */
+    e->legal_actions[J] = 0;                                    /* :161 */
+    for (int i = 0; i < J * M; ++i) e->solution[i] = -1;        /* :163 */
+    memset(e->time_until_available_machine, 0, sizeof(int32_t) * M);
+    memset(e->time_until_finish_current_op_jobs, 0, sizeof(int32_t) * J);
+    memset(e->todo_time_step_job, 0, sizeof(int32_t) * J);
+    memset(e->total_perform_op_time_jobs, 0, sizeof(int32_t) * J);
+    memset(e->needed_machine_jobs, 0, sizeof(int32_t) * J);
+    memset(e->total_idle_time_jobs, 0, sizeof(int32_t) * J);
+    memset(e->idle_time_jobs_last_op, 0, sizeof(int32_t) * J);
+    memset(e->illegal_actions, 0, (size_t)M * J);               /* :171 */
+    memset(e->action_illegal_no_op, 0, J);                      /* :172 */
+    memset(e->machine_legal, 0, M);                             /* :173 */
+    for (int j = 0; j < J; ++j) {                               /* :174-179 */
+        int needed = MACH(e, j, 0);
+        e->needed_machine_jobs[j] = needed;
+        if (!e->machine_legal[needed]) {
+            e->machine_legal[needed] = 1;
+            e->nb_machine_legal += 1;
+        }
+    }
+    memset(e->state, 0, sizeof(double) * J * 7);                /* :180 */
+    e->err = 0;
+    e->last_reward_numerator = 0;
+    get_current_state_representation(e);                        /* :181 */
+}
+
+/* jss_env.py:183-254 */
+static void prioritization_non_final(OrcEnv *e) {
+    int J = e->jobs, M = e->machines;
+    if (e->nb_machine_legal < 1) return;                        /* :202 */
+    int *final_job = (int *)malloc(sizeof(int) * J);
+    for (int machine = 0; machine < M; ++machine) {             /* :203 */
+        if (!e->machine_legal[machine]) continue;               /* :204 */
+        int n_final = 0, n_non_final = 0;
+        long min_non_final = 0x7fffffffL;                       /* :208 (inf) */
+        for (int job = 0; job < J; ++job) {                     /* :211 */
+            if (e->needed_machine_jobs[job] == machine && e->legal_actions[job]) {
+                if (e->todo_time_step_job[job] == M - 1) {      /* :217 */
+                    final_job[n_final++] = job;
+                } else {
+                    int k = e->todo_time_step_job[job];         /* :221 */
+                    int time_needed_legal = DUR(e, job, k);     /* :222 */
+                    int machine_needed_nextstep = MACH(e, job, k + 1); /* :227 */
+                    if (e->time_until_available_machine[machine_needed_nextstep] == 0) { /* :234 */
+                        if (time_needed_legal < min_non_final) min_non_final = time_needed_legal; /* :238 */
+                        n_non_final++;                          /* :239 */
+                    }
+                }
+            }
+        }
+        if (n_non_final > 0) {                                  /* :243 */
+            for (int i = 0; i < n_final; ++i) {                 /* :244 */
+                int job = final_job[i];
+                int time_needed_legal = DUR(e, job, e->todo_time_step_job[job]); /* :245-248 */
+                if (time_needed_legal > min_non_final) {        /* :252 */
+                    e->legal_actions[job] = 0;                  /* :253 */
+                    e->nb_legal_actions -= 1;                   /* :254 */
+                }
+            }
+        }
+    }
+    free(final_job);
+}
+
+/* shared body of the two look-ahead walks, jss_env.py:340-363 and :380-401.
+ * Returns 1 when the walk made NOPE legal (the reference `return`s there). */
+static int walk(OrcEnv *e, int job, int time_step, long time_needed, long max_horizon,
+                const long *max_horizon_machine, uint8_t *machine_next, int *n_machine_next) {
+    int M = e->machines;
+    while (time_step < M - 1 && max_horizon > time_needed) {    /* :340-342 / :380-382 */
+        int machine_needed = MACH(e, job, time_step);           /* :343 / :383 */
+        if (max_horizon_machine[machine_needed] > time_needed && e->machine_legal[machine_needed]) {
+            if (!machine_next[machine_needed]) {                /* set.add  :351 / :391 */
+                machine_next[machine_needed] = 1;
+                (*n_machine_next)++;
+            }
+            if (*n_machine_next == e->nb_machine_legal) {       /* :357 / :395 */
+                e->legal_actions[e->jobs] = 1;
+                return 1;
+            }
+        }
+        time_needed += DUR(e, job, time_step);                  /* :362 / :400 */
+        time_step += 1;
+    }
+    return 0;
+}
+
+/* jss_env.py:256-401 */
+static void check_no_op(OrcEnv *e) {
+    int J = e->jobs, M = e->machines;
+    e->legal_actions[J] = 0;                                    /* :278 */
+    if (!(e->queue_len > 0 && e->nb_machine_legal <= 3 && e->nb_legal_actions <= 4)) return; /* :284-288 */
+    uint8_t *machine_next = (uint8_t *)calloc(M, 1);            /* :290 */
+    long *max_horizon_machine = (long *)malloc(sizeof(long) * M);
+    int n_machine_next = 0;
+    long next_time_step = e->next_time_step[0];                 /* :293 */
+    long max_horizon = e->current_time_step;                    /* :296 */
+    for (int m = 0; m < M; ++m) max_horizon_machine[m] = (long)e->current_time_step + e->max_time_op; /* :300-302 */
+    for (int job = 0; job < J; ++job) {                         /* :305 pass 1, ascending job order */
+        if (e->legal_actions[job]) {
+            int time_step = e->todo_time_step_job[job];
+            int machine_needed = MACH(e, job, time_step);       /* :308 */
+            int time_needed = DUR(e, job, time_step);           /* :309 */
+            long end_job = (long)e->current_time_step + time_needed; /* :310 */
+            if (end_job < next_time_step) goto out;             /* :314-315 */
+            if (end_job < max_horizon_machine[machine_needed]) max_horizon_machine[machine_needed] = end_job; /* :318 */
+            if (max_horizon_machine[machine_needed] > max_horizon) max_horizon = max_horizon_machine[machine_needed]; /* :321 */
+        }
+    }
+    for (int job = 0; job < J; ++job) {                         /* :324 pass 2 */
+        if (e->legal_actions[job]) continue;                    /* :325 */
+        if (e->time_until_finish_current_op_jobs[job] > 0 && e->todo_time_step_job[job] + 1 < M) { /* :327-330 */
+            int time_step = e->todo_time_step_job[job] + 1;     /* :332 */
+            long time_needed = (long)e->current_time_step + e->time_until_finish_current_op_jobs[job]; /* :334-337 */
+            if (walk(e, job, time_step, time_needed, max_horizon, max_horizon_machine, machine_next, &n_machine_next)) goto out;
+        } else if (!e->action_illegal_no_op[job] && e->todo_time_step_job[job] < M) { /* :366-369 */
+            int time_step = e->todo_time_step_job[job];         /* :370 */
+            int machine_needed = MACH(e, job, time_step);       /* :371 */
+            long time_needed = (long)e->current_time_step + e->time_until_available_machine[machine_needed]; /* :374-377 */
+            if (walk(e, job, time_step, time_needed, max_horizon, max_horizon_machine, machine_next, &n_machine_next)) goto out;
+        }
+    }
+out:
+    free(machine_next);
+    free(max_horizon_machine);
+}
+
+/* jss_env.py:495-637 */
+int orc_increase_time_step(OrcEnv *e, int *hole_out) {
+    int J = e->jobs, M = e->machines;
+    int hole_planning = 0;                                      /* :514 */
+    if (e->queue_len == 0) {                                    /* :517 pop(0) on [] -> IndexError */
+        e->err |= ORC_ERR_NOPE_IDLE;
+        if (hole_out) *hole_out = 0;
+        return -1;
+    }
+    int next_time_step_to_pick = e->next_time_step[0];          /* :517-518 */
+    memmove(e->next_time_step, e->next_time_step + 1, sizeof(int32_t) * (e->queue_len - 1));
+    memmove(e->next_jobs, e->next_jobs + 1, sizeof(int32_t) * (e->queue_len - 1));
+    e->queue_len -= 1;
+    int difference = next_time_step_to_pick - e->current_time_step; /* :521 */
+    e->current_time_step = next_time_step_to_pick;              /* :522 */
+    for (int job = 0; job < J; ++job) {                         /* :525 */
+        int was_left_time = e->time_until_finish_current_op_jobs[job]; /* :526 */
+        if (was_left_time > 0) {                                /* :529 */
+            int performed_op_job = imin(difference, was_left_time); /* :531 */
+            e->time_until_finish_current_op_jobs[job] = imax(0, e->time_until_finish_current_op_jobs[job] - difference); /* :534 */
+            ST(e, job, 1) = (double)e->time_until_finish_current_op_jobs[job] / e->max_time_op; /* :539 */
+            e->total_perform_op_time_jobs[job] += performed_op_job; /* :544 */
+            ST(e, job, 3) = (double)e->total_perform_op_time_jobs[job] / e->max_time_jobs; /* :545 */
+            if (e->time_until_finish_current_op_jobs[job] == 0) { /* :550 */
+                e->total_idle_time_jobs[job] += difference - was_left_time; /* :552 */
+                ST(e, job, 6) = (double)e->total_idle_time_jobs[job] / e->sum_op; /* :553 */
+                e->idle_time_jobs_last_op[job] = difference - was_left_time; /* :554 */
+                ST(e, job, 5) = (double)e->idle_time_jobs_last_op[job] / e->sum_op; /* :555 */
+                e->todo_time_step_job[job] += 1;                /* :558 */
+                ST(e, job, 2) = (double)e->todo_time_step_job[job] / M; /* :559 */
+                if (e->todo_time_step_job[job] < M) {           /* :562 */
+                    e->needed_machine_jobs[job] = MACH(e, job, e->todo_time_step_job[job]); /* :564 */
+                    ST(e, job, 4) = (double)imax(0, e->time_until_available_machine[e->needed_machine_jobs[job]] - difference)
+                                    / e->max_time_op;           /* :569-578 (machine times not yet advanced) */
+                } else {
+                    e->needed_machine_jobs[job] = -1;           /* :581 */
+                    ST(e, job, 4) = 1.0;                        /* :586 */
+                    if (e->legal_actions[job]) {                /* :589-591 */
+                        e->legal_actions[job] = 0;
+                        e->nb_legal_actions -= 1;
+                    }
+                }
+            }
+        } else if (e->todo_time_step_job[job] < M) {            /* :594 */
+            e->total_idle_time_jobs[job] += difference;         /* :596 */
+            e->idle_time_jobs_last_op[job] += difference;       /* :597 */
+            ST(e, job, 5) = (double)e->idle_time_jobs_last_op[job] / e->sum_op; /* :600 */
+            ST(e, job, 6) = (double)e->total_idle_time_jobs[job] / e->sum_op;   /* :601 */
+        }
+    }
+    for (int machine = 0; machine < M; ++machine) {             /* :604 */
+        if (e->time_until_available_machine[machine] < difference) { /* :606 */
+            int empty = difference - e->time_until_available_machine[machine];
+            hole_planning += empty;                             /* :608 */
+        }
+        e->time_until_available_machine[machine] = imax(0, e->time_until_available_machine[machine] - difference); /* :611 */
+        if (e->time_until_available_machine[machine] == 0) {    /* :616 */
+            for (int job = 0; job < J; ++job) {                 /* :617 */
+                if (e->needed_machine_jobs[job] == machine && !e->legal_actions[job]
+                    && !e->illegal_actions[machine * J + job]) { /* :622-626 */
+                    e->legal_actions[job] = 1;                  /* :628 */
+                    e->nb_legal_actions += 1;                   /* :629 */
+                    if (!e->machine_legal[machine]) {           /* :632-634 */
+                        e->machine_legal[machine] = 1;
+                        e->nb_machine_legal += 1;
+                    }
+                }
+            }
+        }
+    }
+    if (hole_out) *hole_out = hole_planning;
+    return 0;                                                   /* :637 */
+}
+
+/* bisect.bisect_left + "not in" of jss_env.py:450-453 */
+static void queue_insert(OrcEnv *e, int when, int job) {
+    int lo = 0, hi = e->queue_len;
+    while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        if (e->next_time_step[mid] < when) lo = mid + 1; else hi = mid;
+    }
+    if (lo < e->queue_len && e->next_time_step[lo] == when) return; /* :450 already present */
+    if (e->queue_len == e->queue_cap) {
+        e->queue_cap *= 2;
+        e->next_time_step = (int32_t *)realloc(e->next_time_step, sizeof(int32_t) * e->queue_cap);
+        e->next_jobs = (int32_t *)realloc(e->next_jobs, sizeof(int32_t) * e->queue_cap);
+    }
+    memmove(e->next_time_step + lo + 1, e->next_time_step + lo, sizeof(int32_t) * (e->queue_len - lo));
+    memmove(e->next_jobs + lo + 1, e->next_jobs + lo, sizeof(int32_t) * (e->queue_len - lo));
+    e->next_time_step[lo] = when;
+    e->next_jobs[lo] = job;
+    e->queue_len += 1;
+}
+
+/* jss_env.py:639-653 */
+static int is_done(const OrcEnv *e) { return e->nb_legal_actions == 0; }
+
+/* jss_env.py:403-481 */
+int orc_step(OrcEnv *e, int action, int strict, double *reward_out, int *done_out) {
+    int J = e->jobs;
+    double reward = 0.0;                                        /* :418 */
+    int rc = 0;
+    if (action < 0 || action > J) {          /* ref: IndexError; device: ignored + flag */
+        e->err |= ORC_ERR_BAD_ACTION;
+        rc = -2;
+        goto ignored;
+    }
+    if (action == J) {                                          /* :419 */
+        e->nb_machine_legal = 0;                                /* :420 */
+        e->nb_legal_actions = 0;                                /* :421 */
+        for (int job = 0; job < J; ++job) {                     /* :422 */
+            if (e->legal_actions[job]) {
+                e->legal_actions[job] = 0;                      /* :424 */
+                int needed_machine = e->needed_machine_jobs[job];
+                e->machine_legal[needed_machine] = 0;           /* :426 */
+                e->illegal_actions[needed_machine * J + job] = 1; /* :427 */
+                e->action_illegal_no_op[job] = 1;               /* :428 */
+            }
+        }
+        while (e->nb_machine_legal == 0) {                      /* :429 */
+            int hole;
+            if (orc_increase_time_step(e, &hole) < 0) { rc = -1; break; } /* ref raises here */
+            reward -= hole;                                     /* :430 */
+        }
+    } else {
+        if (strict && !e->legal_actions[action]) {  /* ref: silent corruption; device: ignored + flag */
+            e->err |= ORC_ERR_ILLEGAL_ACTION;
+            rc = -3;
+            goto ignored;
+        }
+        int current_time_step_job = e->todo_time_step_job[action]; /* :442 */
+        int machine_needed = e->needed_machine_jobs[action];    /* :443 */
+        int time_needed = DUR(e, action, current_time_step_job); /* :444 */
+        reward += time_needed;                                  /* :445 */
+        e->time_until_available_machine[machine_needed] = time_needed; /* :446 */
+        e->time_until_finish_current_op_jobs[action] = time_needed;    /* :447 */
+        ST(e, action, 1) = (double)time_needed / e->max_time_op;       /* :448 */
+        queue_insert(e, e->current_time_step + time_needed, action);   /* :449-453 */
+        e->solution[action * e->machines + current_time_step_job] = e->current_time_step; /* :454 */
+        for (int job = 0; job < J; ++job) {                     /* :455-461 */
+            if (e->needed_machine_jobs[job] == machine_needed && e->legal_actions[job]) {
+                e->legal_actions[job] = 0;
+                e->nb_legal_actions -= 1;
+            }
+        }
+        e->nb_machine_legal -= 1;                               /* :462 */
+        e->machine_legal[machine_needed] = 0;                   /* :463 */
+        for (int job = 0; job < J; ++job) {                     /* :464-467 */
+            if (e->illegal_actions[machine_needed * J + job]) {
+                e->action_illegal_no_op[job] = 0;
+                e->illegal_actions[machine_needed * J + job] = 0;
+            }
+        }
+        while (e->nb_machine_legal == 0 && e->queue_len > 0) {  /* :469 */
+            int hole;
+            orc_increase_time_step(e, &hole);
+            reward -= hole;                                     /* :470 */
+        }
+    }
+    prioritization_non_final(e);                                /* :432 / :471 */
+    check_no_op(e);                                             /* :433 / :472 */
+    e->last_reward_numerator = (long)reward;
+    if (reward_out) *reward_out = reward / e->max_time_op;      /* :431 / :474, :483-493 */
+    get_current_state_representation(e);                        /* :435 / :476 */
+    if (done_out) *done_out = is_done(e);                       /* :437 / :478 */
+    return rc;
+ignored:
+    e->last_reward_numerator = 0;
+    if (reward_out) *reward_out = 0.0;
+    get_current_state_representation(e);
+    if (done_out) *done_out = is_done(e);
+    return rc;
+}
+
+/* getters ----------------------------------------------------------------- */
+int orc_jobs(const OrcEnv *e) { return e->jobs; }
+int orc_machines(const OrcEnv *e) { return e->machines; }
+int orc_current_time_step(const OrcEnv *e) { return e->current_time_step; }
+int orc_nb_legal_actions(const OrcEnv *e) { return e->nb_legal_actions; }
+int orc_nb_machine_legal(const OrcEnv *e) { return e->nb_machine_legal; }
+int orc_next_time_step_len(const OrcEnv *e) { return e->queue_len; }
+int orc_err(const OrcEnv *e) { return e->err; }
+int orc_max_time_op(const OrcEnv *e) { return e->max_time_op; }
+int orc_max_time_jobs(const OrcEnv *e) { return e->max_time_jobs; }
+int orc_sum_op(const OrcEnv *e) { return e->sum_op; }
+long orc_last_reward_numerator(const OrcEnv *e) { return e->last_reward_numerator; }
+const int32_t *orc_todo_time_step_job(const OrcEnv *e) { return e->todo_time_step_job; }
+const int32_t *orc_needed_machine_jobs(const OrcEnv *e) { return e->needed_machine_jobs; }
+const int32_t *orc_time_until_finish_current_op_jobs(const OrcEnv *e) { return e->time_until_finish_current_op_jobs; }
+const int32_t *orc_total_perform_op_time_jobs(const OrcEnv *e) { return e->total_perform_op_time_jobs; }
+const int32_t *orc_total_idle_time_jobs(const OrcEnv *e) { return e->total_idle_time_jobs; }
+const int32_t *orc_idle_time_jobs_last_op(const OrcEnv *e) { return e->idle_time_jobs_last_op; }
+const int32_t *orc_time_until_available_machine(const OrcEnv *e) { return e->time_until_available_machine; }
+const int32_t *orc_solution(const OrcEnv *e) { return e->solution; }
+const int32_t *orc_next_time_step(const OrcEnv *e) { return e->next_time_step; }
+const uint8_t *orc_legal_actions(const OrcEnv *e) { return e->legal_actions; }
+const uint8_t *orc_action_illegal_no_op(const OrcEnv *e) { return e->action_illegal_no_op; }
+const uint8_t *orc_machine_legal(const OrcEnv *e) { return e->machine_legal; }
+const uint8_t *orc_illegal_actions(const OrcEnv *e) { return e->illegal_actions; }
+const double *orc_state(const OrcEnv *e) { return e->state; }
+
+/* action selectors ---------------------------------------------------------- */
+
+/* Counter RNG shared with the device policy kernel (jssenv_amd/csrc/jss_kernels.hip
+ * rng_u32): two splitmix64 finalisers keyed by (seed, env, episode, step). */
+static uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+uint32_t orc_rng_u32(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step) {
+    uint64_t k = mix64(seed ^ (env_id * 0xD1342543DE82EF95ULL));
+    uint64_t x = mix64(k ^ (((uint64_t)episode << 32) | (uint64_t)step));
+    return (uint32_t)(x >> 32);
+}
+
+static long remaining_work(const OrcEnv *e, int job) { /* dispatching.py:187-189 */
+    long r = 0;
+    for (int op = e->todo_time_step_job[job]; op < e->machines; ++op) r += DUR(e, job, op);
+    return r;
+}
+
+int orc_policy(const OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step) {
+    int J = e->jobs;
+    const uint8_t *legal = e->legal_actions;
+    if (kind == ORC_POLICY_RANDOM) {
+        /* README.md:58-60: np.random.choice(len(mask), p=mask/mask.sum()) -- uniform
+         * over the set bits, NOPE included.  Index = floor(u32 * n / 2^32). */
+        int n = 0;
+        for (int a = 0; a <= J; ++a) n += legal[a] ? 1 : 0;
+        if (n == 0) return J;
+        uint32_t r = orc_rng_u32(seed, env_id, episode, step);
+        int pick = (int)(((uint64_t)r * (uint64_t)n) >> 32);
+        for (int a = 0; a <= J; ++a) {
+            if (legal[a]) {
+                if (pick == 0) return a;
+                --pick;
+            }
+        }
+        return J;
+    }
+    /* every rule: NOPE when it is the only legal action (dispatching.py:96-97, 137-138, ...) */
+    int n_jobs_legal = 0;
+    for (int j = 0; j < J; ++j) n_jobs_legal += legal[j] ? 1 : 0;
+    if (n_jobs_legal == 0) return J; /* includes sum==1 and legal[-1]; with nothing legal the rules return -1, we return NOPE */
+    int best = -1;
+    long best_v = 0;
+    for (int job = 0; job < J; ++job) {
+        if (!legal[job]) continue;
+        long v;
+        int larger_wins;
+        switch (kind) {
+        case ORC_POLICY_FIFO: v = e->idle_time_jobs_last_op[job]; larger_wins = 1; break;             /* :146-150 */
+        case ORC_POLICY_SPT:  v = DUR(e, job, e->todo_time_step_job[job]); larger_wins = 0; break;     /* :105-110 */
+        case ORC_POLICY_MWR:  v = remaining_work(e, job); larger_wins = 1; break;                      /* :187-193 */
+        case ORC_POLICY_LWR:  v = remaining_work(e, job); larger_wins = 0; break;                      /* :230-236 */
+        case ORC_POLICY_MOR:  v = e->machines - e->todo_time_step_job[job]; larger_wins = 1; break;    /* :273-277 */
+        case ORC_POLICY_LOR:  v = e->machines - e->todo_time_step_job[job]; larger_wins = 0; break;    /* :314-318 */
+        default: return -1;
+        }
+        /* strict comparison: the first index wins ties */
+        if (best < 0 || (larger_wins ? v > best_v : v < best_v)) {
+            best = job;
+            best_v = v;
+        }
+    }
+    return best;
+}
+
+long orc_rollout(OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32_t *episode, uint32_t *step_in_episode,
+                 long iterations, long counters[3], double *reward_sum) {
+    long executed = 0;
+    for (long it = 0; it < iterations; ++it) {
+        if (is_done(e)) {
+            orc_reset(e);
+            *episode += 1;
+            *step_in_episode = 0;
+            continue;
+        }
+        int a = orc_policy(e, kind, seed, env_id, *episode, *step_in_episode);
+        double r;
+        int done;
+        orc_step(e, a, 1, &r, &done);
+        *step_in_episode += 1;
+        executed += 1;
+        counters[0] += 1;
+        *reward_sum += r;
+        if (done) {
+            counters[1] += 1;
+            counters[2] += e->current_time_step;
+        }
+    }
+    return executed;
+}
