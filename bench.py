@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- env steps/sec of the batched JSS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over the batch: ONE launch of the fused
+policy+step kernel (jss_rollout with n_iter = 1) that, for every env, picks a random
+masked action on the device, executes step() and writes the full gym outputs
+(real_obs, action_mask, reward, done) to HBM -- exactly what a reference
+``obs, r, done, _, _ = env.step(policy(obs))`` iteration produces.  Envs found done
+are reset by that launch instead (the iteration is not counted as an env step).
+value = env steps executed by all ranks / max-over-ranks wall time of the K launches.
+
+Workload: BASELINE.json configs[1] shape (ta01, 15x15, one shared instance, random
+masked policy) at the north_star's target batch of 65 536 envs per GPU (weak scaling:
+every rank owns its own 65 536 envs, no data-path collective; one RCCL all-reduce of
+the counters after the timed region).  The configs[1] batch of 4 096 and the fused
+multi-step rollout (state kept in registers for 64 iterations) are measured after the
+timed region and reported as extra fields.
+
+Extra objects: roofline (HBM; algorithmic bytes per launch / HIP-event kernel time) and
+cpu_baseline (the C oracle of oracle/, timed on this box's host cores, rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def b_alg(J, M):
+    """Algorithmic bytes of one env step: read + write the per-env state
+    (7 int32/job, 2 flag bytes/job, int32 + flag per machine, clock + counters), the action,
+    one solution entry, the float32 observation, the mask, reward and done."""
+    return 89 * J + 10 * M + 40
+
+
+def cpu_baseline(inst_name, seed, target_seconds=12.0):
+    """The C oracle (a scalar restatement of the reference's step(), oracle/jss_oracle.c) running
+    the same policy+step loop on this box's host cores, one env per thread."""
+    import concurrent.futures as cf
+    from jssenv_amd import builtin_instance
+    from oracle import OracleEnv
+    inst = builtin_instance(inst_name)
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    envs = [OracleEnv(inst, strict=True) for _ in range(threads)]
+    for e in envs:
+        e.reset()
+    t0 = time.perf_counter()
+    envs[0].rollout("random", seed, 0, 20000, episode=1)
+    per_step = (time.perf_counter() - t0) / 20000
+    iters = int(max(20000, target_seconds / max(per_step, 1e-9)))
+    for e in envs:
+        e.reset()
+
+    def work(i):
+        return envs[i].rollout("random", seed, i, iters, episode=1)["steps"]
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(threads) as ex:
+        steps = sum(ex.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env steps/s", "cores": threads, "kind": "port",
+            "sample": f"{inst_name} random-masked policy+step, {threads} envs x {iters} iterations "
+                      f"({steps} env steps, {dt:.1f} s, one env per thread; 1 thread = {1.0 / per_step:.0f} steps/s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--instance", default="ta01")
+    ap.add_argument("--policy", default="random")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from jssenv_amd import BatchedJssEnv, builtin_instance
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+
+    inst = builtin_instance(args.instance)
+    B = args.batch
+
+    def make_env(batch):
+        e = BatchedJssEnv(inst, batch=batch, device=dev, seed=args.seed, env_id_base=rank * batch)
+        e.reset()
+        # decorrelate episode phases so the timed window sees the steady-state mix of episode stages
+        e.rollout(args.policy, n_iter=257, autoreset=True)
+        e.counters.zero_()
+        return e
+
+    def timed(env, n_launch, n_iter, record_events=False):
+        evs = None
+        if record_events:
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_launch + 1)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if evs:
+            evs[0].record()
+        for i in range(n_launch):
+            env.rollout(args.policy, n_iter=n_iter, autoreset=True)
+            if evs:
+                evs[i + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        per_launch_ms = None
+        if evs:
+            per_launch_ms = sum(evs[i].elapsed_time(evs[i + 1]) for i in range(n_launch)) / n_launch
+        return dt, per_launch_ms
+
+    env = make_env(B)
+    for _ in range(args.warmup):
+        env.rollout(args.policy, n_iter=1, autoreset=True)
+    torch.cuda.synchronize()
+    env.counters.zero_()
+    dt, kernel_ms = timed(env, args.steps, 1, record_events=True)
+    cnt = env.counters.sum(dim=0).to(torch.float64)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)   # the only collective: 4 counters over RCCL/xGMI
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    steps_total, episodes, makespan_sum, reward_num = [float(x) for x in cnt.tolist()]
+    dt_max = float(tmax.item())
+    value = steps_total / dt_max
+
+    # roofline of the dominant (only) kernel: algorithmic bytes per launch / HIP-event time per launch
+    stepped_per_launch = steps_total / world / args.steps
+    alg_bytes = stepped_per_launch * b_alg(inst.jobs, inst.machines)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.isfile(prof):
+        try:
+            with open(prof) as fh:
+                traffic = json.load(fh).get(f"{args.instance}_b{B}", {}).get("bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "env steps/sec (batched)", "value": value, "unit": "env steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": f"{args.instance} ({inst.jobs}x{inst.machines}) shared instance, {args.policy} masked "
+                               f"policy fused with step(), batch {B} envs per GPU, one launch per env step, "
+                               f"full obs/mask/reward/done written every step, auto-restart",
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"env-shard x{world}",
+                   "policy": args.policy},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "jss_kernel<1,kRollout>", "kernel_ms": kernel_ms,
+                     "alg_bytes_per_env_step": b_alg(inst.jobs, inst.machines),
+                     "env_steps_per_launch": stepped_per_launch},
+        "episodes_finished": episodes,
+        "mean_makespan": makespan_sum / episodes if episodes else None,
+        "mean_reward_per_step": reward_num / inst.max_time_op / steps_total if steps_total else None,
+    }
+
+    if not args.no_extras:
+        # fused multi-step rollout: 64 iterations per launch, state in registers, outputs once per launch
+        env.counters.zero_()
+        n_l = max(4, args.steps // 16)
+        dtf, _ = timed(env, n_l, 64)
+        c = env.counters.sum(dim=0).to(torch.float64)
+        tf = torch.tensor([dtf], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+        out["fused_rollout"] = {"value": float(c[0].item()) / float(tf.item()), "unit": "env steps/s",
+                                "iterations_per_launch": 64, "launches": n_l,
+                                "note": "policy+step x64 per launch, observation written once per launch"}
+        if world == 1:
+            env4k = make_env(4096)
+            for _ in range(args.warmup):
+                env4k.rollout(args.policy, n_iter=1, autoreset=True)
+            env4k.counters.zero_()
+            dt4, ms4 = timed(env4k, args.steps, 1, record_events=True)
+            out["configs1_batch4096"] = {"value": float(env4k.counters[:, 0].sum().item()) / dt4,
+                                         "unit": "env steps/s", "kernel_ms": ms4}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.instance, args.seed)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

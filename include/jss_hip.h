@@ -1,0 +1,156 @@
+/*
+ * include/jss_hip.h -- C ABI of libjss_hip.so, the MI355X (gfx950) batched
+ * Job-Shop-Scheduling simulator.
+ *
+ * The reference (prosysscience/JSSEnv v1.1.0) is pure Python with no FFI; the
+ * boundary this library replaces is the method surface of
+ * JSSEnv/envs/jss_env.py::JssEnv, lifted over a batch axis:
+ *
+ *   jss_reset    <- JssEnv.reset()                        jss_env.py:145-181
+ *   jss_step     <- JssEnv.step(action)                   jss_env.py:403-481
+ *                   (+ _prioritization_non_final :183-254, _check_no_op :256-401,
+ *                      increase_time_step :495-637, _get_current_state_representation
+ *                      :121-134, _reward_scaler :483-493, _is_done :639-653)
+ *   jss_advance  <- JssEnv.increase_time_step()           jss_env.py:495-637
+ *                   (public; the reference's tests call it directly,
+ *                    tests/test_solutions.py:66)
+ *   jss_policy   <- the action selectors callers put in front of step():
+ *                   README.md:58-60 (random masked), JSSEnv/dispatching.py
+ *                   FIFO :133-156, SPT :92-116, MWR :173-199, LWR :216-242,
+ *                   MOR :259-283, LOR :300-324 (exploration handled by the host)
+ *   jss_rollout  <- DispatchingRule.run_episode's loop    dispatching.py:55-75
+ *                   (policy + step fused, n iterations per launch, optional
+ *                    auto-restart of finished episodes)
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer in JssDesc/JssState/JssOut is a
+ *     DEVICE pointer owned by the caller (the Python host allocates them as torch
+ *     tensors).  The library never allocates, frees or synchronises.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*).
+ *   - return value: 0 = launched, <0 = argument error (JSS_E_*), >0 = hipError_t.
+ *   - one wavefront (64 lanes) simulates one env: job j lives on lane j % 64 (slot
+ *     j / 64), machine m on lane m.  Limits: jobs <= 128, machines <= 64,
+ *     durations in [1, 65535].
+ *
+ * Data layout (all row-major, batch outermost)
+ *   op table      int32 [n_tables][jmax][mmax]   machine << 16 | duration, 0 = padding
+ *   job state     int32 [B][JSS_NF][jmax]        JSS_F_* rows, see below
+ *   machine state int32 [B][mmax]                time_until_available_machine
+ *   action_mask   uint8 [B][jmax + 1]            legal_actions; NOPE flag at index J(env)
+ *   blocked       uint8 [B][jmax]                action_illegal_no_op
+ *   solution      int32 [B][jmax][mmax]          start time of op k of job j, -1 = unscheduled
+ *   real_obs      float [B][jmax][7]             the reference's (J,7) observation
+ */
+#ifndef JSS_HIP_H
+#define JSS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JSS_ABI_VERSION 1
+
+#define JSS_MAX_JOBS 128
+#define JSS_MAX_MACHINES 64
+
+/* rows of the per-job state block */
+#define JSS_F_TODO 0      /* todo_time_step_job                                   */
+#define JSS_F_CUR 1       /* current op, machine << 16 | duration; -1 = job finished.
+                             needed_machine_jobs == cur >> 16 (arithmetic shift)   */
+#define JSS_F_LEFT 2      /* time_until_finish_current_op_jobs                    */
+#define JSS_F_PERF 3      /* total_perform_op_time_jobs                           */
+#define JSS_F_IDLE 4      /* total_idle_time_jobs                                 */
+#define JSS_F_IDLE_LAST 5 /* idle_time_jobs_last_op                               */
+#define JSS_F_F4 6        /* numerator of observation feature 4 (written only when an
+                             op finishes, jss_env.py:569-586); JSS_F4_ONE = "1.0"  */
+#define JSS_NF 7
+#define JSS_F4_ONE (-1)
+
+/* per-env error bits (state.err, sticky until reset) */
+#define JSS_ERR_ILLEGAL_ACTION 1 /* job action outside the mask: ignored (reference: silent corruption) */
+#define JSS_ERR_NOPE_IDLE 2      /* NOPE/advance with no busy machine (reference: IndexError, jss_env.py:517) */
+#define JSS_ERR_BAD_ACTION 4     /* action < -1 or > J: ignored (reference: IndexError) */
+
+#define JSS_ACTION_SKIP (-1) /* batched step: leave this env untouched */
+
+/* policies */
+#define JSS_POLICY_RANDOM 0
+#define JSS_POLICY_FIFO 1
+#define JSS_POLICY_SPT 2
+#define JSS_POLICY_MWR 3
+#define JSS_POLICY_LWR 4
+#define JSS_POLICY_MOR 5
+#define JSS_POLICY_LOR 6
+#define JSS_N_POLICIES 7
+
+/* jss_rollout flags */
+#define JSS_ROLLOUT_AUTORESET 1 /* an env found done is reset instead of stepped (iteration not counted) */
+
+/* argument errors */
+#define JSS_E_NULL (-1)
+#define JSS_E_SHAPE (-2)
+#define JSS_E_KIND (-3)
+
+typedef struct JssDesc {
+    int32_t batch;               /* B: envs in this shard                                   */
+    int32_t jmax, mmax;          /* padded job / machine extents of every per-env row       */
+    int32_t n_tables;            /* distinct instances                                      */
+    const int32_t *ops;          /* [n_tables][jmax][mmax]                                  */
+    const int32_t *jobs;         /* [n_tables] J                                            */
+    const int32_t *machines;     /* [n_tables] M                                            */
+    const int32_t *max_time_op;  /* [n_tables] jss_env.py:86                                */
+    const int32_t *max_time_jobs;/* [n_tables] jss_env.py:89                                */
+    const int32_t *sum_op;       /* [n_tables] jss_env.py:88                                */
+    const int32_t *table_of_env; /* [B] instance of env i; NULL: 0 if n_tables==1 else i    */
+    int64_t env_id_base;         /* global id of env 0 (keys the RNG stream under sharding) */
+} JssDesc;
+
+typedef struct JssState {
+    int32_t *clock;           /* [B] current_time_step                */
+    int32_t *job;             /* [B][JSS_NF][jmax]                    */
+    int32_t *machine;         /* [B][mmax]                            */
+    uint8_t *action_mask;     /* [B][jmax+1]                          */
+    uint8_t *blocked;         /* [B][jmax]                            */
+    int32_t *solution;        /* [B][jmax][mmax]                      */
+    int32_t *episode;         /* [B] episodes started (RNG key)       */
+    int32_t *step_in_episode; /* [B] env steps since reset (RNG key)  */
+    uint8_t *err;             /* [B] JSS_ERR_* bits                   */
+    int64_t *counters;        /* [B][4]: env steps, finished episodes, sum of makespans,
+                                 sum of reward numerators (reward * max_time_op); may be NULL */
+} JssState;
+
+typedef struct JssOut {
+    float *real_obs;   /* [B][jmax][7]                                         */
+    float *reward;     /* [B] reward of the last step (jss_env.py:483-493)     */
+    uint8_t *done;     /* [B] nb_legal_actions == 0 (jss_env.py:639-653)       */
+    int32_t *makespan; /* [B] clock at the last done transition (last_time_step, jss_env.py:650) */
+} JssOut;
+
+int jss_abi_version(void);
+const char *jss_error_string(int code);
+
+/* reset every env (which == NULL) or the envs with which[i] != 0 */
+int jss_reset(const JssDesc *desc, const JssState *state, const JssOut *out, const uint8_t *which, void *stream);
+
+/* one step() per env; actions[i] in [0, J] or JSS_ACTION_SKIP */
+int jss_step(const JssDesc *desc, const JssState *state, const int32_t *actions, const JssOut *out, void *stream);
+
+/* one increase_time_step() per env with which[i] != 0 (NULL = all); hole[i] = returned idle time (may be NULL) */
+int jss_advance(const JssDesc *desc, const JssState *state, const uint8_t *which, int32_t *hole, const JssOut *out,
+                void *stream);
+
+/* actions[i] = policy(state i); explore_q16 = probability (x 65536) of answering NOPE when NOPE is
+ * legal (the reference's rules use 0.1, dispatching.py:113; 0 = deterministic) */
+int jss_policy(const JssDesc *desc, const JssState *state, int kind, uint64_t seed, uint32_t explore_q16,
+               int32_t *actions, void *stream);
+
+/* n_iter x (policy + step) per env inside one launch, state held in registers */
+int jss_rollout(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
+                uint32_t explore_q16, int32_t n_iter, int32_t flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,25 @@
+"""jssenv_amd -- MI355X-native batched Job-Shop-Scheduling environment.
+
+Drop-in for the hot path of prosysscience/JSSEnv (``JssEnv.reset()/step()`` and
+what they call): ``make('jss-v1', env_config=...)`` / ``JssEnv`` keep the
+reference's single-env API, ``BatchedJssEnv`` runs thousands of envs per GPU
+with hand-written HIP kernels (``csrc/jss_kernels.hip``) behind a C ABI
+(``include/jss_hip.h``).
+"""
+from .instances import (Instance, available_instances, builtin_instance, load_instance_file,  # noqa: F401
+                        parse_instance_text, synthetic_batch, taillard_instance)
+from .env import BatchedJssEnv, HipBackend, JssEnv, make  # noqa: F401
+
+__version__ = "0.1.0"
+
+
+def _register_with_gymnasium():
+    """``gym.make('jss-v1', env_config=...)`` as in JSSEnv/__init__.py:6-9, when gymnasium exists."""
+    try:
+        from gymnasium.envs.registration import register
+        register(id="jss-v1", entry_point="jssenv_amd.env:JssEnv")
+    except Exception:
+        pass
+
+
+_register_with_gymnasium()

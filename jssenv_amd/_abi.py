@@ -1,0 +1,67 @@
+"""ctypes mirror of include/jss_hip.h (structs, constants, prototypes).
+
+Pure declarations: no torch, no device access.  ``bind(lib)`` attaches the
+prototypes to a loaded ``libjss_hip.so`` and fails loudly if a symbol the header
+declares is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+MAX_JOBS, MAX_MACHINES = 128, 64
+F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, NF = 0, 1, 2, 3, 4, 5, 6, 7
+F4_ONE = -1
+ERR_ILLEGAL_ACTION, ERR_NOPE_IDLE, ERR_BAD_ACTION = 1, 2, 4
+ACTION_SKIP = -1
+POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6}
+ROLLOUT_AUTORESET = 1
+
+SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_reset", "jss_step", "jss_advance", "jss_policy", "jss_rollout")
+
+_p = C.c_void_p
+
+
+class JssDesc(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("jmax", C.c_int32), ("mmax", C.c_int32), ("n_tables", C.c_int32),
+                ("ops", _p), ("jobs", _p), ("machines", _p), ("max_time_op", _p), ("max_time_jobs", _p),
+                ("sum_op", _p), ("table_of_env", _p), ("env_id_base", C.c_int64)]
+
+
+class JssState(C.Structure):
+    _fields_ = [("clock", _p), ("job", _p), ("machine", _p), ("action_mask", _p), ("blocked", _p),
+                ("solution", _p), ("episode", _p), ("step_in_episode", _p), ("err", _p), ("counters", _p)]
+
+
+class JssOut(C.Structure):
+    _fields_ = [("real_obs", _p), ("reward", _p), ("done", _p), ("makespan", _p)]
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libjss_hip.so")
+
+
+def bind(lib):
+    """Attach prototypes; raises AttributeError naming the first missing symbol."""
+    for name in SYMBOLS:
+        if not hasattr(lib, name):
+            raise AttributeError(f"libjss_hip.so does not export {name}")
+    D, S, O = C.POINTER(JssDesc), C.POINTER(JssState), C.POINTER(JssOut)
+    lib.jss_abi_version.restype, lib.jss_abi_version.argtypes = C.c_int, []
+    lib.jss_error_string.restype, lib.jss_error_string.argtypes = C.c_char_p, [C.c_int]
+    lib.jss_reset.restype, lib.jss_reset.argtypes = C.c_int, [D, S, O, _p, _p]
+    lib.jss_step.restype, lib.jss_step.argtypes = C.c_int, [D, S, _p, O, _p]
+    lib.jss_advance.restype, lib.jss_advance.argtypes = C.c_int, [D, S, _p, _p, O, _p]
+    lib.jss_policy.restype, lib.jss_policy.argtypes = C.c_int, [D, S, C.c_int, C.c_uint64, C.c_uint32, _p, _p]
+    lib.jss_rollout.restype = C.c_int
+    lib.jss_rollout.argtypes = [D, S, O, C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, _p]
+    if lib.jss_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libjss_hip.so ABI {lib.jss_abi_version()} != expected {ABI_VERSION}")
+    return lib
+
+
+def check(lib, rc: int, what: str):
+    if rc != 0:
+        msg = lib.jss_error_string(rc)
+        raise RuntimeError(f"{what} failed: {rc} ({msg.decode() if msg else '?'})")

@@ -474,7 +474,7 @@ int orc_policy(const OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32
          * over the set bits, NOPE included.  Index = floor(u32 * n / 2^32). */
         int n = 0;
         for (int a = 0; a <= J; ++a) n += legal[a] ? 1 : 0;
-        if (n == 0) return J;
+        if (n == 0) return -1; /* nothing legal (episode over): no action */
         uint32_t r = orc_rng_u32(seed, env_id, episode, step);
         int pick = (int)(((uint64_t)r * (uint64_t)n) >> 32);
         for (int a = 0; a <= J; ++a) {
@@ -488,7 +488,7 @@ int orc_policy(const OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32
     /* every rule: NOPE when it is the only legal action (dispatching.py:96-97, 137-138, ...) */
     int n_jobs_legal = 0;
     for (int j = 0; j < J; ++j) n_jobs_legal += legal[j] ? 1 : 0;
-    if (n_jobs_legal == 0) return J; /* includes sum==1 and legal[-1]; with nothing legal the rules return -1, we return NOPE */
+    if (n_jobs_legal == 0) return legal[J] ? J : -1; /* only NOPE legal -> NOPE; nothing legal -> -1 (the rules' min_job = -1) */
     int best = -1;
     long best_v = 0;
     for (int job = 0; job < J; ++job) {

@@ -1,0 +1,61 @@
+"""TEST INFRASTRUCTURE: a NumPy 'device' for jssenv_amd.BatchedJssEnv backed by
+tests/emu/libjss_emu.so (the unmodified kernel source compiled against the SIMT
+emulator).  Lets the host layer and the kernel logic run in a container without
+a GPU.  Never imported by the package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from jssenv_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libjss_emu.so")
+_SRC = [os.path.join(_HERE, "hip", "hip_runtime.h"),
+        os.path.join(_HERE, "..", "..", "jssenv_amd", "csrc", "jss_kernels.hip"),
+        os.path.join(_HERE, "..", "..", "include", "jss_hip.h")]
+
+
+def build(force=False):
+    stale = not os.path.isfile(_LIB) or any(os.path.getmtime(p) > os.path.getmtime(_LIB) for p in _SRC)
+    if force or stale:
+        subprocess.check_call([os.path.join(_HERE, "build_emu.sh")])
+    return _LIB
+
+
+class EmuBackend:
+    name = "emu"
+
+    def __init__(self):
+        self.lib = _abi.bind(C.CDLL(build()))
+        self._keep = []
+
+    def zeros(self, shape, dtype):
+        return np.zeros(shape, dtype=getattr(np, dtype))
+
+    def from_numpy(self, a):
+        return np.ascontiguousarray(a).copy()
+
+    def ptr(self, x):
+        if x is None:
+            return 0
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data
+
+    def numpy(self, x):
+        return np.array(x, copy=True)
+
+    def stream(self):
+        return 0
+
+    def sync(self):
+        pass
+
+    def as_device(self, x, dtype):
+        a = np.ascontiguousarray(np.asarray(x).astype(getattr(np, dtype)))
+        self._keep = [a]
+        return a
+
+    def shift_right(self, x, n):
+        return x >> n

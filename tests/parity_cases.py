@@ -1,0 +1,293 @@
+"""Parity cases shared by tests/test_kernel_emu.py (kernel source under the SIMT
+emulator, CPU) and tests/test_hip_parity.py (the real libjss_hip.so on an MI355X).
+
+Every case drives jssenv_amd through its public host API / the C ABI and compares with
+the CPU oracle (oracle/, pinned to the live reference by tests/test_oracle_golden.py) and
+with the golden vectors directly.  Bars: integers bit-exact; float32 observation and
+reward within 1e-6 of the reference's float64 (north_star)."""
+import numpy as np
+
+import golden_util as G
+from jssenv_amd import _abi
+from jssenv_amd import instances as I
+from jssenv_amd.env import BatchedJssEnv, JssEnv
+from oracle import OracleEnv
+
+OBS_TOL = 1e-6
+
+
+def assert_matches_oracle(h, orc, where, fresh_col0=True, check_outputs=True):
+    """h = BatchedJssEnv.host_state(i); orc = OracleEnv in the same state."""
+    J = orc.jobs
+    assert h["clock"] == orc.current_time_step, f"{where}: clock {h['clock']} != {orc.current_time_step}"
+    js = h["job_state"]
+    pairs = [(_abi.F_TODO, "todo_time_step_job"), (_abi.F_LEFT, "time_until_finish_current_op_jobs"),
+             (_abi.F_PERF, "total_perform_op_time_jobs"), (_abi.F_IDLE, "total_idle_time_jobs"),
+             (_abi.F_IDLE_LAST, "idle_time_jobs_last_op")]
+    for f, name in pairs:
+        want = getattr(orc, name)
+        assert (js[f] == want).all(), f"{where}: {name}\n got={js[f]}\nwant={want}"
+    need = js[_abi.F_CUR] >> 16
+    assert (need == orc.needed_machine_jobs).all(), f"{where}: needed_machine_jobs\n got={need}\nwant={orc.needed_machine_jobs}"
+    todo = orc.todo_time_step_job
+    for j in range(J):  # the packed current op carries the duration of op todo[j]
+        if todo[j] < orc.machines:
+            assert (js[_abi.F_CUR][j] & 0xFFFF) == orc.instance_matrix[j, todo[j], 1], f"{where}: cur dur job {j}"
+    assert (h["tm"] == orc.time_until_available_machine).all(), f"{where}: time_until_available_machine"
+    assert (h["mask"] == orc.legal_actions).all(), \
+        f"{where}: legal_actions\n got={h['mask'].astype(int)}\nwant={orc.legal_actions.astype(int)}"
+    assert (h["blocked"] == orc.action_illegal_no_op).all(), f"{where}: action_illegal_no_op"
+    assert (h["solution"] == orc.solution).all(), f"{where}: solution"
+    want_obs = orc.state
+    got_obs = h["obs"].astype(np.float64)
+    if not fresh_col0:
+        want_obs, got_obs = want_obs[:, 1:], got_obs[:, 1:]
+    err = np.abs(got_obs - want_obs).max()
+    assert err <= OBS_TOL, f"{where}: real_obs max |diff| {err}"
+    if check_outputs:
+        assert h["done"] == (orc.nb_legal_actions == 0), f"{where}: done"
+
+
+# -----------------------------------------------------------------------------------------
+# single-env facade (the reference's own API) against golden traces
+# -----------------------------------------------------------------------------------------
+def replay_golden_through_facade(backend, golden_name, inst, max_rows=None, check_every=1):
+    g = G.load(golden_name)
+    env = JssEnv({"instance_path": inst}, _backend=backend)
+    orc = OracleEnv(I.builtin_instance(inst))
+    env.reset()
+    orc.reset()
+    n = len(g["action"]) if max_rows is None else min(max_rows, len(g["action"]))
+    obs_rows = {int(s): k for k, s in enumerate(g["obs_step"])}
+    for i in range(n):
+        a = int(g["action"][i])
+        where = f"{golden_name} row {i} action {a}"
+        if a == -2:
+            env.reset()
+            orc.reset()
+        elif a == -1:
+            h1, h2 = env.increase_time_step(), orc.increase_time_step()
+            assert h1 == h2, f"{where}: hole {h1} != {h2}"
+        else:
+            _, r1, d1, t1, info = env.step(a)
+            _, r2, d2, _, _ = orc.step(a)
+            assert abs(r1 - g["reward"][i]) <= OBS_TOL and abs(r1 - r2) <= OBS_TOL, f"{where}: reward {r1} vs {g['reward'][i]}"
+            assert d1 == bool(g["done"][i]) == d2, f"{where}: done"
+            assert t1 is False and info == {}
+        # golden rows (the reference's own values) ...
+        G.check_env_against_row(env, g, i, where)
+        if i in obs_rows:
+            want = g["obs"][obs_rows[i]]
+            got = np.asarray(env.state, dtype=np.float64)
+            if a == -1:
+                want, got = want[:, 1:], got[:, 1:]
+            assert np.abs(got - want).max() <= OBS_TOL, f"{where}: obs vs golden {np.abs(got - want).max()}"
+        # ... and the full oracle state
+        if i % check_every == 0 or i == n - 1:
+            assert_matches_oracle(env._b.host_state(0), orc, where, fresh_col0=(a != -1), check_outputs=(a != -1))
+    return env, g, n == len(g["action"])
+
+
+def case_published(backend, inst, max_rows=None):
+    env, g, complete = replay_golden_through_facade(backend, f"published_{inst}", inst, max_rows)
+    if complete:
+        assert env.current_time_step == G.PUBLISHED_MAKESPAN[inst]
+        assert (env.solution == g["solution"]).all()
+        assert env.last_time_step == G.PUBLISHED_MAKESPAN[inst]
+        assert (env.todo_time_step_job == env.machines).all()
+        env.reset()
+        assert env.current_time_step == 0
+
+
+def case_random_golden(backend, inst, max_rows=None):
+    env, g, complete = replay_golden_through_facade(backend, f"random_{inst}", inst, max_rows)
+    if complete:
+        assert (env.solution == g["solution"]).all()
+
+
+# -----------------------------------------------------------------------------------------
+# batched API: ragged batch, on-device policies, every env compared with its own oracle
+# -----------------------------------------------------------------------------------------
+def case_batch_lockstep(backend, inst_names, batch, n_steps, kind="random", seed=11, nope_every=0, check_every=1,
+                        explore=0.0):
+    insts = [I.builtin_instance(n) if isinstance(n, str) else n for n in inst_names]
+    env = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=1000, _backend=backend)
+    orcs = [OracleEnv(insts[t], strict=True) for t in env.table_of_env_host]
+    env.reset()
+    for o in orcs:
+        o.reset()
+    be = env.backend
+    done_seen = np.zeros(batch, dtype=bool)
+    for it in range(n_steps):
+        acts = be.numpy(env.policy(kind, explore=explore)).astype(np.int64)
+        for i, o in enumerate(orcs):  # the device selector must agree with the oracle's (same counter RNG)
+            want = o.policy(kind, seed=seed, env_id=1000 + i, episode=o.episode, step=o.step_in_episode) \
+                if explore == 0.0 else None
+            if want is not None:
+                assert acts[i] == want, f"iter {it} env {i}: policy {kind} chose {acts[i]}, oracle {want}"
+        if nope_every and it % nope_every == nope_every - 1:
+            # force NOPE against the mask on some envs that have a busy machine (the fixtures do this)
+            for i, o in enumerate(orcs):
+                if i % 2 == 0 and len(o.next_time_step) > 0 and o.nb_legal_actions > 0:
+                    acts[i] = o.jobs
+        _, reward, done, trunc, info = env.step(acts)
+        reward, done = be.numpy(reward), be.numpy(done)
+        for i, o in enumerate(orcs):
+            if acts[i] == -1:
+                continue
+            _, r, d, _, _ = o.step(int(acts[i]))
+            assert abs(float(reward[i]) - r) <= OBS_TOL, f"iter {it} env {i}: reward {reward[i]} vs {r}"
+            assert bool(done[i]) == d, f"iter {it} env {i}: done"
+            done_seen[i] |= d
+        if it % check_every == 0 or it == n_steps - 1:
+            for i, o in enumerate(orcs):
+                h = env.host_state(i)
+                assert_matches_oracle(h, o, f"iter {it} env {i} ({o.instance.name}) action {acts[i]}")
+                assert h["err"] == o.err, f"iter {it} env {i}: err {h['err']} vs {o.err}"
+                assert h["step_in_episode"] == o.step_in_episode
+        if done_seen.all():
+            break
+    return env, orcs
+
+
+def case_rollout(backend, inst_names, batch, n_iter, kind="random", seed=5, chunks=(1,), autoreset=True):
+    """jss_rollout (fused policy+step, auto-restart) against orc_rollout: same counter RNG, so
+    final state, counters and makespans must agree exactly."""
+    insts = [I.builtin_instance(n) for n in inst_names]
+    env = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=77, _backend=backend)
+    orcs = [OracleEnv(insts[t], strict=True) for t in env.table_of_env_host]
+    env.reset()
+    tot = [dict(steps=0, episodes=0, makespan_sum=0, reward_sum=0.0) for _ in orcs]
+    ep = [1] * batch
+    st = [0] * batch
+    for o in orcs:
+        o.reset()
+    for chunk in chunks:
+        env.rollout(kind, n_iter=chunk, seed=seed, autoreset=autoreset)
+        for i, o in enumerate(orcs):
+            if autoreset:
+                r = o.rollout(kind, seed, 77 + i, chunk, episode=ep[i], step_in_episode=st[i])
+                ep[i], st[i] = r["episode"], r["step_in_episode"]
+                for k in ("steps", "episodes", "makespan_sum", "reward_sum"):
+                    tot[i][k] += r[k]
+            else:
+                for _ in range(chunk):
+                    if o.nb_legal_actions == 0:
+                        break
+                    a = o.policy(kind, seed=seed, env_id=77 + i, episode=ep[i], step=st[i])
+                    _, rew, d, _, _ = o.step(a)
+                    st[i] += 1
+                    tot[i]["steps"] += 1
+                    tot[i]["reward_sum"] += rew
+                    if d:
+                        tot[i]["episodes"] += 1
+                        tot[i]["makespan_sum"] += o.current_time_step
+    cnt = env.backend.numpy(env.counters)
+    for i, o in enumerate(orcs):
+        h = env.host_state(i)
+        assert_matches_oracle(h, o, f"rollout env {i} ({o.instance.name})")
+        assert h["episode"] == ep[i] and h["step_in_episode"] == st[i], f"env {i}: rng position"
+        assert cnt[i, 0] == tot[i]["steps"], f"env {i}: steps {cnt[i, 0]} vs {tot[i]['steps']}"
+        assert cnt[i, 1] == tot[i]["episodes"], f"env {i}: episodes"
+        assert cnt[i, 2] == tot[i]["makespan_sum"], f"env {i}: makespan sum"
+        assert abs(cnt[i, 3] / o.max_time_op - tot[i]["reward_sum"]) < 1e-6, f"env {i}: reward sum"
+        assert h["err"] == 0
+    return env, orcs
+
+
+def case_rule_makespans(backend, rules=("FIFO", "SPT", "MWR", "LWR", "MOR", "LOR"), insts=("ta01", "ta41")):
+    """G3: deterministic rule makespans of the live reference, reproduced by device rollouts."""
+    g = G.load("rules")
+    rnames, inames = [str(r) for r in g["rules"]], [str(i) for i in g["instances"]]
+    for inst in insts:
+        inst_obj = I.builtin_instance(inst)
+        for rule in rules:
+            one = BatchedJssEnv(inst_obj, batch=2, _backend=backend)
+            one.reset()
+            one.rollout(rule, n_iter=2 * inst_obj.jobs * inst_obj.machines, autoreset=False)
+            h = one.host_state(1)
+            want = int(g["makespan"][rnames.index(rule), inames.index(inst)])
+            assert h["done"] and h["makespan"] == want == h["clock"], f"{rule} {inst}: {h['makespan']} vs {want}"
+            total = one.backend.numpy(one.counters)[1, 3] / inst_obj.max_time_op
+            assert abs(total - g["total_reward"][rnames.index(rule), inames.index(inst)]) < 1e-6
+            assert (h["solution"] >= 0).all()
+
+
+def case_error_semantics(backend):
+    """Behaviour outside the reference's contract is total and flagged (include/jss_hip.h JSS_ERR_*)."""
+    inst = I.builtin_instance("ta01")
+    env = BatchedJssEnv(inst, batch=5, _backend=backend)
+    orcs = [OracleEnv(inst, strict=True) for _ in range(5)]
+    env.reset()
+    for o in orcs:
+        o.reset()
+    J = inst.jobs
+    # env0: NOPE at t=0 with nothing busy; env1: legal job; env2: skip; env3: out of range; env4: legal job
+    acts = np.array([J, 3, -1, J + 5, 7], dtype=np.int32)
+    env.step(acts)
+    for i in (0, 1, 3, 4):
+        orcs[i].step(int(acts[i]))
+    errs = [env.host_state(i)["err"] for i in range(5)]
+    assert errs == [_abi.ERR_NOPE_IDLE, 0, 0, _abi.ERR_BAD_ACTION, 0], errs
+    for i in range(5):
+        assert_matches_oracle(env.host_state(i), orcs[i], f"err case env {i}")
+    assert env.host_state(0)["done"] is True and env.host_state(2)["step_in_episode"] == 0
+    # repeat a running job: outside the mask -> ignored + flagged, state untouched
+    before = env.host_state(1)
+    env.step(np.array([-1, 3, -1, -1, -1], dtype=np.int32))
+    orcs[1].step(3)
+    after = env.host_state(1)
+    assert after["err"] == _abi.ERR_ILLEGAL_ACTION == orcs[1].err
+    assert (after["job_state"] == before["job_state"]).all() and after["reward"] == 0.0
+    assert_matches_oracle(after, orcs[1], "illegal action")
+    # partial reset clears the flags of the chosen envs only
+    env.reset(which=np.array([1, 0, 0, 0, 0], dtype=np.uint8))
+    orcs[0].reset()
+    assert env.host_state(0)["err"] == 0 and env.host_state(3)["err"] == _abi.ERR_BAD_ACTION
+    assert_matches_oracle(env.host_state(0), orcs[0], "after partial reset")
+    assert env.host_state(0)["episode"] == 2 and env.host_state(1)["episode"] == 1
+
+
+def case_facade_errors(backend):
+    env = JssEnv({"instance_path": "ta01"}, _backend=backend)
+    env.reset()
+    try:
+        env.step(env.jobs)
+        raise AssertionError("NOPE with nothing busy must raise like the reference")
+    except IndexError:
+        pass
+    env.reset()
+    env.step(0)
+    try:
+        env.step(0)
+        raise AssertionError("illegal job must raise")
+    except ValueError:
+        pass
+    try:
+        env.step(env.jobs + 3)
+        raise AssertionError("out-of-range action must raise")
+    except IndexError:
+        pass
+
+
+def case_state_invariants(backend, episodes=3, inst="ta01"):
+    """The reference's tests/test_state.py:8-76 on the facade with the device random policy."""
+    env = JssEnv({"instance_path": inst}, _backend=backend)
+    for ep in range(episodes):
+        state = env.reset()
+        assert env.current_time_step == 0
+        done = False
+        while not done:
+            legal = env.get_legal_actions()
+            a = env._policy("random")
+            assert legal[a]
+            assert legal[:-1].sum() == env.nb_legal_actions
+            state, r, done, _, _ = env.step(a)
+            obs = state["real_obs"]
+            assert obs.max() <= 1.0 and obs.min() >= 0.0 and np.isfinite(obs).all()
+            avail = {int(env.needed_machine_jobs[j]) for j in range(env.jobs) if env.legal_actions[j]}
+            assert len(avail) == env.nb_machine_legal
+        assert len(env.next_time_step) == 0
+        assert env.solution.min() != -1
+        assert (env.todo_time_step_job == env.machines).all()
+        assert env.last_time_step == env.current_time_step

@@ -1,0 +1,92 @@
+"""CPU-only checks of the boundary and the host logic: the C-ABI library loads and exports
+every symbol include/jss_hip.h declares; instance parsing / Taillard generator; the product
+refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from jssenv_amd import _abi
+from jssenv_amd import instances as I
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    from jssenv_amd.build import build_extension
+    return ctypes.CDLL(build_extension())
+
+
+def test_header_symbols_exported(hip_lib):
+    hdr = open(os.path.join(ROOT, "include", "jss_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*\*?(jss_\w+)\(", hdr, flags=re.M))
+    assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
+    for name in declared:
+        assert hasattr(hip_lib, name), name
+    _abi.bind(hip_lib)
+    assert hip_lib.jss_abi_version() == _abi.ABI_VERSION
+    assert b"null" in hip_lib.jss_error_string(-1)
+
+
+def test_header_constants_match_python_mirror():
+    hdr = open(os.path.join(ROOT, "include", "jss_hip.h")).read()
+    defs = {k: int(v) for k, v in re.findall(r"#define (JSS_\w+) \(?(-?\d+)\)?", hdr)}
+    assert defs["JSS_NF"] == _abi.NF and defs["JSS_F_CUR"] == _abi.F_CUR and defs["JSS_F_F4"] == _abi.F_F4
+    assert defs["JSS_MAX_JOBS"] == _abi.MAX_JOBS == I.MAX_JOBS and defs["JSS_MAX_MACHINES"] == I.MAX_MACHINES
+    assert defs["JSS_ERR_NOPE_IDLE"] == _abi.ERR_NOPE_IDLE and defs["JSS_ERR_ILLEGAL_ACTION"] == _abi.ERR_ILLEGAL_ACTION
+    for name, kid in _abi.POLICY.items():
+        assert defs["JSS_POLICY_" + name.upper()] == kid
+    assert ctypes.sizeof(_abi.JssDesc) == 16 + 7 * 8 + 8 and ctypes.sizeof(_abi.JssState) == 80
+
+
+def test_argument_errors_without_gpu(hip_lib):
+    _abi.bind(hip_lib)
+    d, s, o = _abi.JssDesc(), _abi.JssState(), _abi.JssOut()
+    assert hip_lib.jss_reset(ctypes.byref(d), ctypes.byref(s), ctypes.byref(o), None, None) == -1   # JSS_E_NULL
+    assert hip_lib.jss_policy(None, None, 0, 0, 0, None, None) == -1
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from jssenv_amd import BatchedJssEnv, make
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        BatchedJssEnv("ta01", batch=4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        make("jss-v1", env_config={"instance_path": "ta01"})
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "jssenv_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "libjss_oracle" not in src, f
+
+
+def test_instances_roundtrip_and_taillard():
+    assert len(I.available_instances()) == 85
+    ta01 = I.builtin_instance("ta01")
+    gen = I.taillard_instance(15, 15, 840612802, 398197754)
+    assert (ta01.machine == gen.machine).all() and (ta01.duration == gen.duration).all()
+    assert (ta01.jobs, ta01.machines, ta01.max_time_op) == (15, 15, 99)
+    again = I.parse_instance_text(ta01.to_text())
+    assert (again.packed() == ta01.packed()).all()
+    assert I.builtin_instance("ta80").jobs == 100 and I.builtin_instance("dmu16").max_time_op == 200
+    pk = I.pack_batch([ta01, I.builtin_instance("ta80")])
+    assert pk.ops.shape == (2, 100, 20) and pk.ops[0, 15:].max() == 0 and pk.jobs.tolist() == [15, 100]
+    for row in ta01.machine:
+        assert sorted(row.tolist()) == list(range(15))
+    syn = I.synthetic_batch(3, 50, 20)
+    assert syn[2].duration.min() >= 1 and syn[2].duration.max() <= 99 and syn[0].packed().shape == (50, 20)
+
+
+@pytest.mark.parametrize("text", ["", "2 2\n0 1 1 1\n", "2 2\n0 1 1 1\n0 1\n", "2 1\n0 3\n0 4\n", "2 2\n0 0 1 1\n1 1 0 1\n",
+                                  "2 2\n0 1 2 1\n1 1 0 1\n"])
+def test_parser_rejects_malformed(text):
+    with pytest.raises(ValueError):
+        I.parse_instance_text(text)

@@ -1,0 +1,155 @@
+"""Parity of the real HIP path (libjss_hip.so on an MI355X) with the oracle and the golden
+vectors, through the public host API / C ABI.  Run with -m gpu on the GPU box."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import parity_cases as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from jssenv_amd.env import HipBackend
+    be = HipBackend("cuda:0")
+    assert be.name == "hip"
+    return be
+
+
+@pytest.mark.parametrize("inst", G.PUBLISHED)
+def test_published_schedules(hip, inst):
+    """G1: makespan and machine/job schedules of the reference's tests/test_solutions.py, bit-exact."""
+    P.case_published(hip, inst)
+
+
+@pytest.mark.parametrize("inst", G.RANDOM)
+def test_random_golden(hip, inst):
+    """G2: random traces incl. NOPEs forced against the mask; ta80 = two jobs per lane."""
+    P.case_random_golden(hip, inst)
+
+
+def test_batch_ragged_random_policy(hip):
+    names = ["ta01", "ta11", "ta21", "ta31", "ta41", "ta51", "ta61", "ta71", "dmu16"]
+    P.case_batch_lockstep(hip, names, batch=27, n_steps=400, kind="random", nope_every=9, check_every=7)
+
+
+@pytest.mark.parametrize("kind", ["FIFO", "SPT", "MWR", "LWR", "MOR", "LOR"])
+def test_batch_rules(hip, kind):
+    P.case_batch_lockstep(hip, ["ta01", "ta21", "ta72"], batch=6, n_steps=2500, kind=kind, check_every=25)
+
+
+def test_rollout_autoreset(hip):
+    P.case_rollout(hip, ["ta01"], batch=64, n_iter=0, chunks=(300, 1, 1, 555))
+
+
+def test_rollout_ragged(hip):
+    P.case_rollout(hip, ["ta02", "ta72", "ta45", "dmu17"], batch=16, n_iter=0, chunks=(512, 700), kind="random")
+    P.case_rollout(hip, ["ta02", "ta72"], batch=4, n_iter=0, chunks=(400,), kind="SPT", autoreset=False)
+
+
+def test_rule_makespans(hip):
+    """G3: ta01 FIFO 1486 / SPT 1462, ta41 SPT 2499 ... as captured from the live reference."""
+    P.case_rule_makespans(hip, insts=("ta01", "ta41", "ta80"))
+
+
+def test_error_semantics(hip):
+    P.case_error_semantics(hip)
+    P.case_facade_errors(hip)
+
+
+def test_state_invariants(hip):
+    P.case_state_invariants(hip, episodes=5)
+
+
+def test_config2_ta01_batch4096_random(hip):
+    """BASELINE config 2 at full size: size-independent properties on every env + oracle on a sample."""
+    from jssenv_amd import BatchedJssEnv, builtin_instance
+    from oracle import OracleEnv
+    inst = builtin_instance("ta01")
+    B, seed = 4096, 9
+    env = BatchedJssEnv(inst, batch=B, seed=seed, _backend=hip)
+    env.reset()
+    env.rollout("random", n_iter=400, autoreset=False)   # every episode ends well before 400 steps
+    done = env.done.cpu().numpy()
+    assert done.all()
+    sol = env.solution.cpu().numpy()
+    assert (sol >= 0).all()
+    todo = env.todo_time_step_job.cpu().numpy()
+    assert (todo == inst.machines).all()
+    cnt = env.counters.cpu().numpy()
+    mk = env.makespan.cpu().numpy()
+    assert (cnt[:, 1] == 1).all() and (cnt[:, 2] == mk).all() and (mk == env.clock.cpu().numpy()).all()
+    # reward identity: sum of reward numerators = 2*sum_op - M*makespan
+    assert (cnt[:, 3] == 2 * inst.sum_op - inst.machines * mk).all()
+    # schedule validity: ops of a job in order, no overlap on a machine
+    dur, mach = inst.duration, inst.machine
+    end = sol + dur[None]
+    assert (sol[:, :, 1:] >= end[:, :, :-1]).all()
+    assert (end.max(axis=(1, 2)) == mk).all()
+    for b in range(0, B, 97):
+        for m in range(inst.machines):
+            sel = mach == m
+            s, e = sol[b][sel], end[b][sel]
+            order = np.argsort(s)
+            assert (s[order][1:] >= e[order][:-1]).all()
+    assert env.err.cpu().numpy().max() == 0
+    # oracle comparison without auto-restart
+    for i in range(0, B, 173):
+        orc = OracleEnv(inst, strict=True)
+        orc.reset()
+        st = 0
+        while orc.nb_legal_actions:
+            orc.step(orc.policy("random", seed=seed, env_id=i, episode=1, step=st))
+            st += 1
+        assert orc.current_time_step == mk[i] and (orc.solution == sol[i]).all() and st == cnt[i, 0]
+
+
+def test_config3_ta41_spt_batch16384(hip):
+    """BASELINE config 3: ta41, SPT, every env 600 steps and makespan 2499 (G3)."""
+    from jssenv_amd import BatchedJssEnv, builtin_instance
+    inst = builtin_instance("ta41")
+    env = BatchedJssEnv(inst, batch=16384, _backend=hip)
+    env.reset()
+    env.rollout("SPT", n_iter=1000, autoreset=False)
+    assert (env.makespan.cpu().numpy() == 2499).all()
+    assert (env.counters.cpu().numpy()[:, 0] == 600).all()
+    sol = env.solution.cpu().numpy()
+    assert (sol == sol[0]).all()
+
+
+def test_config5_mixed_ta01_ta80_padded(hip):
+    """BASELINE config 5 (reduced batch): env i <- ta(1 + i % 80), padded 100x20, ragged J/M."""
+    from jssenv_amd import BatchedJssEnv, builtin_instance
+    from oracle import OracleEnv
+    insts = [builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
+    B, seed = 1600, 21
+    env = BatchedJssEnv(insts, batch=B, seed=seed, _backend=hip)
+    env.reset()
+    env.rollout("random", n_iter=700, autoreset=True)
+    cnt = env.counters.cpu().numpy()
+    assert env.err.cpu().numpy().max() == 0
+    for i in list(range(0, 80, 9)) + [79, 80 + 70, 1599]:
+        orc = OracleEnv(insts[i % 80], strict=True)
+        orc.reset()
+        r = orc.rollout("random", seed, i, 700, episode=1, step_in_episode=0)
+        P.assert_matches_oracle(env.host_state(i), orc, f"mixed env {i}")
+        assert cnt[i, 0] == r["steps"] and cnt[i, 1] == r["episodes"] and cnt[i, 2] == r["makespan_sum"]
+
+
+def test_config4_synthetic_50x20(hip):
+    """BASELINE config 4 (one GPU's share, reduced): Taillard-LCG 50x20 instances, one table per env."""
+    from jssenv_amd import BatchedJssEnv, synthetic_batch
+    from oracle import OracleEnv
+    insts = synthetic_batch(256, 50, 20)
+    seed = 4
+    env = BatchedJssEnv(insts, seed=seed, _backend=hip)
+    env.reset()
+    env.rollout("random", n_iter=1500, autoreset=True)
+    cnt = env.counters.cpu().numpy()
+    for i in range(0, 256, 4):   # a 64-env sample against the oracle
+        orc = OracleEnv(insts[i], strict=True)
+        orc.reset()
+        r = orc.rollout("random", seed, i, 1500, episode=1, step_in_episode=0)
+        P.assert_matches_oracle(env.host_state(i), orc, f"synthetic env {i}")
+        assert cnt[i, 0] == r["steps"] and cnt[i, 2] == r["makespan_sum"]

@@ -1,0 +1,69 @@
+"""Kernel logic under the SIMT emulator (tests/emu): the unmodified
+jssenv_amd/csrc/jss_kernels.hip compiled with g++ and executed lane by lane on the CPU,
+driven through the same host layer and C ABI as on the GPU.  Sizes are small (the
+emulator runs ~250 env-steps/s); the full-size runs live in tests/test_hip_parity.py."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+import parity_cases as P  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu_backend import EmuBackend
+    return EmuBackend()
+
+
+def test_published_ta01(emu):
+    P.case_published(emu, "ta01")
+
+
+def test_published_ta41_prefix(emu):
+    P.case_published(emu, "ta41", max_rows=260)
+
+
+def test_random_golden_ta01(emu):
+    P.case_random_golden(emu, "ta01", max_rows=300)
+
+
+def test_random_golden_ta80_two_jobs_per_lane(emu):
+    P.case_random_golden(emu, "ta80", max_rows=180)
+
+
+def test_random_golden_dmu16(emu):
+    P.case_random_golden(emu, "dmu16", max_rows=150)
+
+
+def test_batch_ragged_random_policy(emu):
+    P.case_batch_lockstep(emu, ["ta01", "ta31", "ta51", "ta71"], batch=6, n_steps=90, kind="random", nope_every=7,
+                          check_every=3)
+
+
+@pytest.mark.parametrize("kind", ["FIFO", "SPT", "MWR", "LWR", "MOR", "LOR"])
+def test_batch_rules(emu, kind):
+    P.case_batch_lockstep(emu, ["ta01", "ta21"], batch=3, n_steps=60, kind=kind, check_every=5)
+
+
+def test_rollout_autoreset(emu):
+    P.case_rollout(emu, ["ta01"], batch=5, n_iter=None or 300, chunks=(120, 1, 179))
+
+
+def test_rollout_ragged(emu):
+    P.case_rollout(emu, ["ta02", "ta72"], batch=3, n_iter=0, chunks=(64, 40), kind="SPT")
+
+
+def test_rule_makespan_ta01(emu):
+    P.case_rule_makespans(emu, rules=("FIFO", "SPT", "MOR"), insts=("ta01",))
+
+
+def test_error_semantics(emu):
+    P.case_error_semantics(emu)
+    P.case_facade_errors(emu)
+
+
+def test_state_invariants(emu):
+    P.case_state_invariants(emu, episodes=1)
