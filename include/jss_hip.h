@@ -131,6 +131,14 @@ typedef struct JssOut {
 int jss_abi_version(void);
 const char *jss_error_string(int code);
 
+/* process-wide options.  JSS_OPT_KERNEL: JSS_KERNEL_AUTO packs 64/G envs per wavefront when every
+ * env of the batch fits a 16- or 32-lane group (jmax, mmax <= 32) and uses one wavefront per env
+ * otherwise; JSS_KERNEL_WAVE forces one wavefront per env (A/B runs, tests). */
+#define JSS_OPT_KERNEL 0
+#define JSS_KERNEL_AUTO 0
+#define JSS_KERNEL_WAVE 1
+int jss_set_option(int option, int value);
+
 /* reset every env (which == NULL) or the envs with which[i] != 0 */
 int jss_reset(const JssDesc *desc, const JssState *state, const JssOut *out, const uint8_t *which, void *stream);
 

@@ -17,8 +17,9 @@ ERR_ILLEGAL_ACTION, ERR_NOPE_IDLE, ERR_BAD_ACTION = 1, 2, 4
 ACTION_SKIP = -1
 POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6}
 ROLLOUT_AUTORESET = 1
+OPT_KERNEL, KERNEL_AUTO, KERNEL_WAVE = 0, 0, 1
 
-SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_reset", "jss_step", "jss_advance", "jss_policy", "jss_rollout")
+SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_set_option", "jss_reset", "jss_step", "jss_advance", "jss_policy", "jss_rollout")
 
 _p = C.c_void_p
 
@@ -50,6 +51,7 @@ def bind(lib):
     D, S, O = C.POINTER(JssDesc), C.POINTER(JssState), C.POINTER(JssOut)
     lib.jss_abi_version.restype, lib.jss_abi_version.argtypes = C.c_int, []
     lib.jss_error_string.restype, lib.jss_error_string.argtypes = C.c_char_p, [C.c_int]
+    lib.jss_set_option.restype, lib.jss_set_option.argtypes = C.c_int, [C.c_int, C.c_int]
     lib.jss_reset.restype, lib.jss_reset.argtypes = C.c_int, [D, S, O, _p, _p]
     lib.jss_step.restype, lib.jss_step.argtypes = C.c_int, [D, S, _p, O, _p]
     lib.jss_advance.restype, lib.jss_advance.argtypes = C.c_int, [D, S, _p, _p, O, _p]

@@ -1,0 +1,108 @@
+// jssenv_amd/csrc/jss_kernels.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI of the
+// batched Job-Shop-Scheduling simulator.  Interface and layout: include/jss_hip.h.
+//
+// Execution model
+//   * one 64-lane wavefront simulates one env; job j sits on lane j%64 (slot j/64,
+//     JPL = 1 or 2 slots), machine m on lane m.  256-thread workgroups = 4 envs in
+//     flight per workgroup, waves grid-stride over the batch.
+//   * the env's whole state lives in registers for the duration of the call:
+//     7 int32 per job (VGPRs), the machine clocks (one VGPR, lane = machine) and the
+//     legal / blocked job sets as wave-uniform 64-bit masks (SGPR pairs), so
+//     nb_legal_actions is one s_bcnt1 and "any legal" one s_cmp.
+//   * the op table (machine << 16 | duration) is staged in LDS: once per workgroup
+//     when the batch shares one instance, once per env otherwise; the look-ahead
+//     walk of _check_no_op is a per-lane chain of ds_read_b32.
+//   * cross-lane work: __ballot for every "for job in range(J)" predicate of the
+//     reference, a butterfly min for the next event time, readlane for the (<= 4)
+//     legal jobs the order-dependent pass of _check_no_op walks through.
+//   * no MFMA: the path is integer indexing, there is no dense contraction.
+//
+// Semantics follow the reference JSSEnv/envs/jss_env.py (cited per function) in the
+// queue-free form: the reference's sorted event list `next_time_step` always equals
+// the distinct values {t + tm[m] : tm[m] > 0}, its M x J `illegal_actions` matrix
+// equals blocked[j] && need[j] == m, and nb_legal_actions / nb_machine_legal /
+// machine_legal are functions of the legal set (tests/ checks all of this against
+// the oracle step by step).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jss_hip.h"
+
+namespace jss {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kMaxBlocks = 2048;  // 8192 waves = every wave slot of the chip (256 CUs x 32)
+constexpr int kBig = 0x3fffffff;
+constexpr int kDurMask = 0xffff;
+
+enum Mode { kReset = 0, kStep = 1, kAdvance = 2, kPolicy = 3, kRollout = 4 };
+
+struct Params {
+    JssDesc d;
+    JssState s;
+    JssOut o;
+    const int32_t *actions;  // kStep
+    int32_t *actions_out;    // kPolicy
+    const uint8_t *which;    // kReset / kAdvance
+    int32_t *hole;           // kAdvance
+    uint64_t seed;
+    uint32_t explore_q16;
+    int32_t kind;
+    int32_t n_iter;
+    int32_t flags;
+    int32_t stride;       // LDS row stride of the op table (= mmax: rows are copied verbatim)
+    int32_t region_ints;  // LDS ints per staged table
+    int32_t shared_table; // 1: one table for the whole batch, staged once per workgroup
+};
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// LDS writes of one wave consumed by other lanes of the same wave
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Counter RNG, identical to oracle/jss_oracle.c orc_rng_u32: four rounds of a 32-bit
+// finaliser keyed by (seed, env, episode, step).  32-bit on purpose: the packed kernel
+// evaluates it per lane on the VALU, where a 64-bit multiply costs 4+ instructions.
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step) {
+    uint32_t h = fmix32((uint32_t)seed ^ (uint32_t)env_id);
+    h = fmix32(h ^ ((uint32_t)(seed >> 32) + 0x9E3779B9u * (uint32_t)(env_id >> 32)));
+    h = fmix32(h ^ episode);
+    return fmix32(h + step);
+}
+constexpr uint64_t kExploreSeedXor = 0x5851F42D4C957F2DULL;
+
+}  // namespace jss

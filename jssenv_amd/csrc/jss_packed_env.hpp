@@ -1,0 +1,563 @@
+#pragma once
+// Packed kernel: 64/G envs per wavefront, G = 16 or 32 lanes per env (J <= G, M <= G).
+//
+// On ta01-shaped instances (15 x 15) a wave-per-env kernel keeps 15 of 64 lanes busy and is
+// instruction-issue bound (profiles/r01_wave_per_env).  Here every env owns an aligned group of
+// G lanes: job j on group lane j, machine m on group lane m, and everything the wave kernel
+// keeps wave-uniform in SGPRs (clock, legal set, loop conditions) becomes group-uniform values
+// replicated in VGPRs.  Cross-lane traffic stays inside a group:
+//   * reductions (next event time, arg-best of a rule) are DPP row operations -- a 16-lane DPP
+//     row is exactly one env at G = 16; G = 32 adds one ds_swizzle (lane ^ 16);
+//   * "for job in range(J)" predicates are one __ballot, each lane then shifts out its group's
+//     bits;
+//   * reading job a's / machine m's register is one ds_bpermute inside the group.
+// Data-dependent loops (`while nb_machine_legal == 0: increase_time_step()`) run while ANY group
+// of the wave still needs them, with the state updates predicated per group.
+//
+// Semantics and citations are the same as jss_wave_env.hpp (reference JSSEnv/envs/jss_env.py).
+#include "jss_common.hpp"
+
+namespace jss {
+
+template <int G>
+struct PCtx {                 // per-lane view of "my env"
+    int lane, gl, gbase;      // gl = lane within the group, gbase = first lane of the group
+    int b;                    // env index (clamped to batch-1 for dead groups)
+    bool alive;               // b < batch
+    bool jvalid, mvalid;      // gl < J, gl < M
+    int J, M, max_time_op, max_time_jobs, sum_op;
+    const int32_t *ops;       // LDS op table of my env, row stride `stride`
+    int stride;
+};
+
+template <int G>
+struct PEnv {
+    int t;                    // group-uniform
+    int todo, cur, left, perf, idle, idle_last, f4;  // job gl
+    int tm;                   // machine gl
+    bool legal, blocked;      // job gl
+    int noop, err;            // group-uniform
+};
+
+template <int G>
+__device__ __forceinline__ uint32_t grp_ballot(bool p, int gbase) {
+    const uint64_t w = __ballot(p);
+    const uint32_t x = (uint32_t)(w >> gbase);
+    return G == 32 ? x : (x & 0xFFFFu);
+}
+
+template <int G>
+__device__ __forceinline__ bool grp_any(bool p, int gbase) {
+    return grp_ballot<G>(p, gbase) != 0;
+}
+
+// value of `v` on group lane `idx` (idx group-uniform or not, any lane may ask for any lane)
+template <int G>
+__device__ __forceinline__ int grp_read(int v, int idx, int gbase) {
+    return __builtin_amdgcn_ds_bpermute((gbase + (idx & (G - 1))) << 2, v);
+}
+
+#define JSS_DPP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xF, 0xF, false)
+
+template <int G>
+__device__ __forceinline__ int grp_min(int v) {
+    v = imin(v, JSS_DPP(v, 0xB1));   // quad_perm [1,0,3,2]   lane ^ 1
+    v = imin(v, JSS_DPP(v, 0x4E));   // quad_perm [2,3,0,1]   lane ^ 2
+    v = imin(v, JSS_DPP(v, 0x141));  // row_half_mirror       quads 0<->1, 2<->3 (quads are uniform by now)
+    v = imin(v, JSS_DPP(v, 0x140));  // row_mirror            halves of the 16-lane row
+    if (G == 32) v = imin(v, __builtin_amdgcn_ds_swizzle(v, 0x401F));  // lane ^ 16
+    return v;
+}
+
+template <int G>
+__device__ __forceinline__ int grp_max(int v) {
+    v = imax(v, JSS_DPP(v, 0xB1));
+    v = imax(v, JSS_DPP(v, 0x4E));
+    v = imax(v, JSS_DPP(v, 0x141));
+    v = imax(v, JSS_DPP(v, 0x140));
+    if (G == 32) v = imax(v, __builtin_amdgcn_ds_swizzle(v, 0x401F));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// reset(): jss_env.py:145-181 (registers only; `on` = groups being reset)
+// ---------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G> &c, const Params &p, bool on) {
+    if (on) {
+        e.t = 0;                                                         // :154
+        e.tm = 0;                                                        // :164
+        e.noop = 0;                                                      // :161
+        e.err = 0;
+        e.todo = 0;                                                      // :166
+        e.cur = c.jvalid ? c.ops[c.gl * c.stride] : -1;                  // :174-176
+        e.left = e.perf = e.idle = e.idle_last = 0;                      // :165-170
+        e.f4 = 0;                                                        // :180
+        e.legal = c.jvalid;                                              // :160
+        e.blocked = false;                                               // :171-172
+        if (c.alive) {                                                   // solution = -1 (:163)
+            int32_t *sol = p.s.solution + (size_t)c.b * p.d.jmax * p.d.mmax;
+            const int n = c.J * p.d.mmax;
+            for (int i = c.gl; i < n; i += G) sol[i] = -1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// increase_time_step(): jss_env.py:495-637 for the groups with `act`; returns hole_planning.
+// ---------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act) {
+    const int d = grp_min<G>(e.tm > 0 ? e.tm : kBig);                    // :517-522 next event = earliest release
+    const int idle_machines = __popc(grp_ballot<G>(c.mvalid && e.tm < d, c.gbase));
+    const int hole = d * idle_machines;                                  // :606-608 (tm < d only when tm == 0)
+    bool fin = false;
+    if (act) {
+        e.t += d;
+        const int was = e.left;
+        if (was > 0) {                                                   // :529 running
+            const int nl = imax(0, was - d);                             // :534
+            e.perf += imin(d, was);                                      // :531,:544
+            e.left = nl;
+            if (nl == 0) {                                               // :550 op finished
+                e.idle += d - was;                                       // :552
+                e.idle_last = d - was;                                   // :554
+                e.todo += 1;                                             // :558
+                fin = true;
+            }
+        } else if (c.jvalid && e.todo < c.M) {                           // :594 waiting
+            e.idle += d;                                                 // :596
+            e.idle_last += d;                                            // :597
+        }
+        e.tm = imax(0, e.tm - d);                                        // :611
+        if (fin) e.cur = e.todo < c.M ? c.ops[c.gl * c.stride + e.todo] : -1;  // :562-566 / :581
+    }
+    // time left on the machine my job needs (after the update): feature-4 numerator
+    // max(0, tm_old[need] - d) (:569-578) and the "machine is free" test of :616 in one read
+    const int tm_need = grp_read<G>(e.tm, e.cur >> 16, c.gbase);
+    if (fin) e.f4 = e.cur >= 0 ? tm_need : JSS_F4_ONE;                   // :586
+    // re-legalisation :616-634: need[j] free, not legal, not blocked (a finished job has cur = -1)
+    if (act && c.jvalid && e.cur >= 0 && tm_need == 0 && !e.blocked) e.legal = true;
+    return hole;
+}
+
+// ---------------------------------------------------------------------------------------
+// _prioritization_non_final(): jss_env.py:183-254 for the groups with `on`
+// ---------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void p_prioritize(PEnv<G> &e, const PCtx<G> &c, bool on) {
+    const bool fin = on && e.legal && e.todo == c.M - 1;                 // :217 final ops among legal jobs
+    uint32_t bits = grp_ballot<G>(fin, c.gbase);
+    if (__ballot(bits != 0) == 0) return;                                // nothing to suppress anywhere in the wave
+    bool nf = false;
+    int tm_next = 1;
+    {
+        const bool cand = on && e.legal && e.todo < c.M - 1;             // :219
+        const int next_m = cand ? (c.ops[c.gl * c.stride + e.todo + 1] >> 16) : 0;  // :227
+        tm_next = grp_read<G>(e.tm, next_m, c.gbase);
+        nf = cand && tm_next == 0;                                       // :234 next machine idle
+    }
+    const int my_m = e.cur >> 16, my_d = e.cur & kDurMask;
+    while (__ballot(bits != 0) != 0) {                                   // :244 each final job of each group
+        const int l = bits ? __ffs(bits) - 1 : 0;
+        const int cf = grp_read<G>(e.cur, l, c.gbase);
+        const int mf = cf >> 16, df = cf & kDurMask;
+        // a non-final job on the same machine, strictly shorter: df > min_non_final (:252)
+        const bool hit = grp_any<G>(bits != 0 && nf && my_m == mf && my_d < df, c.gbase);
+        if (bits != 0 && hit && c.gl == l) e.legal = false;              // :253-254
+        bits &= bits - 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// _check_no_op(): jss_env.py:256-401 for the groups with `on`
+// ---------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool on) {
+    if (on) e.noop = 0;                                                  // :278
+    const uint32_t lm = grp_ballot<G>(e.legal, c.gbase);
+    const int nl = __popc(lm);
+    const bool busy = grp_any<G>(e.tm > 0, c.gbase);
+    bool gate = on && nl >= 1 && nl <= 4 && busy;                        // :284-288 (nb_machine_legal checked below)
+    if (__ballot(gate) == 0) return;
+    // PASS 1 (:305-321): the <= 4 legal jobs in ascending job index; every lane of the group
+    // computes the same sequence (max_horizon sees the running prefix, so the order matters)
+    int cf[4];
+    {
+        uint32_t bits = lm;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = bits ? __ffs(bits) - 1 : 0;
+            cf[i] = grp_read<G>(e.cur, l, c.gbase);
+            bits &= bits - 1;
+        }
+    }
+    int mm0 = -1, mm1 = -1, mm2 = -1, n_ml = 0;                          // the legal machines (:286 needs their count)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = cf[i] >> 16;
+        if (i < nl && m != mm0 && m != mm1 && m != mm2) {
+            if (n_ml == 0) mm0 = m; else if (n_ml == 1) mm1 = m; else if (n_ml == 2) mm2 = m;
+            ++n_ml;
+        }
+    }
+    gate = gate && n_ml <= 3;                                            // :286
+    const int nxt = e.t + grp_min<G>(e.tm > 0 ? e.tm : kBig);            // :293 next_time_step[0]
+    int mh = e.t;                                                        // :296
+    int mv0 = e.t + c.max_time_op, mv1 = mv0, mv2 = mv0;                 // :300-302
+    bool early = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < nl && !early) {
+            const int m = cf[i] >> 16;
+            const int end = e.t + (cf[i] & kDurMask);                    // :310
+            if (end < nxt) {
+                early = true;                                            // :314-315 return, NOPE stays illegal
+            } else {
+                int h;
+                if (m == mm0) { mv0 = imin(mv0, end); h = mv0; }         // :318
+                else if (m == mm1) { mv1 = imin(mv1, end); h = mv1; }
+                else { mv2 = imin(mv2, end); h = mv2; }
+                mh = imax(mh, h);                                        // :321
+            }
+        }
+    }
+    gate = gate && !early;
+    // PASS 2 (:324-401): every illegal job walks its future ops
+    const bool caseA = c.jvalid && !e.legal && e.left > 0 && e.todo + 1 < c.M;      // :327-330
+    const bool caseB = c.jvalid && !e.legal && !caseA && !e.blocked && e.todo < c.M; // :366-369
+    const int tm_need = grp_read<G>(e.tm, e.cur >> 16, c.gbase);                      // :376
+    int k = caseA ? e.todo + 1 : e.todo;                                              // :332 / :370
+    int tn = caseA ? e.t + e.left : e.t + tm_need;                                    // :334-337 / :374-377
+    int u = 0;
+    if (gate && (caseA || caseB)) {
+        while (k < c.M - 1 && mh > tn) {                                              // :340-342 / :380-382
+            const int op = c.ops[c.gl * c.stride + k];
+            const int m = op >> 16;
+            if (m == mm0 && mv0 > tn) u |= 1;                                         // :346-351
+            if (m == mm1 && mv1 > tn) u |= 2;
+            if (m == mm2 && mv2 > tn) u |= 4;
+            tn += op & kDurMask;                                                      // :362
+            ++k;
+        }
+    }
+    const int covered = (grp_any<G>(u & 1, c.gbase) ? 1 : 0) + (grp_any<G>(u & 2, c.gbase) ? 1 : 0) +
+                        (grp_any<G>(u & 4, c.gbase) ? 1 : 0);
+    if (gate && covered == n_ml) e.noop = 1;                                          // :357-359 / :395-397
+}
+
+// ---------------------------------------------------------------------------------------
+// step(): jss_env.py:403-481.  `a` is group-uniform.  Returns the reward numerator.
+// ---------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params &p, int a) {
+    const bool is_nope = c.alive && a == c.J;                            // :419
+    const bool is_job = c.alive && a >= 0 && a < c.J;
+    if (c.alive && (a < JSS_ACTION_SKIP || a > c.J)) e.err |= JSS_ERR_BAD_ACTION;
+    const bool mine = c.gl == a;
+    const bool a_legal = grp_any<G>(mine && e.legal, c.gbase);
+    if (is_job && !a_legal) e.err |= JSS_ERR_ILLEGAL_ACTION;             // outside the mask: ignored + flagged
+    const bool alloc = is_job && a_legal;
+    const int ca = grp_read<G>(e.cur, a, c.gbase);
+    const int m = ca >> 16, d = ca & kDurMask;                           // :443-444
+    int rn = 0;
+    if (alloc) {                                                         // :441 allocate job a
+        rn = d;                                                          // :445
+        if (c.gl == m) e.tm = d;                                         // :446
+        if (mine) {
+            e.left = d;                                                  // :447
+            p.s.solution[((size_t)c.b * p.d.jmax + a) * p.d.mmax + e.todo] = e.t;  // :454
+        }
+        if (e.cur >= 0 && (e.cur >> 16) == m) {
+            e.legal = false;                                             // :455-463
+            e.blocked = false;                                           // :464-467
+        }
+    }
+    if (is_nope) {                                                       // :422-428
+        e.blocked = e.blocked || e.legal;
+        e.legal = false;
+    }
+    const bool stepping = alloc || is_nope;
+    for (;;) {                                                           // :429-430 / :469-470
+        const bool none_legal = !grp_any<G>(e.legal, c.gbase);
+        const bool busy = grp_any<G>(e.tm > 0, c.gbase);
+        bool act = stepping && none_legal;
+        if (act && !busy && is_nope) e.err |= JSS_ERR_NOPE_IDLE;         // reference: IndexError (:517)
+        act = act && busy;
+        if (__ballot(act) == 0) break;
+        const int hole = p_advance(e, c, act);
+        if (act) rn -= hole;
+    }
+    p_prioritize(e, c, stepping);                                        // :432 / :471
+    p_check_no_op(e, c, stepping);                                       // :433 / :472
+    return rn;
+}
+
+// ---------------------------------------------------------------------------------------
+// action selectors (group-uniform result; -1 when nothing is legal)
+// ---------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G> &c, int kind, uint64_t seed, uint32_t explore_q16,
+                                        uint64_t env_id, uint32_t episode, uint32_t step) {
+    const uint32_t lm = grp_ballot<G>(e.legal, c.gbase);
+    const int nl = __popc(lm);
+    const int n = nl + (e.noop ? 1 : 0);
+    int a;
+    if (kind == JSS_POLICY_RANDOM) {
+        const uint32_t r = rng_u32(seed, env_id, episode, step);
+        const int pick = (int)__umulhi(r, (uint32_t)n);
+        const int below = __popc(lm & ((1u << c.gl) - 1u));
+        const uint32_t hit = grp_ballot<G>(e.legal && below == pick, c.gbase);
+        a = hit ? __ffs(hit) - 1 : c.J;                                  // pick >= nl: NOPE (it is legal then)
+    } else {
+        const bool larger = (kind == JSS_POLICY_FIFO || kind == JSS_POLICY_MWR || kind == JSS_POLICY_MOR);
+        int v;
+        if (kind == JSS_POLICY_FIFO) v = e.idle_last;
+        else if (kind == JSS_POLICY_SPT) v = e.cur & kDurMask;
+        else if (kind == JSS_POLICY_MOR || kind == JSS_POLICY_LOR) v = c.M - e.todo;
+        else {
+            v = 0;
+            if (e.legal)
+                for (int k = e.todo; k < c.M; ++k) v += c.ops[c.gl * c.stride + k] & kDurMask;
+        }
+        const int key = e.legal ? (larger ? v : -v) : -kBig;
+        const int best = grp_max<G>(key);
+        const uint32_t hit = grp_ballot<G>(e.legal && key == best, c.gbase);
+        a = hit ? __ffs(hit) - 1 : c.J;                                  // no job legal: NOPE
+        if (e.noop && explore_q16 != 0) {
+            const uint32_t r = rng_u32(seed ^ kExploreSeedXor, env_id, episode, step);
+            if ((r >> 16) < explore_q16) a = c.J;
+        }
+    }
+    return n == 0 ? -1 : a;
+}
+
+// ---------------------------------------------------------------------------------------
+// HBM <-> registers
+// ---------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void p_load(PEnv<G> &e, const PCtx<G> &c, const Params &p) {
+    const int jm = p.d.jmax;
+    const int32_t *js = p.s.job + (size_t)c.b * JSS_NF * jm;
+    const uint8_t *mk = p.s.action_mask + (size_t)c.b * (jm + 1);
+    const uint8_t *bk = p.s.blocked + (size_t)c.b * jm;
+    const int j = c.jvalid ? c.gl : 0;
+    e.t = p.s.clock[c.b];
+    e.err = p.s.err[c.b];
+    e.noop = mk[c.J];
+    e.tm = c.mvalid ? p.s.machine[(size_t)c.b * p.d.mmax + c.gl] : 0;
+    e.todo = js[JSS_F_TODO * jm + j];
+    e.cur = js[JSS_F_CUR * jm + j];
+    e.left = js[JSS_F_LEFT * jm + j];
+    e.perf = js[JSS_F_PERF * jm + j];
+    e.idle = js[JSS_F_IDLE * jm + j];
+    e.idle_last = js[JSS_F_IDLE_LAST * jm + j];
+    e.f4 = js[JSS_F_F4 * jm + j];
+    e.legal = c.jvalid && mk[j] != 0;
+    e.blocked = c.jvalid && bk[j] != 0;
+    if (!c.jvalid) {
+        e.todo = 0; e.cur = -1; e.left = 0; e.perf = 0; e.idle = 0; e.idle_last = 0; e.f4 = 0;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G> &c, const Params &p) {
+    if (!c.alive) return;
+    const int jm = p.d.jmax;
+    int32_t *js = p.s.job + (size_t)c.b * JSS_NF * jm;
+    uint8_t *mk = p.s.action_mask + (size_t)c.b * (jm + 1);
+    uint8_t *bk = p.s.blocked + (size_t)c.b * jm;
+    if (c.gl == 0) {
+        p.s.clock[c.b] = e.t;
+        p.s.err[c.b] = (uint8_t)e.err;
+        mk[c.J] = (uint8_t)e.noop;
+    }
+    if (c.mvalid) p.s.machine[(size_t)c.b * p.d.mmax + c.gl] = e.tm;
+    if (c.jvalid) {
+        const int j = c.gl;
+        js[JSS_F_TODO * jm + j] = e.todo;
+        js[JSS_F_CUR * jm + j] = e.cur;
+        js[JSS_F_LEFT * jm + j] = e.left;
+        js[JSS_F_PERF * jm + j] = e.perf;
+        js[JSS_F_IDLE * jm + j] = e.idle;
+        js[JSS_F_IDLE_LAST * jm + j] = e.idle_last;
+        js[JSS_F_F4 * jm + j] = e.f4;
+        mk[j] = e.legal ? 1 : 0;
+        bk[j] = e.blocked ? 1 : 0;
+    }
+}
+
+// (J,7) float32 observation (jss_env.py:102-111), transposed through LDS so each env's block is
+// written as contiguous floats.  scratch: G*7 floats per group.
+template <int G>
+__device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, const Params &p, float *scratch) {
+    const float f_op = (float)c.max_time_op, f_jobs = (float)c.max_time_jobs, f_sum = (float)c.sum_op, f_m = (float)c.M;
+    float *mine = scratch + (c.gbase / G) * (G * 7);
+    if (c.jvalid) {
+        float *row = mine + c.gl * 7;
+        row[0] = e.legal ? 1.0f : 0.0f;                                  // :130
+        row[1] = (float)e.left / f_op;                                   // :448, :539
+        row[2] = (float)e.todo / f_m;                                    // :559
+        row[3] = (float)e.perf / f_jobs;                                 // :545
+        row[4] = e.f4 == JSS_F4_ONE ? 1.0f : (float)e.f4 / f_op;         // :569-586
+        row[5] = (float)e.idle_last / f_sum;                             // :555, :600
+        row[6] = (float)e.idle / f_sum;                                  // :553, :601
+    }
+    wave_lds_sync();
+    if (c.alive) {
+        float *dst = p.o.real_obs + (size_t)c.b * p.d.jmax * 7;
+        const int n = c.J * 7;
+        for (int i = c.gl; i < n; i += G) dst[i] = mine[i];
+    }
+    wave_lds_sync();
+}
+
+// ---------------------------------------------------------------------------------------
+// the packed kernel
+// ---------------------------------------------------------------------------------------
+template <int G, int MODE>
+__global__ __launch_bounds__(kBlock) void jss_packed_kernel(Params p) {
+    HIP_DYNAMIC_SHARED(int32_t, lds)
+    constexpr int E = kWave / G;                      // envs per wave
+    constexpr int EB = E * kWavesPerBlock;            // envs per workgroup
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int grp_in_block = threadIdx.x / G;
+    const int n_regions = p.shared_table ? 1 : EB;
+    float *scratch = reinterpret_cast<float *>(lds + n_regions * p.region_ints) + wave * (kWave * 7);
+
+    PCtx<G> c;
+    c.lane = lane;
+    c.gl = lane & (G - 1);
+    c.gbase = lane & ~(G - 1);
+    const int b_raw = blockIdx.x * EB + grp_in_block;
+    c.alive = b_raw < p.d.batch;
+    c.b = c.alive ? b_raw : p.d.batch - 1;
+    const int tid = p.shared_table ? 0 : (p.d.table_of_env ? p.d.table_of_env[c.b] : c.b);
+    c.J = p.d.jobs[tid];
+    c.M = p.d.machines[tid];
+    c.max_time_op = p.d.max_time_op[tid];
+    c.max_time_jobs = p.d.max_time_jobs[tid];
+    c.sum_op = p.d.sum_op[tid];
+    c.jvalid = c.gl < c.J;
+    c.mvalid = c.gl < c.M;
+    c.stride = p.stride;
+    int32_t *table = lds + (p.shared_table ? 0 : grp_in_block * p.region_ints);
+    c.ops = table;
+    if (p.shared_table) {
+        const int n0 = p.d.jobs[0] * p.d.mmax;
+        for (int i = threadIdx.x; i < n0; i += kBlock) lds[i] = p.d.ops[i];
+    } else {
+        const int32_t *src = p.d.ops + (size_t)tid * p.d.jmax * p.d.mmax;
+        const int n = c.J * p.d.mmax;
+        for (int i = c.gl; i < n; i += G) table[i] = src[i];
+    }
+    __syncthreads();
+
+    PEnv<G> e;
+    if (MODE == kReset) {
+        const bool on = c.alive && !(p.which && p.which[c.b] == 0);
+        p_load(e, c, p);                              // untouched groups are written back unchanged
+        p_reset(e, c, p, on);
+        if (on && c.gl == 0) {
+            p.s.episode[c.b] += 1;
+            p.s.step_in_episode[c.b] = 0;
+            p.o.reward[c.b] = 0.f;
+            p.o.done[c.b] = 0;
+        }
+        p_store(e, c, p);
+        p_store_obs(e, c, p, scratch);
+    } else if (MODE == kStep) {
+        p_load(e, c, p);
+        const int a = p.actions[c.b];
+        const int rn = p_step(e, c, p, a);
+        const bool called = a != JSS_ACTION_SKIP;
+        const bool done = !grp_any<G>(e.legal, c.gbase);
+        if (c.alive && c.gl == 0) {
+            if (called) p.s.step_in_episode[c.b] += 1;
+            p.o.reward[c.b] = (float)rn / (float)c.max_time_op;          // :483-493
+            p.o.done[c.b] = done ? 1 : 0;                                // :639-653
+            if (called && done) p.o.makespan[c.b] = e.t;                 // :650
+            if (p.s.counters && called) {
+                int64_t *cn = p.s.counters + (size_t)c.b * 4;
+                cn[0] += 1;
+                cn[3] += rn;
+                if (done) {
+                    cn[1] += 1;
+                    cn[2] += e.t;
+                }
+            }
+        }
+        p_store(e, c, p);
+        p_store_obs(e, c, p, scratch);
+    } else if (MODE == kAdvance) {
+        const bool on = c.alive && !(p.which && p.which[c.b] == 0);
+        p_load(e, c, p);
+        const bool busy = grp_any<G>(e.tm > 0, c.gbase);
+        if (on && !busy) e.err |= JSS_ERR_NOPE_IDLE;                     // reference: IndexError (:517)
+        const int hole = p_advance(e, c, on && busy);
+        if (on && c.gl == 0 && p.hole) p.hole[c.b] = busy ? hole : 0;
+        p_store(e, c, p);
+        p_store_obs(e, c, p, scratch);
+    } else if (MODE == kPolicy) {
+        p_load(e, c, p);
+        const int a = p_select(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_id_base + c.b),
+                               (uint32_t)p.s.episode[c.b], (uint32_t)p.s.step_in_episode[c.b]);
+        if (c.alive && c.gl == 0) p.actions_out[c.b] = a;
+    } else {  // kRollout
+        p_load(e, c, p);
+        uint32_t episode = (uint32_t)p.s.episode[c.b];
+        uint32_t step = (uint32_t)p.s.step_in_episode[c.b];
+        const uint64_t env_id = (uint64_t)(p.d.env_id_base + c.b);
+        int n_steps = 0, n_done = 0, last_rn = 0, last_makespan = -1;
+        int64_t sum_makespan = 0, sum_rn = 0;
+        bool stepped = false;
+        const bool autoreset = (p.flags & JSS_ROLLOUT_AUTORESET) != 0;
+        for (int it = 0; it < p.n_iter; ++it) {
+            const bool done0 = !grp_any<G>(e.legal, c.gbase);            // :639-653
+            const bool do_reset = c.alive && done0 && autoreset;
+            const bool do_step = c.alive && !done0;
+            if (__ballot(do_reset || do_step) == 0) break;               // every env frozen
+            p_reset(e, c, p, do_reset);
+            if (do_reset) {
+                episode += 1;
+                step = 0;
+            }
+            int a = p_select(e, c, p.kind, p.seed, p.explore_q16, env_id, episode, step);
+            if (!do_step) a = JSS_ACTION_SKIP;
+            const int rn = p_step(e, c, p, a);
+            if (do_step) {
+                last_rn = rn;
+                stepped = true;
+                step += 1;
+                n_steps += 1;
+                sum_rn += rn;
+            }
+            const bool done1 = !grp_any<G>(e.legal, c.gbase);
+            if (do_step && done1) {
+                n_done += 1;
+                sum_makespan += e.t;
+                last_makespan = e.t;
+            }
+        }
+        const bool done = !grp_any<G>(e.legal, c.gbase);
+        if (c.alive && c.gl == 0) {
+            p.s.episode[c.b] = (int32_t)episode;
+            p.s.step_in_episode[c.b] = (int32_t)step;
+            if (stepped) p.o.reward[c.b] = (float)last_rn / (float)c.max_time_op;
+            p.o.done[c.b] = done ? 1 : 0;
+            if (last_makespan >= 0) p.o.makespan[c.b] = last_makespan;
+            if (p.s.counters) {
+                int64_t *cn = p.s.counters + (size_t)c.b * 4;
+                cn[0] += n_steps;
+                cn[1] += n_done;
+                cn[2] += sum_makespan;
+                cn[3] += sum_rn;
+            }
+        }
+        p_store(e, c, p);
+        p_store_obs(e, c, p, scratch);
+    }
+}
+
+}  // namespace jss

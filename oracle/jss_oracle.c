@@ -445,19 +445,22 @@ const double *orc_state(const OrcEnv *e) { return e->state; }
 
 /* action selectors ---------------------------------------------------------- */
 
-/* Counter RNG shared with the device policy kernel (jssenv_amd/csrc/jss_kernels.hip
- * rng_u32): two splitmix64 finalisers keyed by (seed, env, episode, step). */
-static uint64_t mix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
+/* Counter RNG shared with the device policy kernels (jssenv_amd/csrc/jss_common.hpp
+ * rng_u32): four rounds of a 32-bit finaliser keyed by (seed, env, episode, step). */
+static uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
 }
 
 uint32_t orc_rng_u32(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step) {
-    uint64_t k = mix64(seed ^ (env_id * 0xD1342543DE82EF95ULL));
-    uint64_t x = mix64(k ^ (((uint64_t)episode << 32) | (uint64_t)step));
-    return (uint32_t)(x >> 32);
+    uint32_t h = fmix32((uint32_t)seed ^ (uint32_t)env_id);
+    h = fmix32(h ^ ((uint32_t)(seed >> 32) + 0x9E3779B9u * (uint32_t)(env_id >> 32)));
+    h = fmix32(h ^ episode);
+    return fmix32(h + step);
 }
 
 static long remaining_work(const OrcEnv *e, int job) { /* dispatching.py:187-189 */

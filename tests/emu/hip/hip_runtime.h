@@ -221,6 +221,18 @@ inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int v) {
     return emu::exchange((uint64_t)(uint32_t)v,
                          [=](const uint64_t *vals) { return (int)(uint32_t)vals[(byte_addr >> 2) & 63]; });
 }
+/* ds_swizzle, bit-mask mode (offset bit 15 = 0): within each group of 32 lanes,
+ * src = ((lane & and_mask) | or_mask) ^ xor_mask. */
+inline int __builtin_amdgcn_ds_swizzle(int v, int pattern) {
+    int me = emu::lane_id();
+    if (pattern & 0x8000) {
+        fprintf(stderr, "emu: ds_swizzle quad-perm mode unsupported\n");
+        abort();
+    }
+    int and_mask = pattern & 31, or_mask = (pattern >> 5) & 31, xor_mask = (pattern >> 10) & 31;
+    int from = (me & 32) | ((((me & 31) & and_mask) | or_mask) ^ xor_mask);
+    return emu::exchange((uint64_t)(uint32_t)v, [=](const uint64_t *vals) { return (int)(uint32_t)vals[from]; });
+}
 inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) {
     int l = emu::lane_id();
     unsigned m = l >= 32 ? mask : (mask & ((1u << l) - 1u));

@@ -9,12 +9,17 @@ import parity_cases as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def hip():
+@pytest.fixture(scope="module", params=["auto", "wave"])
+def hip(request):
+    """auto: packed kernel (64/G envs per wavefront) where the batch shape fits, wave-per-env
+    otherwise; wave: force one wavefront per env everywhere."""
+    from jssenv_amd import _abi
     from jssenv_amd.env import HipBackend
     be = HipBackend("cuda:0")
     assert be.name == "hip"
-    return be
+    assert be.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_WAVE if request.param == "wave" else _abi.KERNEL_AUTO) == 0
+    yield be
+    be.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_AUTO)
 
 
 @pytest.mark.parametrize("inst", G.PUBLISHED)
