@@ -163,6 +163,8 @@ def main():
     stepped_per_launch = steps_total / world / args.steps
     alg_bytes = stepped_per_launch * b_alg(inst.jobs, inst.machines)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    kernel_name = ("jss_packed_kernel<%d,kRollout>" % (16 if max(inst.jobs, inst.machines) <= 16 else 32)
+                   if max(inst.jobs, inst.machines) <= 32 else "jss_kernel<%d,kRollout>" % (1 if inst.jobs <= 64 else 2))
     traffic = None
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.isfile(prof):
@@ -183,7 +185,7 @@ def main():
                    "policy": args.policy},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "jss_kernel<1,kRollout>", "kernel_ms": kernel_ms,
+                     "kernel": kernel_name, "kernel_ms": kernel_ms,
                      "alg_bytes_per_env_step": b_alg(inst.jobs, inst.machines),
                      "env_steps_per_launch": stepped_per_launch},
         "episodes_finished": episodes,

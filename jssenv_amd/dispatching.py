@@ -1,0 +1,212 @@
+"""Dispatching rules with the reference's surface (JSSEnv/dispatching.py).
+
+Same names (``ShortestProcessingTime`` ... ``CriticalRatio``, ``DISPATCHING_RULES``,
+``get_rule``, ``compare_rules``), same call convention (``rule(env) -> action``,
+``rule.run_episode(env) -> (total_reward, makespan)``) and the same semantics:
+
+  * NOPE when it is the only legal action (dispatching.py:96-97 and twins);
+  * arg-min / arg-max over the legal jobs with strict comparisons, so the lowest job
+    index wins ties (:108, :148, ...);
+  * then, if NOPE is legal, NOPE with probability 0.1 drawn from NumPy's *global* RNG
+    (:113, :153, ...) -- kept on the host exactly so, which makes ``np.random.seed(s)``
+    runs reproduce the reference's traces.
+
+The arg-best itself runs on the GPU (``jss_policy``, csrc ``select_action``/``p_select``)
+when ``env`` is a ``jssenv_amd.JssEnv``; any other env object exposing the reference's
+attributes falls back to the attribute-reading loop of the reference rule.  CriticalRatio is
+float arithmetic with a per-episode cache (:327-408) and stays on the host.
+
+For whole batches use ``BatchedJssEnv.rollout(kind)`` -- rule + step fused on the device.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+EXPLORATION_PROBABILITY = 0.1  # dispatching.py:113
+
+
+class DispatchingRule:
+    """Base class (dispatching.py:21-75)."""
+
+    kind: Optional[str] = None   # name of the on-device selector
+    larger_wins = False
+
+    def __init__(self, name: str, description: str):
+        self.name = name
+        self.description = description
+
+    def get_name(self) -> str:
+        return self.name
+
+    def get_description(self) -> str:
+        return self.description
+
+    # value the rule ranks job `job` by (host path)
+    def _value(self, env, job: int):
+        raise NotImplementedError("Subclasses must implement __call__")
+
+    def _best_job(self, env, legal_actions) -> int:
+        if self.kind is not None and hasattr(env, "_policy"):
+            a = env._policy(self.kind)            # device arg-best, lowest index wins ties
+            return a if a < env.jobs else -1
+        best, best_v = -1, None
+        for job in range(env.jobs):
+            if legal_actions[job]:
+                v = self._value(env, job)
+                if best_v is None or (v > best_v if self.larger_wins else v < best_v):
+                    best, best_v = job, v
+        return best
+
+    def __call__(self, env) -> int:
+        legal_actions = env.get_legal_actions()
+        if np.sum(legal_actions) == 1 and legal_actions[-1]:
+            return env.jobs
+        job = self._best_job(env, legal_actions)
+        if legal_actions[env.jobs] and np.random.random() < EXPLORATION_PROBABILITY:
+            return env.jobs
+        return job
+
+    def run_episode(self, env) -> Tuple[float, int]:
+        """dispatching.py:55-75."""
+        env.reset()
+        done = False
+        total_reward = 0.0
+        while not done:
+            action = self(env)
+            _, reward, done, _, _ = env.step(action)
+            total_reward += reward
+        return total_reward, env.current_time_step
+
+
+def _remaining_work(env, job: int) -> int:                                # dispatching.py:187-189
+    return int(sum(env.instance_matrix[job][op][1] for op in range(env.todo_time_step_job[job], env.machines)))
+
+
+class ShortestProcessingTime(DispatchingRule):                            # dispatching.py:78-116
+    kind, larger_wins = "SPT", False
+
+    def __init__(self):
+        super().__init__("SPT", "Shortest Processing Time: Schedule the job with the shortest processing time next")
+
+    def _value(self, env, job):
+        return env.instance_matrix[job][env.todo_time_step_job[job]][1]
+
+
+class FirstInFirstOut(DispatchingRule):                                   # dispatching.py:119-156
+    kind, larger_wins = "FIFO", True
+
+    def __init__(self):
+        super().__init__("FIFO", "First In First Out: Schedule the job that has been waiting the longest")
+
+    def _value(self, env, job):
+        return env.idle_time_jobs_last_op[job]
+
+
+class MostWorkRemaining(DispatchingRule):                                 # dispatching.py:159-199
+    kind, larger_wins = "MWR", True
+
+    def __init__(self):
+        super().__init__("MWR", "Most Work Remaining: Schedule the job with the most processing time remaining")
+
+    def _value(self, env, job):
+        return _remaining_work(env, job)
+
+
+class LeastWorkRemaining(DispatchingRule):                                # dispatching.py:202-242
+    kind, larger_wins = "LWR", False
+
+    def __init__(self):
+        super().__init__("LWR", "Least Work Remaining: Schedule the job with the least processing time remaining")
+
+    def _value(self, env, job):
+        return _remaining_work(env, job)
+
+
+class MostOperationsRemaining(DispatchingRule):                           # dispatching.py:245-283
+    kind, larger_wins = "MOR", True
+
+    def __init__(self):
+        super().__init__("MOR", "Most Operations Remaining: Schedule the job with the most operations remaining")
+
+    def _value(self, env, job):
+        return env.machines - env.todo_time_step_job[job]
+
+
+class LeastOperationsRemaining(DispatchingRule):                          # dispatching.py:286-324
+    kind, larger_wins = "LOR", False
+
+    def __init__(self):
+        super().__init__("LOR", "Least Operations Remaining: Schedule the job with the fewest operations remaining")
+
+    def _value(self, env, job):
+        return env.machines - env.todo_time_step_job[job]
+
+
+class CriticalRatio(DispatchingRule):                                     # dispatching.py:327-408
+    """(due date - now) / remaining work, smallest first; due date = factor x job length, cached
+    per job and dropped when ``current_time_step == 0`` (:373-374).  Host-side float arithmetic."""
+
+    kind, larger_wins = None, False
+
+    def __init__(self, due_date_factor: float = 1.5):
+        super().__init__("CR", "Critical Ratio: Schedule based on the ratio of time to due date versus remaining work")
+        self.due_date_factor = due_date_factor
+        self._due_dates: Dict[int, float] = {}
+
+    def _calculate_due_date(self, env, job: int) -> float:                # :351-363
+        if job not in self._due_dates:
+            total = sum(env.instance_matrix[job][op][1] for op in range(env.machines))
+            self._due_dates[job] = total * self.due_date_factor
+        return self._due_dates[job]
+
+    def _value(self, env, job):
+        remaining = _remaining_work(env, job)
+        time_remaining = self._calculate_due_date(env, job) - env.current_time_step
+        return time_remaining / remaining if remaining > 0 else float("inf")   # :395-398
+
+    def __call__(self, env) -> int:
+        legal_actions = env.get_legal_actions()
+        if np.sum(legal_actions) == 1 and legal_actions[-1]:
+            return env.jobs
+        if env.current_time_step == 0:                                    # :373-374
+            self._due_dates = {}
+        job = self._best_job(env, legal_actions)
+        if legal_actions[env.jobs] and np.random.random() < EXPLORATION_PROBABILITY:
+            return env.jobs
+        return job
+
+
+DISPATCHING_RULES = {                                                     # dispatching.py:412-420
+    "SPT": ShortestProcessingTime(),
+    "FIFO": FirstInFirstOut(),
+    "MWR": MostWorkRemaining(),
+    "LWR": LeastWorkRemaining(),
+    "MOR": MostOperationsRemaining(),
+    "LOR": LeastOperationsRemaining(),
+    "CR": CriticalRatio(),
+}
+
+
+def get_rule(rule_name: str) -> DispatchingRule:                          # dispatching.py:423-439
+    if rule_name not in DISPATCHING_RULES:
+        raise ValueError(f"Rule '{rule_name}' not found. Available rules: {list(DISPATCHING_RULES.keys())}")
+    return DISPATCHING_RULES[rule_name]
+
+
+def compare_rules(env, rules: Optional[List[str]] = None, num_episodes: int = 10) -> Dict[str, Dict[str, float]]:
+    """dispatching.py:442-475."""
+    if rules is None:
+        rules = list(DISPATCHING_RULES.keys())
+    results = {}
+    for rule_name in rules:
+        rule = get_rule(rule_name)
+        total_reward = 0.0
+        total_makespan = 0.0
+        for _ in range(num_episodes):
+            reward, makespan = rule.run_episode(env)
+            total_reward += reward
+            total_makespan += makespan
+        results[rule_name] = {"avg_reward": total_reward / num_episodes, "avg_makespan": total_makespan / num_episodes}
+    return results

@@ -291,3 +291,50 @@ def case_state_invariants(backend, episodes=3, inst="ta01"):
         assert env.solution.min() != -1
         assert (env.todo_time_step_job == env.machines).all()
         assert env.last_time_step == env.current_time_step
+
+
+# -----------------------------------------------------------------------------------------
+# jssenv_amd.dispatching (the reference's rule classes) on the single-env facade
+# -----------------------------------------------------------------------------------------
+def case_dispatching_seeded(backend, keys=None):
+    """G4: np.random.seed(s) + rule(env) loop reproduces the live reference's action trace, because the
+    arg-best is deterministic and the 10 % exploration draws from NumPy's global RNG in the same order."""
+    from jssenv_amd import dispatching as D
+    g = G.load("rules_seeded")
+    for key in (keys or [k for k in g if k.startswith("trace_")]):
+        _, rule, inst, seed = key.split("_")
+        np.random.seed(int(seed))
+        env = JssEnv({"instance_path": inst}, _backend=backend)
+        env.reset()
+        policy = D.get_rule(rule)
+        done, trace = False, []
+        while not done:
+            a = policy(env)
+            trace.append(a)
+            _, _, done, _, _ = env.step(a)
+        assert trace == g[key].tolist(), f"{key}: trace differs"
+        assert env.current_time_step == int(g[f"makespan_{rule}_{inst}_{seed}"])
+
+
+def case_dispatching_deterministic(backend, rules=("SPT", "FIFO", "MWR", "LWR", "MOR", "LOR", "CR"), insts=("ta01",)):
+    """G3 through the module API (exploration disabled the way the golden run did: random() -> 1.0)."""
+    from jssenv_amd import dispatching as D
+    g = G.load("rules")
+    rnames, inames = [str(r) for r in g["rules"]], [str(i) for i in g["instances"]]
+    real = np.random.random
+    np.random.random = lambda *a, **k: 1.0
+    try:
+        for inst in insts:
+            env = JssEnv({"instance_path": inst}, _backend=backend)
+            for rule in rules:
+                total, makespan = D.get_rule(rule).run_episode(env)
+                ri, ii = rnames.index(rule), inames.index(inst)
+                assert makespan == g["makespan"][ri, ii], (rule, inst, makespan)
+                assert abs(total - g["total_reward"][ri, ii]) < 1e-4, (rule, inst)
+    finally:
+        np.random.random = real
+    with np.testing.assert_raises(ValueError):
+        D.get_rule("nope")
+    assert set(D.DISPATCHING_RULES) == {"SPT", "FIFO", "MWR", "LWR", "MOR", "LOR", "CR"}
+    res = D.compare_rules(JssEnv({"instance_path": "ta01"}, _backend=backend), rules=["SPT"], num_episodes=1)
+    assert set(res["SPT"]) == {"avg_reward", "avg_makespan"} and res["SPT"]["avg_makespan"] > 0

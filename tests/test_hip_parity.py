@@ -158,3 +158,8 @@ def test_config4_synthetic_50x20(hip):
         r = orc.rollout("random", seed, i, 1500, episode=1, step_in_episode=0)
         P.assert_matches_oracle(env.host_state(i), orc, f"synthetic env {i}")
         assert cnt[i, 0] == r["steps"] and cnt[i, 2] == r["makespan_sum"]
+
+
+def test_dispatching_module(hip):
+    P.case_dispatching_seeded(hip)
+    P.case_dispatching_deterministic(hip, insts=("ta01", "ta41"))

@@ -73,3 +73,8 @@ def test_error_semantics(emu):
 
 def test_state_invariants(emu):
     P.case_state_invariants(emu, episodes=1)
+
+
+def test_dispatching_module(emu):
+    P.case_dispatching_seeded(emu, keys=["trace_FIFO_ta01_0", "trace_SPT_ta01_1"])
+    P.case_dispatching_deterministic(emu, rules=("SPT", "CR"))

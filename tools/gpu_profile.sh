@@ -6,10 +6,10 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 CMD="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_trace -o trace -- $CMD > $OUT/prof_trace.log 2>&1; echo "trace rc=$?"
-rocprofv3 -f csv --kernel-include-regex jss_kernel --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_ANY -d $OUT/prof_pmc1 -o pmc1 -- $CMD > $OUT/prof_pmc1.log 2>&1; echo "pmc1 rc=$?"
-rocprofv3 -f csv --kernel-include-regex jss_kernel --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU -d $OUT/prof_pmc2 -o pmc2 -- $CMD > $OUT/prof_pmc2.log 2>&1; echo "pmc2 rc=$?"
-rocprofv3 -f csv --kernel-include-regex jss_kernel --pmc FETCH_SIZE -d $OUT/prof_fetch -o fetch -- $CMD > $OUT/prof_fetch.log 2>&1; echo "fetch rc=$?"
-rocprofv3 -f csv --kernel-include-regex jss_kernel --pmc WRITE_SIZE -d $OUT/prof_write -o write -- $CMD > $OUT/prof_write.log 2>&1; echo "write rc=$?"
+rocprofv3 -f csv --kernel-include-regex jss_ --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_ANY -d $OUT/prof_pmc1 -o pmc1 -- $CMD > $OUT/prof_pmc1.log 2>&1; echo "pmc1 rc=$?"
+rocprofv3 -f csv --kernel-include-regex jss_ --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU -d $OUT/prof_pmc2 -o pmc2 -- $CMD > $OUT/prof_pmc2.log 2>&1; echo "pmc2 rc=$?"
+rocprofv3 -f csv --kernel-include-regex jss_ --pmc FETCH_SIZE -d $OUT/prof_fetch -o fetch -- $CMD > $OUT/prof_fetch.log 2>&1; echo "fetch rc=$?"
+rocprofv3 -f csv --kernel-include-regex jss_ --pmc WRITE_SIZE -d $OUT/prof_write -o write -- $CMD > $OUT/prof_write.log 2>&1; echo "write rc=$?"
 find $OUT -name "*.csv" | xargs ls -la | head -30
 tail -3 $OUT/prof_trace.log $OUT/prof_pmc1.log
 python - <<'PY'
