@@ -34,10 +34,12 @@
  *
  * Data layout (all row-major, batch outermost)
  *   op table      int32 [n_tables][jmax][mmax]   machine << 16 | duration, 0 = padding
- *   job state     int32 [B][JSS_NF][jmax]        JSS_F_* rows, see below
+ *   job state     int32 [B][jmax][JSS_NF]        one 32-byte record per job (JSS_F_* words below):
+ *                                                a lane moves its job with two dwordx4 accesses
+ *   env header    int32 [B][4]                   JSS_H_*: clock, episode, step, status
  *   machine state int32 [B][mmax]                time_until_available_machine
- *   action_mask   uint8 [B][jmax + 1]            legal_actions; NOPE flag at index J(env)
- *   blocked       uint8 [B][jmax]                action_illegal_no_op
+ *   action_mask   uint8 [B][jmax + 1]            legal_actions (output; rebuilt from the flag words
+ *                                                every call); NOPE flag at index J(env)
  *   solution      int32 [B][jmax][mmax]          start time of op k of job j, -1 = unscheduled
  *   real_obs      float [B][jmax][7]             the reference's (J,7) observation
  */
@@ -50,12 +52,12 @@
 extern "C" {
 #endif
 
-#define JSS_ABI_VERSION 1
+#define JSS_ABI_VERSION 2
 
 #define JSS_MAX_JOBS 128
 #define JSS_MAX_MACHINES 64
 
-/* rows of the per-job state block */
+/* words of the per-job record */
 #define JSS_F_TODO 0      /* todo_time_step_job                                   */
 #define JSS_F_CUR 1       /* current op, machine << 16 | duration; -1 = job finished.
                              needed_machine_jobs == cur >> 16 (arithmetic shift)   */
@@ -65,10 +67,20 @@ extern "C" {
 #define JSS_F_IDLE_LAST 5 /* idle_time_jobs_last_op                               */
 #define JSS_F_F4 6        /* numerator of observation feature 4 (written only when an
                              op finishes, jss_env.py:569-586); JSS_F4_ONE = "1.0"  */
-#define JSS_NF 7
+#define JSS_F_FLAGS 7     /* bit 0 legal_actions[j], bit 1 action_illegal_no_op[j]    */
+#define JSS_NF 8
 #define JSS_F4_ONE (-1)
+#define JSS_FLAG_LEGAL 1
+#define JSS_FLAG_BLOCKED 2
 
-/* per-env error bits (state.err, sticky until reset) */
+/* words of the per-env header */
+#define JSS_H_CLOCK 0    /* current_time_step                                     */
+#define JSS_H_EPISODE 1  /* episodes started (RNG key)                            */
+#define JSS_H_STEP 2     /* env steps since reset (RNG key)                       */
+#define JSS_H_STATUS 3   /* bits 0-7 JSS_ERR_*, bit 8 legal_actions[J] (NOPE)     */
+#define JSS_STATUS_NOOP 256
+
+/* per-env error bits (low byte of the header's status word, sticky until reset) */
 #define JSS_ERR_ILLEGAL_ACTION 1 /* job action outside the mask: ignored (reference: silent corruption) */
 #define JSS_ERR_NOPE_IDLE 2      /* NOPE/advance with no busy machine (reference: IndexError, jss_env.py:517) */
 #define JSS_ERR_BAD_ACTION 4     /* action < -1 or > J: ignored (reference: IndexError) */
@@ -108,24 +120,20 @@ typedef struct JssDesc {
 } JssDesc;
 
 typedef struct JssState {
-    int32_t *clock;           /* [B] current_time_step                */
-    int32_t *job;             /* [B][JSS_NF][jmax]                    */
-    int32_t *machine;         /* [B][mmax]                            */
-    uint8_t *action_mask;     /* [B][jmax+1]                          */
-    uint8_t *blocked;         /* [B][jmax]                            */
-    int32_t *solution;        /* [B][jmax][mmax]                      */
-    int32_t *episode;         /* [B] episodes started (RNG key)       */
-    int32_t *step_in_episode; /* [B] env steps since reset (RNG key)  */
-    uint8_t *err;             /* [B] JSS_ERR_* bits                   */
-    int64_t *counters;        /* [B][4]: env steps, finished episodes, sum of makespans,
-                                 sum of reward numerators (reward * max_time_op); may be NULL */
+    int32_t *env;      /* [B][4]  JSS_H_*                                              */
+    int32_t *job;      /* [B][jmax][JSS_NF]                                            */
+    int32_t *machine;  /* [B][mmax]                                                    */
+    int32_t *solution; /* [B][jmax][mmax]                                              */
+    int64_t *counters; /* [B][4]: env steps, finished episodes, sum of makespans,
+                          sum of reward numerators (reward * max_time_op); may be NULL */
 } JssState;
 
 typedef struct JssOut {
-    float *real_obs;   /* [B][jmax][7]                                         */
-    float *reward;     /* [B] reward of the last step (jss_env.py:483-493)     */
-    uint8_t *done;     /* [B] nb_legal_actions == 0 (jss_env.py:639-653)       */
-    int32_t *makespan; /* [B] clock at the last done transition (last_time_step, jss_env.py:650) */
+    float *real_obs;      /* [B][jmax][7]; rows J..jmax-1 are written as zeros            */
+    uint8_t *action_mask; /* [B][jmax+1]                                                  */
+    float *reward;        /* [B] reward of the last step (jss_env.py:483-493)             */
+    uint8_t *done;        /* [B] nb_legal_actions == 0 (jss_env.py:639-653)               */
+    int32_t *makespan;    /* [B] clock at the last done transition (last_time_step, :650) */
 } JssOut;
 
 int jss_abi_version(void);

@@ -9,9 +9,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_JOBS, MAX_MACHINES = 128, 64
-F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, NF = 0, 1, 2, 3, 4, 5, 6, 7
+F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_FLAGS, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
+FLAG_LEGAL, FLAG_BLOCKED = 1, 2
+H_CLOCK, H_EPISODE, H_STEP, H_STATUS = 0, 1, 2, 3
+STATUS_NOOP = 256
 F4_ONE = -1
 ERR_ILLEGAL_ACTION, ERR_NOPE_IDLE, ERR_BAD_ACTION = 1, 2, 4
 ACTION_SKIP = -1
@@ -31,12 +34,11 @@ class JssDesc(C.Structure):
 
 
 class JssState(C.Structure):
-    _fields_ = [("clock", _p), ("job", _p), ("machine", _p), ("action_mask", _p), ("blocked", _p),
-                ("solution", _p), ("episode", _p), ("step_in_episode", _p), ("err", _p), ("counters", _p)]
+    _fields_ = [("env", _p), ("job", _p), ("machine", _p), ("solution", _p), ("counters", _p)]
 
 
 class JssOut(C.Structure):
-    _fields_ = [("real_obs", _p), ("reward", _p), ("done", _p), ("makespan", _p)]
+    _fields_ = [("real_obs", _p), ("action_mask", _p), ("reward", _p), ("done", _p), ("makespan", _p)]
 
 
 def library_path() -> str:

@@ -18,7 +18,8 @@ def hipcc() -> str:
 
 
 def build_extension(force: bool = False, extra=()) -> str:
-    deps = [SRC, os.path.join(_ROOT, "include", "jss_hip.h")]
+    csrc = os.path.dirname(SRC)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(_ROOT, "include", "jss_hip.h")]
     if not force and os.path.isfile(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     subprocess.check_call([hipcc(), *FLAGS, *extra, SRC, "-o", OUT])

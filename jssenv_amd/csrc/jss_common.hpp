@@ -38,7 +38,9 @@ constexpr int kMaxBlocks = 2048;  // 8192 waves = every wave slot of the chip (2
 constexpr int kBig = 0x3fffffff;
 constexpr int kDurMask = 0xffff;
 
-enum Mode { kReset = 0, kStep = 1, kAdvance = 2, kPolicy = 3, kRollout = 4 };
+// kRollout1 = kRollout with n_iter == 1 compiled loop-free (fewer live registers: the benchmarked
+// one-launch-per-env-step path)
+enum Mode { kReset = 0, kStep = 1, kAdvance = 2, kPolicy = 3, kRollout = 4, kRollout1 = 5 };
 
 struct Params {
     JssDesc d;
@@ -56,7 +58,22 @@ struct Params {
     int32_t stride;       // LDS row stride of the op table (= mmax: rows are copied verbatim)
     int32_t region_ints;  // LDS ints per staged table
     int32_t shared_table; // 1: one table for the whole batch, staged once per workgroup
+    int32_t obs_off_ints;    // packed kernel: LDS offset (ints, multiple of 4) of the observation images
+    int32_t obs_wave_floats; // packed kernel: floats per wave image (multiple of 4)
 };
+
+// a / b for small non-negative integers as float32: reciprocal (v_rcp_f32 + one Newton step) and
+// one residual correction of the quotient -- the core of the IEEE division sequence without its
+// range scaling (operands here are far from denormal/overflow).  |error| <= 1 ulp, i.e. < 1.2e-7
+// on values in [0, 1]: inside the 1e-6 budget of the float observation.
+__device__ __forceinline__ float refined_rcp(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float div_by(float a, float b, float rb) {
+    const float q = a * rb;
+    return __builtin_fmaf(__builtin_fmaf(-q, b, a), rb, q);
+}
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }

@@ -19,10 +19,8 @@ using namespace jss;
 int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_out) {
     if (!d || !s) return JSS_E_NULL;
     if (!d->ops || !d->jobs || !d->machines || !d->max_time_op || !d->max_time_jobs || !d->sum_op) return JSS_E_NULL;
-    if (!s->clock || !s->job || !s->machine || !s->action_mask || !s->blocked || !s->solution || !s->episode ||
-        !s->step_in_episode || !s->err)
-        return JSS_E_NULL;
-    if (need_out && (!o || !o->real_obs || !o->reward || !o->done || !o->makespan)) return JSS_E_NULL;
+    if (!s->env || !s->job || !s->machine || !s->solution) return JSS_E_NULL;
+    if (need_out && (!o || !o->real_obs || !o->action_mask || !o->reward || !o->done || !o->makespan)) return JSS_E_NULL;
     if (d->batch < 0 || d->jmax < 1 || d->jmax > JSS_MAX_JOBS || d->mmax < 2 || d->mmax > JSS_MAX_MACHINES ||
         d->n_tables < 1)
         return JSS_E_SHAPE;
@@ -52,7 +50,9 @@ int launch(Params &p, void *stream) {
     if (G) {
         const int envs_per_block = (kWave / G) * kWavesPerBlock;
         const int n_regions = p.shared_table ? 1 : envs_per_block;
-        const size_t shmem = sizeof(int32_t) * (size_t)n_regions * p.region_ints + sizeof(float) * kBlock * 7;
+        p.obs_off_ints = (n_regions * p.region_ints + 3) & ~3;
+        p.obs_wave_floats = ((kWave / G) * p.d.jmax * 7 + 3) & ~3;
+        const size_t shmem = sizeof(int32_t) * (size_t)p.obs_off_ints + sizeof(float) * kWavesPerBlock * p.obs_wave_floats;
         const int blocks = (p.d.batch + envs_per_block - 1) / envs_per_block;
         if (G == 16)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed_kernel<16, MODE>), dim3(blocks), dim3(kBlock), shmem, st, p);
@@ -141,7 +141,7 @@ int jss_rollout(const JssDesc *desc, const JssState *state, const JssOut *out, i
     Params p = {};
     p.d = *desc; p.s = *state; p.o = *out; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
     p.n_iter = n_iter; p.flags = flags;
-    return launch<kRollout>(p, stream);
+    return n_iter == 1 ? launch<kRollout1>(p, stream) : launch<kRollout>(p, stream);
 }
 
 }  // extern "C"

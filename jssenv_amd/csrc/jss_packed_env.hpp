@@ -333,81 +333,104 @@ __device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G> &c, int 
 }
 
 // ---------------------------------------------------------------------------------------
-// HBM <-> registers
+// HBM <-> registers.  One 32-byte record per job (two dwordx4 per lane), one int4 header per env.
+// None of the addresses depends on another load, so everything is in flight at once.
 // ---------------------------------------------------------------------------------------
+struct PHeader {
+    int episode, step;
+};
+
 template <int G>
-__device__ __forceinline__ void p_load(PEnv<G> &e, const PCtx<G> &c, const Params &p) {
+struct PRaw {  // loads issued before the op table is staged; unpacked after the barrier
+    int4 h, lo, hi;
+    int tm;
+};
+
+template <int G>
+__device__ __forceinline__ PRaw<G> p_issue_loads(int b, int gl, const Params &p) {
+    PRaw<G> r;
     const int jm = p.d.jmax;
-    const int32_t *js = p.s.job + (size_t)c.b * JSS_NF * jm;
-    const uint8_t *mk = p.s.action_mask + (size_t)c.b * (jm + 1);
-    const uint8_t *bk = p.s.blocked + (size_t)c.b * jm;
-    const int j = c.jvalid ? c.gl : 0;
-    e.t = p.s.clock[c.b];
-    e.err = p.s.err[c.b];
-    e.noop = mk[c.J];
-    e.tm = c.mvalid ? p.s.machine[(size_t)c.b * p.d.mmax + c.gl] : 0;
-    e.todo = js[JSS_F_TODO * jm + j];
-    e.cur = js[JSS_F_CUR * jm + j];
-    e.left = js[JSS_F_LEFT * jm + j];
-    e.perf = js[JSS_F_PERF * jm + j];
-    e.idle = js[JSS_F_IDLE * jm + j];
-    e.idle_last = js[JSS_F_IDLE_LAST * jm + j];
-    e.f4 = js[JSS_F_F4 * jm + j];
-    e.legal = c.jvalid && mk[j] != 0;
-    e.blocked = c.jvalid && bk[j] != 0;
-    if (!c.jvalid) {
-        e.todo = 0; e.cur = -1; e.left = 0; e.perf = 0; e.idle = 0; e.idle_last = 0; e.f4 = 0;
-    }
+    const int jc = gl < jm ? gl : 0;
+    const int mc = gl < p.d.mmax ? gl : 0;
+    const int4 *js = reinterpret_cast<const int4 *>(p.s.job) + ((size_t)b * jm + jc) * 2;
+    r.h = reinterpret_cast<const int4 *>(p.s.env)[b];
+    r.lo = js[0];
+    r.hi = js[1];
+    r.tm = p.s.machine[(size_t)b * p.d.mmax + mc];
+    return r;
 }
 
 template <int G>
-__device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G> &c, const Params &p) {
+__device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G> &c, const PRaw<G> &r) {
+    e.t = r.h.x;
+    e.err = r.h.w & 0xFF;
+    e.noop = (r.h.w & JSS_STATUS_NOOP) ? 1 : 0;
+    e.tm = c.mvalid ? r.tm : 0;
+    const bool v = c.jvalid;
+    e.todo = v ? r.lo.x : 0;
+    e.cur = v ? r.lo.y : -1;
+    e.left = v ? r.lo.z : 0;
+    e.perf = v ? r.lo.w : 0;
+    e.idle = v ? r.hi.x : 0;
+    e.idle_last = v ? r.hi.y : 0;
+    e.f4 = v ? r.hi.z : 0;
+    e.legal = v && (r.hi.w & JSS_FLAG_LEGAL);
+    e.blocked = v && (r.hi.w & JSS_FLAG_BLOCKED);
+    PHeader hd;
+    hd.episode = r.h.y;
+    hd.step = r.h.z;
+    return hd;
+}
+
+template <int G>
+__device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G> &c, const Params &p, const PHeader &hd) {
     if (!c.alive) return;
     const int jm = p.d.jmax;
-    int32_t *js = p.s.job + (size_t)c.b * JSS_NF * jm;
-    uint8_t *mk = p.s.action_mask + (size_t)c.b * (jm + 1);
-    uint8_t *bk = p.s.blocked + (size_t)c.b * jm;
+    uint8_t *mk = p.o.action_mask + (size_t)c.b * (jm + 1);
     if (c.gl == 0) {
-        p.s.clock[c.b] = e.t;
-        p.s.err[c.b] = (uint8_t)e.err;
+        reinterpret_cast<int4 *>(p.s.env)[c.b] =
+            make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
         mk[c.J] = (uint8_t)e.noop;
     }
     if (c.mvalid) p.s.machine[(size_t)c.b * p.d.mmax + c.gl] = e.tm;
     if (c.jvalid) {
-        const int j = c.gl;
-        js[JSS_F_TODO * jm + j] = e.todo;
-        js[JSS_F_CUR * jm + j] = e.cur;
-        js[JSS_F_LEFT * jm + j] = e.left;
-        js[JSS_F_PERF * jm + j] = e.perf;
-        js[JSS_F_IDLE * jm + j] = e.idle;
-        js[JSS_F_IDLE_LAST * jm + j] = e.idle_last;
-        js[JSS_F_F4 * jm + j] = e.f4;
-        mk[j] = e.legal ? 1 : 0;
-        bk[j] = e.blocked ? 1 : 0;
+        int4 *js = reinterpret_cast<int4 *>(p.s.job) + ((size_t)c.b * jm + c.gl) * 2;
+        js[0] = make_int4(e.todo, e.cur, e.left, e.perf);
+        js[1] = make_int4(e.idle, e.idle_last, e.f4, (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0));
+        mk[c.gl] = e.legal ? 1 : 0;
     }
 }
 
-// (J,7) float32 observation (jss_env.py:102-111), transposed through LDS so each env's block is
-// written as contiguous floats.  scratch: G*7 floats per group.
+// (J,7) float32 observation (jss_env.py:102-111).  Each lane writes its job's row into an LDS
+// image of the wave's E consecutive envs ([E][jmax][7], padding rows zero), which then goes out as
+// one linear copy -- dwordx4 per lane when the wave's block is whole and 16-byte sized.
 template <int G>
-__device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, const Params &p, float *scratch) {
+__device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, const Params &p, float *scratch,
+                                            int first_env, bool wave_whole) {
+    constexpr int E = kWave / G;
+    const int row_floats = p.d.jmax * 7;
     const float f_op = (float)c.max_time_op, f_jobs = (float)c.max_time_jobs, f_sum = (float)c.sum_op, f_m = (float)c.M;
-    float *mine = scratch + (c.gbase / G) * (G * 7);
-    if (c.jvalid) {
+    const float r_op = refined_rcp(f_op), r_jobs = refined_rcp(f_jobs), r_sum = refined_rcp(f_sum), r_m = refined_rcp(f_m);
+    float *mine = scratch + (c.gbase / G) * row_floats;
+    if (c.gl < p.d.jmax) {
         float *row = mine + c.gl * 7;
-        row[0] = e.legal ? 1.0f : 0.0f;                                  // :130
-        row[1] = (float)e.left / f_op;                                   // :448, :539
-        row[2] = (float)e.todo / f_m;                                    // :559
-        row[3] = (float)e.perf / f_jobs;                                 // :545
-        row[4] = e.f4 == JSS_F4_ONE ? 1.0f : (float)e.f4 / f_op;         // :569-586
-        row[5] = (float)e.idle_last / f_sum;                             // :555, :600
-        row[6] = (float)e.idle / f_sum;                                  // :553, :601
+        row[0] = e.legal ? 1.0f : 0.0f;                                                  // :130
+        row[1] = div_by((float)e.left, f_op, r_op);                                      // :448, :539
+        row[2] = div_by((float)e.todo, f_m, r_m);                                        // :559
+        row[3] = div_by((float)e.perf, f_jobs, r_jobs);                                  // :545
+        row[4] = e.f4 == JSS_F4_ONE ? 1.0f : div_by((float)e.f4, f_op, r_op);            // :569-586
+        row[5] = div_by((float)e.idle_last, f_sum, r_sum);                               // :555, :600
+        row[6] = div_by((float)e.idle, f_sum, r_sum);                                    // :553, :601
     }
     wave_lds_sync();
-    if (c.alive) {
-        float *dst = p.o.real_obs + (size_t)c.b * p.d.jmax * 7;
-        const int n = c.J * 7;
-        for (int i = c.gl; i < n; i += G) dst[i] = mine[i];
+    const int n = E * row_floats;
+    if (wave_whole && (n & 3) == 0) {
+        const float4 *src = reinterpret_cast<const float4 *>(scratch);
+        float4 *dst = reinterpret_cast<float4 *>(p.o.real_obs + (size_t)first_env * row_floats);
+        for (int i = c.lane; i < (n >> 2); i += kWave) dst[i] = src[i];
+    } else if (c.alive) {
+        float *dst = p.o.real_obs + (size_t)c.b * row_floats;
+        for (int i = c.gl; i < row_floats; i += G) dst[i] = mine[i];
     }
     wave_lds_sync();
 }
@@ -423,16 +446,25 @@ __global__ __launch_bounds__(kBlock) void jss_packed_kernel(Params p) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int grp_in_block = threadIdx.x / G;
-    const int n_regions = p.shared_table ? 1 : EB;
-    float *scratch = reinterpret_cast<float *>(lds + n_regions * p.region_ints) + wave * (kWave * 7);
+    // obs image of this wave: E * jmax * 7 floats, 16-byte aligned (p.obs_off_ints is a multiple of 4)
+    float *scratch = reinterpret_cast<float *>(lds + p.obs_off_ints) + wave * p.obs_wave_floats;
 
     PCtx<G> c;
     c.lane = lane;
     c.gl = lane & (G - 1);
     c.gbase = lane & ~(G - 1);
     const int b_raw = blockIdx.x * EB + grp_in_block;
+    const int first_env = blockIdx.x * EB + wave * E;
+    const bool wave_whole = first_env + E <= p.d.batch;
     c.alive = b_raw < p.d.batch;
     c.b = c.alive ? b_raw : p.d.batch - 1;
+    // 1. state loads first: they depend on nothing but the env index
+    const PRaw<G> raw = p_issue_loads<G>(c.b, c.gl, p);
+    int a_in = JSS_ACTION_SKIP;
+    if (MODE == kStep) a_in = p.actions[c.b];
+    bool selected = true;
+    if ((MODE == kReset || MODE == kAdvance) && p.which) selected = p.which[c.b] != 0;
+    // 2. instance constants + op table -> LDS
     const int tid = p.shared_table ? 0 : (p.d.table_of_env ? p.d.table_of_env[c.b] : c.b);
     c.J = p.d.jobs[tid];
     c.M = p.d.machines[tid];
@@ -455,26 +487,24 @@ __global__ __launch_bounds__(kBlock) void jss_packed_kernel(Params p) {
     __syncthreads();
 
     PEnv<G> e;
+    PHeader hd = p_unpack(e, c, raw);
     if (MODE == kReset) {
-        const bool on = c.alive && !(p.which && p.which[c.b] == 0);
-        p_load(e, c, p);                              // untouched groups are written back unchanged
+        const bool on = c.alive && selected;          // untouched groups are written back unchanged
         p_reset(e, c, p, on);
-        if (on && c.gl == 0) {
-            p.s.episode[c.b] += 1;
-            p.s.step_in_episode[c.b] = 0;
-            p.o.reward[c.b] = 0.f;
-            p.o.done[c.b] = 0;
+        if (on) {
+            hd.episode += 1;
+            hd.step = 0;
+            if (c.gl == 0) {
+                p.o.reward[c.b] = 0.f;
+                p.o.done[c.b] = 0;
+            }
         }
-        p_store(e, c, p);
-        p_store_obs(e, c, p, scratch);
     } else if (MODE == kStep) {
-        p_load(e, c, p);
-        const int a = p.actions[c.b];
-        const int rn = p_step(e, c, p, a);
-        const bool called = a != JSS_ACTION_SKIP;
+        const int rn = p_step(e, c, p, a_in);
+        const bool called = a_in != JSS_ACTION_SKIP;
         const bool done = !grp_any<G>(e.legal, c.gbase);
+        if (called) hd.step += 1;
         if (c.alive && c.gl == 0) {
-            if (called) p.s.step_in_episode[c.b] += 1;
             p.o.reward[c.b] = (float)rn / (float)c.max_time_op;          // :483-493
             p.o.done[c.b] = done ? 1 : 0;                                // :639-653
             if (called && done) p.o.makespan[c.b] = e.t;                 // :650
@@ -488,63 +518,51 @@ __global__ __launch_bounds__(kBlock) void jss_packed_kernel(Params p) {
                 }
             }
         }
-        p_store(e, c, p);
-        p_store_obs(e, c, p, scratch);
     } else if (MODE == kAdvance) {
-        const bool on = c.alive && !(p.which && p.which[c.b] == 0);
-        p_load(e, c, p);
+        const bool on = c.alive && selected;
         const bool busy = grp_any<G>(e.tm > 0, c.gbase);
         if (on && !busy) e.err |= JSS_ERR_NOPE_IDLE;                     // reference: IndexError (:517)
         const int hole = p_advance(e, c, on && busy);
         if (on && c.gl == 0 && p.hole) p.hole[c.b] = busy ? hole : 0;
-        p_store(e, c, p);
-        p_store_obs(e, c, p, scratch);
     } else if (MODE == kPolicy) {
-        p_load(e, c, p);
         const int a = p_select(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_id_base + c.b),
-                               (uint32_t)p.s.episode[c.b], (uint32_t)p.s.step_in_episode[c.b]);
+                               (uint32_t)hd.episode, (uint32_t)hd.step);
         if (c.alive && c.gl == 0) p.actions_out[c.b] = a;
-    } else {  // kRollout
-        p_load(e, c, p);
-        uint32_t episode = (uint32_t)p.s.episode[c.b];
-        uint32_t step = (uint32_t)p.s.step_in_episode[c.b];
+        return;
+    } else {  // kRollout / kRollout1
         const uint64_t env_id = (uint64_t)(p.d.env_id_base + c.b);
-        int n_steps = 0, n_done = 0, last_rn = 0, last_makespan = -1;
-        int64_t sum_makespan = 0, sum_rn = 0;
-        bool stepped = false;
+        int n_steps = 0, n_done = 0, last_rn = 0, last_makespan = -1, sum_makespan = 0, sum_rn = 0;
         const bool autoreset = (p.flags & JSS_ROLLOUT_AUTORESET) != 0;
-        for (int it = 0; it < p.n_iter; ++it) {
+        const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;
+        for (int it = 0; it < n_iter; ++it) {
             const bool done0 = !grp_any<G>(e.legal, c.gbase);            // :639-653
             const bool do_reset = c.alive && done0 && autoreset;
             const bool do_step = c.alive && !done0;
-            if (__ballot(do_reset || do_step) == 0) break;               // every env frozen
+            if (MODE != kRollout1 && __ballot(do_reset || do_step) == 0) break;  // every env frozen
             p_reset(e, c, p, do_reset);
             if (do_reset) {
-                episode += 1;
-                step = 0;
+                hd.episode += 1;
+                hd.step = 0;
             }
-            int a = p_select(e, c, p.kind, p.seed, p.explore_q16, env_id, episode, step);
+            int a = p_select(e, c, p.kind, p.seed, p.explore_q16, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
             if (!do_step) a = JSS_ACTION_SKIP;
             const int rn = p_step(e, c, p, a);
+            const bool done1 = !grp_any<G>(e.legal, c.gbase);            // collective: outside the divergent branch
             if (do_step) {
                 last_rn = rn;
-                stepped = true;
-                step += 1;
+                hd.step += 1;
                 n_steps += 1;
                 sum_rn += rn;
-            }
-            const bool done1 = !grp_any<G>(e.legal, c.gbase);
-            if (do_step && done1) {
-                n_done += 1;
-                sum_makespan += e.t;
-                last_makespan = e.t;
+                if (done1) {
+                    n_done += 1;
+                    sum_makespan += e.t;
+                    last_makespan = e.t;
+                }
             }
         }
         const bool done = !grp_any<G>(e.legal, c.gbase);
         if (c.alive && c.gl == 0) {
-            p.s.episode[c.b] = (int32_t)episode;
-            p.s.step_in_episode[c.b] = (int32_t)step;
-            if (stepped) p.o.reward[c.b] = (float)last_rn / (float)c.max_time_op;
+            if (n_steps) p.o.reward[c.b] = (float)last_rn / (float)c.max_time_op;
             p.o.done[c.b] = done ? 1 : 0;
             if (last_makespan >= 0) p.o.makespan[c.b] = last_makespan;
             if (p.s.counters) {
@@ -555,9 +573,9 @@ __global__ __launch_bounds__(kBlock) void jss_packed_kernel(Params p) {
                 cn[3] += sum_rn;
             }
         }
-        p_store(e, c, p);
-        p_store_obs(e, c, p, scratch);
     }
+    p_store(e, c, p, hd);
+    p_store_obs(e, c, p, scratch, first_env, wave_whole);
 }
 
 }  // namespace jss

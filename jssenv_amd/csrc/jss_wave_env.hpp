@@ -391,44 +391,55 @@ __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, in
 }
 
 // ---------------------------------------------------------------------------------------
-// HBM <-> registers
+// HBM <-> registers.  One 32-byte record per job (two dwordx4 per lane), one int4 header per env.
 // ---------------------------------------------------------------------------------------
+struct Header {
+    int clock, episode, step, status;
+};
+
 template <int JPL>
-__device__ __forceinline__ void load_env(Env<JPL> &e, const Ctx &c, const Params &p) {
+__device__ __forceinline__ Header load_env(Env<JPL> &e, const Ctx &c, const Params &p) {
     const int jm = p.d.jmax;
-    const int32_t *js = p.s.job + (size_t)c.b * JSS_NF * jm;
-    const uint8_t *mk = p.s.action_mask + (size_t)c.b * (jm + 1);
-    const uint8_t *bk = p.s.blocked + (size_t)c.b * jm;
-    e.t = __builtin_amdgcn_readfirstlane(p.s.clock[c.b]);
-    e.err = __builtin_amdgcn_readfirstlane((int)p.s.err[c.b]);
-    e.noop = __builtin_amdgcn_readfirstlane((int)mk[c.J]);
-    e.tm = c.lane < c.M ? p.s.machine[(size_t)c.b * p.d.mmax + c.lane] : 0;
+    const int4 h = reinterpret_cast<const int4 *>(p.s.env)[c.b];
+    const int4 *js = reinterpret_cast<const int4 *>(p.s.job) + (size_t)c.b * jm * 2;
+    e.tm = c.lane < p.d.mmax ? p.s.machine[(size_t)c.b * p.d.mmax + c.lane] : 0;
+    if (c.lane >= c.M) e.tm = 0;
+    Header hd;
+    hd.clock = __builtin_amdgcn_readfirstlane(h.x);
+    hd.episode = __builtin_amdgcn_readfirstlane(h.y);
+    hd.step = __builtin_amdgcn_readfirstlane(h.z);
+    hd.status = __builtin_amdgcn_readfirstlane(h.w);
+    e.t = hd.clock;
+    e.err = hd.status & 0xFF;
+    e.noop = (hd.status & JSS_STATUS_NOOP) ? 1 : 0;
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         const bool v = j < c.J;
+        const int jc = j < jm ? j : 0;
+        const int4 lo = js[jc * 2], hi = js[jc * 2 + 1];
         e.valid[s] = __ballot(v);
-        e.todo[s] = v ? js[JSS_F_TODO * jm + j] : 0;
-        e.cur[s] = v ? js[JSS_F_CUR * jm + j] : -1;
-        e.left[s] = v ? js[JSS_F_LEFT * jm + j] : 0;
-        e.perf[s] = v ? js[JSS_F_PERF * jm + j] : 0;
-        e.idle[s] = v ? js[JSS_F_IDLE * jm + j] : 0;
-        e.idle_last[s] = v ? js[JSS_F_IDLE_LAST * jm + j] : 0;
-        e.f4[s] = v ? js[JSS_F_F4 * jm + j] : 0;
-        e.legal[s] = __ballot(v && mk[v ? j : 0] != 0);
-        e.blocked[s] = __ballot(v && bk[v ? j : 0] != 0);
+        e.todo[s] = v ? lo.x : 0;
+        e.cur[s] = v ? lo.y : -1;
+        e.left[s] = v ? lo.z : 0;
+        e.perf[s] = v ? lo.w : 0;
+        e.idle[s] = v ? hi.x : 0;
+        e.idle_last[s] = v ? hi.y : 0;
+        e.f4[s] = v ? hi.z : 0;
+        e.legal[s] = __ballot(v && (hi.w & JSS_FLAG_LEGAL));
+        e.blocked[s] = __ballot(v && (hi.w & JSS_FLAG_BLOCKED));
     }
+    return hd;
 }
 
 template <int JPL>
-__device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p) {
+__device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p, const Header &hd) {
     const int jm = p.d.jmax;
-    int32_t *js = p.s.job + (size_t)c.b * JSS_NF * jm;
-    uint8_t *mk = p.s.action_mask + (size_t)c.b * (jm + 1);
-    uint8_t *bk = p.s.blocked + (size_t)c.b * jm;
+    int4 *js = reinterpret_cast<int4 *>(p.s.job) + (size_t)c.b * jm * 2;
+    uint8_t *mk = p.o.action_mask + (size_t)c.b * (jm + 1);
     if (c.lane == 0) {
-        p.s.clock[c.b] = e.t;
-        p.s.err[c.b] = (uint8_t)e.err;
+        reinterpret_cast<int4 *>(p.s.env)[c.b] =
+            make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
         mk[c.J] = (uint8_t)e.noop;
     }
     if (c.lane < c.M) p.s.machine[(size_t)c.b * p.d.mmax + c.lane] = e.tm;
@@ -436,42 +447,39 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         if (j < c.J) {
-            js[JSS_F_TODO * jm + j] = e.todo[s];
-            js[JSS_F_CUR * jm + j] = e.cur[s];
-            js[JSS_F_LEFT * jm + j] = e.left[s];
-            js[JSS_F_PERF * jm + j] = e.perf[s];
-            js[JSS_F_IDLE * jm + j] = e.idle[s];
-            js[JSS_F_IDLE_LAST * jm + j] = e.idle_last[s];
-            js[JSS_F_F4 * jm + j] = e.f4[s];
-            mk[j] = (uint8_t)((e.legal[s] >> c.lane) & 1);
-            bk[j] = (uint8_t)((e.blocked[s] >> c.lane) & 1);
+            const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = (int)((e.blocked[s] >> c.lane) & 1);
+            js[j * 2] = make_int4(e.todo[s], e.cur[s], e.left[s], e.perf[s]);
+            js[j * 2 + 1] = make_int4(e.idle[s], e.idle_last[s], e.f4[s], lg | (bl << 1));
+            mk[j] = (uint8_t)lg;
         }
     }
 }
 
 // The (J,7) observation of jss_env.py:102-111, float32.  Every column is a function of the
 // integer state (column 4 of its own stored numerator: the reference writes it only when an
-// op finishes).  Transposed through LDS so the HBM write is J*7 contiguous floats.
+// op finishes).  Transposed through LDS so the HBM write is jmax*7 contiguous floats.
 template <int JPL>
 __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const Params &p, float *scratch) {
     const float f_op = (float)c.max_time_op, f_jobs = (float)c.max_time_jobs, f_sum = (float)c.sum_op, f_m = (float)c.M;
+    const float r_op = refined_rcp(f_op), r_jobs = refined_rcp(f_jobs), r_sum = refined_rcp(f_sum), r_m = refined_rcp(f_m);
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
-        if (j < c.J) {
+        if (j < p.d.jmax) {
+            const bool v = j < c.J;  // padding rows are written as zeros
             float *row = scratch + j * 7;
-            row[0] = (float)((e.legal[s] >> c.lane) & 1);                // :130
-            row[1] = (float)e.left[s] / f_op;                            // :448, :539
-            row[2] = (float)e.todo[s] / f_m;                             // :559
-            row[3] = (float)e.perf[s] / f_jobs;                          // :545
-            row[4] = e.f4[s] == JSS_F4_ONE ? 1.0f : (float)e.f4[s] / f_op;  // :569-586
-            row[5] = (float)e.idle_last[s] / f_sum;                      // :555, :600
-            row[6] = (float)e.idle[s] / f_sum;                           // :553, :601
+            row[0] = v ? (float)((e.legal[s] >> c.lane) & 1) : 0.f;                       // :130
+            row[1] = div_by((float)e.left[s], f_op, r_op);                               // :448, :539
+            row[2] = div_by((float)e.todo[s], f_m, r_m);                                 // :559
+            row[3] = div_by((float)e.perf[s], f_jobs, r_jobs);                           // :545
+            row[4] = e.f4[s] == JSS_F4_ONE ? 1.0f : div_by((float)e.f4[s], f_op, r_op);  // :569-586
+            row[5] = div_by((float)e.idle_last[s], f_sum, r_sum);                        // :555, :600
+            row[6] = div_by((float)e.idle[s], f_sum, r_sum);                             // :553, :601
         }
     }
     wave_lds_sync();
     float *dst = p.o.real_obs + (size_t)c.b * p.d.jmax * 7;
-    const int n = c.J * 7;
+    const int n = p.d.jmax * 7;
     for (int i = c.lane; i < n; i += kWave) dst[i] = scratch[i];
     wave_lds_sync();
 }
@@ -520,23 +528,24 @@ __global__ __launch_bounds__(kBlock) void jss_kernel(Params p) {
         Env<JPL> e;
         if (MODE == kReset) {
             if (p.which && p.which[b] == 0) continue;
+            Header hd;
+            hd.episode = __builtin_amdgcn_readfirstlane(p.s.env[(size_t)b * 4 + JSS_H_EPISODE]) + 1;
+            hd.step = 0;
             reset_env(e, c, p);
             if (lane == 0) {
-                p.s.episode[b] += 1;
-                p.s.step_in_episode[b] = 0;
                 p.o.reward[b] = 0.f;
                 p.o.done[b] = 0;
             }
-            store_env(e, c, p);
+            store_env(e, c, p, hd);
             store_obs(e, c, p, scratch);
         } else if (MODE == kStep) {
-            load_env(e, c, p);
+            Header hd = load_env(e, c, p);
             const int a = __builtin_amdgcn_readfirstlane(p.actions[b]);
             const int rn = step_env(e, c, p, a);
             const bool called = a != JSS_ACTION_SKIP;
             const bool done = !any_legal(e);
+            if (called) hd.step += 1;
             if (lane == 0) {
-                if (called) p.s.step_in_episode[b] += 1;
                 p.o.reward[b] = (float)rn / (float)c.max_time_op;        // :483-493 (0 for skipped / ignored actions)
                 p.o.done[b] = done ? 1 : 0;                              // :639-653
                 if (called && done) p.o.makespan[b] = e.t;               // last_time_step :650
@@ -550,42 +559,40 @@ __global__ __launch_bounds__(kBlock) void jss_kernel(Params p) {
                     }
                 }
             }
-            store_env(e, c, p);
+            store_env(e, c, p, hd);
             store_obs(e, c, p, scratch);
         } else if (MODE == kAdvance) {
             if (p.which && p.which[b] == 0) continue;
-            load_env(e, c, p);
+            const Header hd = load_env(e, c, p);
             int hole = 0;
             if (__ballot(e.tm > 0) == 0) e.err |= JSS_ERR_NOPE_IDLE;    // reference: IndexError (:517)
             else hole = advance(e, c);
             if (lane == 0 && p.hole) p.hole[b] = hole;
-            store_env(e, c, p);
+            store_env(e, c, p, hd);
             store_obs(e, c, p, scratch);
         } else if (MODE == kPolicy) {
-            load_env(e, c, p);
+            const Header hd = load_env(e, c, p);
             const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_id_base + b),
-                                        (uint32_t)p.s.episode[b], (uint32_t)p.s.step_in_episode[b]);
+                                        (uint32_t)hd.episode, (uint32_t)hd.step);
             if (lane == 0) p.actions_out[b] = a;
-        } else {  // kRollout: n_iter x (policy + step), state stays in registers
-            load_env(e, c, p);
-            uint32_t episode = (uint32_t)p.s.episode[b];
-            uint32_t step = (uint32_t)p.s.step_in_episode[b];
+        } else {  // kRollout / kRollout1: n_iter x (policy + step), state stays in registers
+            Header hd = load_env(e, c, p);
             const uint64_t env_id = (uint64_t)(p.d.env_id_base + b);
-            int64_t n_steps = 0, n_done = 0, sum_makespan = 0, sum_rn = 0;
+            int n_steps = 0, n_done = 0, sum_makespan = 0, sum_rn = 0;
             int last_rn = 0, last_makespan = -1;
-            bool stepped = false;
-            for (int it = 0; it < p.n_iter; ++it) {
+            const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;
+            for (int it = 0; it < n_iter; ++it) {
                 if (!any_legal(e)) {                                     // done (:639-653)
                     if (!(p.flags & JSS_ROLLOUT_AUTORESET)) break;       // frozen
                     reset_env(e, c, p);
-                    episode += 1;
-                    step = 0;
+                    hd.episode += 1;
+                    hd.step = 0;
                     continue;
                 }
-                const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, env_id, episode, step);
+                const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, env_id, (uint32_t)hd.episode,
+                                            (uint32_t)hd.step);
                 last_rn = step_env(e, c, p, a);
-                stepped = true;
-                step += 1;
+                hd.step += 1;
                 n_steps += 1;
                 sum_rn += last_rn;
                 if (!any_legal(e)) {
@@ -595,9 +602,7 @@ __global__ __launch_bounds__(kBlock) void jss_kernel(Params p) {
                 }
             }
             if (lane == 0) {
-                p.s.episode[b] = (int32_t)episode;
-                p.s.step_in_episode[b] = (int32_t)step;
-                if (stepped) p.o.reward[b] = (float)last_rn / (float)c.max_time_op;
+                if (n_steps) p.o.reward[b] = (float)last_rn / (float)c.max_time_op;
                 p.o.done[b] = any_legal(e) ? 0 : 1;
                 if (last_makespan >= 0) p.o.makespan[b] = last_makespan;
                 if (p.s.counters) {
@@ -608,11 +613,10 @@ __global__ __launch_bounds__(kBlock) void jss_kernel(Params p) {
                     cn[3] += sum_rn;
                 }
             }
-            store_env(e, c, p);
+            store_env(e, c, p, hd);
             store_obs(e, c, p, scratch);
         }
     }
 }
-
 
 }  // namespace jss

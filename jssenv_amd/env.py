@@ -113,18 +113,14 @@ class BatchedJssEnv:
         self._table_of_env = None if table_of_env is None else be.from_numpy(self.table_of_env_host)
         # state (include/jss_hip.h JssState)
         J, M = self.jmax, self.mmax
-        self.clock = be.zeros((B,), "int32")
-        self.job_state = be.zeros((B, _abi.NF, J), "int32")
+        self.env_header = be.zeros((B, 4), "int32")          # clock, episode, step_in_episode, status
+        self.job_state = be.zeros((B, J, _abi.NF), "int32")  # one 32-byte record per job
         self.machine_state = be.zeros((B, M), "int32")
-        self.action_mask = be.zeros((B, J + 1), "uint8")
-        self.blocked = be.zeros((B, J), "uint8")
         self.solution = be.zeros((B, J, M), "int32")
-        self.episode = be.zeros((B,), "int32")
-        self.step_in_episode = be.zeros((B,), "int32")
-        self.err = be.zeros((B,), "uint8")
         self.counters = be.zeros((B, 4), "int64")
         # outputs (JssOut)
         self.real_obs = be.zeros((B, J, 7), "float32")
+        self.action_mask = be.zeros((B, J + 1), "uint8")
         self.reward = be.zeros((B,), "float32")
         self.done = be.zeros((B,), "uint8")
         self.makespan = be.zeros((B,), "int32")
@@ -132,10 +128,9 @@ class BatchedJssEnv:
         p = be.ptr
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._jobs), p(self._machines), p(self._max_time_op),
                                   p(self._max_time_jobs), p(self._sum_op), p(self._table_of_env), self.env_id_base)
-        self._state = _abi.JssState(p(self.clock), p(self.job_state), p(self.machine_state), p(self.action_mask),
-                                    p(self.blocked), p(self.solution), p(self.episode), p(self.step_in_episode),
-                                    p(self.err), p(self.counters))
-        self._out = _abi.JssOut(p(self.real_obs), p(self.reward), p(self.done), p(self.makespan))
+        self._state = _abi.JssState(p(self.env_header), p(self.job_state), p(self.machine_state), p(self.solution),
+                                    p(self.counters))
+        self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
         self._is_reset = False
 
     # -- raw ABI handles (bench.py launches through these) -------------------------------
@@ -218,31 +213,45 @@ class BatchedJssEnv:
     # -- state views with the reference's names (device arrays, batch first) ---------------
     @property
     def current_time_step(self):
-        return self.clock
+        return self.env_header[:, _abi.H_CLOCK]
+
+    clock = current_time_step
+
+    @property
+    def episode(self):
+        return self.env_header[:, _abi.H_EPISODE]
+
+    @property
+    def step_in_episode(self):
+        return self.env_header[:, _abi.H_STEP]
+
+    @property
+    def err(self):
+        return self.env_header[:, _abi.H_STATUS] & 0xFF
 
     @property
     def todo_time_step_job(self):
-        return self.job_state[:, _abi.F_TODO]
+        return self.job_state[:, :, _abi.F_TODO]
 
     @property
     def needed_machine_jobs(self):
-        return self.backend.shift_right(self.job_state[:, _abi.F_CUR], 16)
+        return self.backend.shift_right(self.job_state[:, :, _abi.F_CUR], 16)
 
     @property
     def time_until_finish_current_op_jobs(self):
-        return self.job_state[:, _abi.F_LEFT]
+        return self.job_state[:, :, _abi.F_LEFT]
 
     @property
     def total_perform_op_time_jobs(self):
-        return self.job_state[:, _abi.F_PERF]
+        return self.job_state[:, :, _abi.F_PERF]
 
     @property
     def total_idle_time_jobs(self):
-        return self.job_state[:, _abi.F_IDLE]
+        return self.job_state[:, :, _abi.F_IDLE]
 
     @property
     def idle_time_jobs_last_op(self):
-        return self.job_state[:, _abi.F_IDLE_LAST]
+        return self.job_state[:, :, _abi.F_IDLE_LAST]
 
     @property
     def time_until_available_machine(self):
@@ -254,7 +263,7 @@ class BatchedJssEnv:
 
     @property
     def action_illegal_no_op(self):
-        return self.blocked
+        return self.backend.shift_right(self.job_state[:, :, _abi.F_FLAGS], 1) & 1
 
     def stats(self):
         """Host dict of the per-env counters summed over the batch."""
@@ -265,22 +274,25 @@ class BatchedJssEnv:
         """Everything about env i as NumPy, sliced to its true (J, M)."""
         n = self.backend.numpy
         J, M = int(self.jobs_per_env[i]), int(self.machines_per_env[i])
-        js = n(self.job_state[i])
+        js = n(self.job_state[i])[:J].astype(np.int64).T          # (NF, J): rows = JSS_F_* words
+        hdr = n(self.env_header[i])
         return {
             "jobs": J, "machines": M,
-            "clock": int(n(self.clock[i:i + 1])[0]),
-            "job_state": js[:, :J].astype(np.int64),
+            "clock": int(hdr[_abi.H_CLOCK]),
+            "job_state": js,
             "tm": n(self.machine_state[i])[:M].astype(np.int64),
             "mask": n(self.action_mask[i])[:J + 1].astype(bool),
-            "blocked": n(self.blocked[i])[:J].astype(bool),
+            "blocked": (js[_abi.F_FLAGS] & _abi.FLAG_BLOCKED) != 0,
             "solution": n(self.solution[i])[:J, :M].astype(np.int64),
             "obs": n(self.real_obs[i])[:J].astype(np.float32),
+            "obs_padding": n(self.real_obs[i])[J:],
             "reward": float(n(self.reward[i:i + 1])[0]),
             "done": bool(n(self.done[i:i + 1])[0]),
-            "err": int(n(self.err[i:i + 1])[0]),
+            "err": int(hdr[_abi.H_STATUS]) & 0xFF,
+            "noop_flag": bool(int(hdr[_abi.H_STATUS]) & _abi.STATUS_NOOP),
             "makespan": int(n(self.makespan[i:i + 1])[0]),
-            "episode": int(n(self.episode[i:i + 1])[0]),
-            "step_in_episode": int(n(self.step_in_episode[i:i + 1])[0]),
+            "episode": int(hdr[_abi.H_EPISODE]),
+            "step_in_episode": int(hdr[_abi.H_STEP]),
         }
 
 

@@ -12,9 +12,9 @@ from jssenv_amd import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libjss_emu.so")
-_SRC = [os.path.join(_HERE, "hip", "hip_runtime.h"),
-        os.path.join(_HERE, "..", "..", "jssenv_amd", "csrc", "jss_kernels.hip"),
-        os.path.join(_HERE, "..", "..", "include", "jss_hip.h")]
+_CSRC = os.path.join(_HERE, "..", "..", "jssenv_amd", "csrc")
+_SRC = [os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.join(_HERE, "..", "..", "include", "jss_hip.h")] + \
+       [os.path.join(_CSRC, f) for f in os.listdir(_CSRC)]
 
 
 def build(force=False):

@@ -49,6 +49,15 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
+struct int4 {
+    int x, y, z, w;
+};
+struct float4 {
+    float x, y, z, w;
+};
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+
 namespace emu {
 
 constexpr int WAVE = 64;

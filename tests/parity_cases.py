@@ -44,6 +44,8 @@ def assert_matches_oracle(h, orc, where, fresh_col0=True, check_outputs=True):
         want_obs, got_obs = want_obs[:, 1:], got_obs[:, 1:]
     err = np.abs(got_obs - want_obs).max()
     assert err <= OBS_TOL, f"{where}: real_obs max |diff| {err}"
+    assert not h["obs_padding"].any(), f"{where}: padding rows of real_obs must be zero"
+    assert h["noop_flag"] == bool(orc.legal_actions[-1]), f"{where}: NOPE flag in the header"
     if check_outputs:
         assert h["done"] == (orc.nb_legal_actions == 0), f"{where}: done"
 

@@ -35,11 +35,13 @@ def test_header_constants_match_python_mirror():
     hdr = open(os.path.join(ROOT, "include", "jss_hip.h")).read()
     defs = {k: int(v) for k, v in re.findall(r"#define (JSS_\w+) \(?(-?\d+)\)?", hdr)}
     assert defs["JSS_NF"] == _abi.NF and defs["JSS_F_CUR"] == _abi.F_CUR and defs["JSS_F_F4"] == _abi.F_F4
+    assert defs["JSS_F_FLAGS"] == _abi.F_FLAGS and defs["JSS_H_STATUS"] == _abi.H_STATUS and defs["JSS_STATUS_NOOP"] == _abi.STATUS_NOOP
+    assert defs["JSS_ABI_VERSION"] == _abi.ABI_VERSION
     assert defs["JSS_MAX_JOBS"] == _abi.MAX_JOBS == I.MAX_JOBS and defs["JSS_MAX_MACHINES"] == I.MAX_MACHINES
     assert defs["JSS_ERR_NOPE_IDLE"] == _abi.ERR_NOPE_IDLE and defs["JSS_ERR_ILLEGAL_ACTION"] == _abi.ERR_ILLEGAL_ACTION
     for name, kid in _abi.POLICY.items():
         assert defs["JSS_POLICY_" + name.upper()] == kid
-    assert ctypes.sizeof(_abi.JssDesc) == 16 + 7 * 8 + 8 and ctypes.sizeof(_abi.JssState) == 80
+    assert ctypes.sizeof(_abi.JssDesc) == 16 + 7 * 8 + 8 and ctypes.sizeof(_abi.JssState) == 40 and ctypes.sizeof(_abi.JssOut) == 40
 
 
 def test_argument_errors_without_gpu(hip_lib):
