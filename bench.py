@@ -82,7 +82,12 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--instance", default="ta01")
     ap.add_argument("--policy", default="random")
+    ap.add_argument("--workload", default="shared", choices=["shared", "synthetic50x20", "mixed"],
+                    help="shared: one instance (--instance) for the whole batch [default, the headline]; "
+                         "synthetic50x20: BASELINE config 4, one Taillard-LCG instance per env; "
+                         "mixed: BASELINE config 5, env i <- ta(1 + i %% 80), padded 100x20")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--eager", action="store_true", help="launch from Python per step instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -90,6 +95,7 @@ def main():
     import torch
     import torch.distributed as dist
     from jssenv_amd import BatchedJssEnv, builtin_instance
+    from jssenv_amd.distributed import reduce_counters
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,8 +111,20 @@ def main():
     inst = builtin_instance(args.instance)
     B = args.batch
 
+    def instances_for(batch):
+        """(instances, mean algorithmic bytes per env step, label)."""
+        if args.workload == "synthetic50x20":
+            from jssenv_amd import synthetic_batch
+            return synthetic_batch(batch, 50, 20, first=rank * batch), b_alg(50, 20), "synthetic 50x20 (Taillard LCG), one instance per env"
+        if args.workload == "mixed":
+            insts = [builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
+            mean = sum(b_alg(i.jobs, i.machines) for i in insts) / 80.0
+            return insts, mean, "mixed ta01-ta80 (env i <- ta(1 + i % 80)), padded 100x20"
+        return inst, b_alg(inst.jobs, inst.machines), f"{args.instance} ({inst.jobs}x{inst.machines}) shared instance"
+
     def make_env(batch):
-        e = BatchedJssEnv(inst, batch=batch, device=dev, seed=args.seed, env_id_base=rank * batch)
+        insts, _, _ = instances_for(batch)
+        e = BatchedJssEnv(insts, batch=batch, device=dev, seed=args.seed, env_id_base=rank * batch)
         e.reset()
         # Spread the episode phases (a fresh batch is in lock step: every env at step 0) so the timed
         # window sees the steady-state mix of episode stages: env i is advanced (i % 16) * 16 extra
@@ -121,50 +139,59 @@ def main():
         e.counters.zero_()
         return e
 
-    def timed(env, n_launch, n_iter, record_events=False):
-        evs = None
-        if record_events:
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_launch + 1)]
+    def timed(env, n_launch, n_iter):
+        """Time n_launch launches of jss_rollout(n_iter).  Returns (max-over-ranks-able wall seconds,
+        GPU ms per launch from HIP events on the launch stream)."""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        graph = None
+        if not args.eager:
+            # the launches go to torch's current stream, so a torch CUDAGraph captures them: one host call
+            # replays all n_launch kernels (the Python+ctypes enqueue costs ~7 us per launch otherwise)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(n_launch):
+                        env.rollout(args.policy, n_iter=n_iter, autoreset=True)
+            torch.cuda.current_stream(dev).wait_stream(side)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if evs:
-            evs[0].record()
-        for i in range(n_launch):
-            env.rollout(args.policy, n_iter=n_iter, autoreset=True)
-            if evs:
-                evs[i + 1].record()
+        ev0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(n_launch):
+                env.rollout(args.policy, n_iter=n_iter, autoreset=True)
+        ev1.record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        per_launch_ms = None
-        if evs:
-            per_launch_ms = sum(evs[i].elapsed_time(evs[i + 1]) for i in range(n_launch)) / n_launch
-        return dt, per_launch_ms
+        return dt, ev0.elapsed_time(ev1) / n_launch
 
     env = make_env(B)
     for _ in range(args.warmup):
         env.rollout(args.policy, n_iter=1, autoreset=True)
     torch.cuda.synchronize()
     env.counters.zero_()
-    dt, kernel_ms = timed(env, args.steps, 1, record_events=True)
-    cnt = env.counters.sum(dim=0).to(torch.float64)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)   # the only collective: 4 counters over RCCL/xGMI
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    steps_total, episodes, makespan_sum, reward_num = [float(x) for x in cnt.tolist()]
-    dt_max = float(tmax.item())
+    dt, kernel_ms = timed(env, args.steps, 1)
+    # the only collectives: SUM of the 4 counters and MAX of the wall time, over RCCL/xGMI
+    tot = reduce_counters(env.counters, dt)
+    steps_total, episodes, makespan_sum, reward_num = tot["steps"], tot["episodes"], tot["makespan_sum"], tot["reward_num_sum"]
+    dt_max = tot["seconds"]
     value = steps_total / dt_max
 
     # roofline of the dominant (only) kernel: algorithmic bytes per launch / HIP-event time per launch
     stepped_per_launch = steps_total / world / args.steps
-    alg_bytes = stepped_per_launch * b_alg(inst.jobs, inst.machines)
+    _, alg_per_step, wl_label = instances_for(1 if args.workload != "mixed" else 80)
+    alg_bytes = stepped_per_launch * alg_per_step
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    kernel_name = ("jss_packed_kernel<%d,kRollout>" % (16 if max(inst.jobs, inst.machines) <= 16 else 32)
-                   if max(inst.jobs, inst.machines) <= 32 else "jss_kernel<%d,kRollout>" % (1 if inst.jobs <= 64 else 2))
+    jm, mm = env.jmax, env.mmax
+    kernel_name = ("jss_packed_kernel<%d,kRollout1>" % (16 if max(jm, mm) <= 16 else 32)
+                   if max(jm, mm) <= 32 else "jss_kernel<%d,kRollout1>" % (1 if jm <= 64 else 2))
     traffic = None
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.isfile(prof):
@@ -178,7 +205,8 @@ def main():
         "metric": "env steps/sec (batched)", "value": value, "unit": "env steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": f"{args.instance} ({inst.jobs}x{inst.machines}) shared instance, {args.policy} masked "
+        "launch": "eager" if args.eager else "hipGraph replay of the K launches",
+        "config": {"workload": f"{wl_label}, {args.policy} masked "
                                f"policy fused with step(), batch {B} envs per GPU, one launch per env step, "
                                f"full obs/mask/reward/done written every step, auto-restart",
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"env-shard x{world}",
@@ -186,7 +214,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": kernel_name, "kernel_ms": kernel_ms,
-                     "alg_bytes_per_env_step": b_alg(inst.jobs, inst.machines),
+                     "alg_bytes_per_env_step": alg_per_step,
                      "env_steps_per_launch": stepped_per_launch},
         "episodes_finished": episodes,
         "mean_makespan": makespan_sum / episodes if episodes else None,
@@ -198,24 +226,20 @@ def main():
         env.counters.zero_()
         n_l = max(4, args.steps // 16)
         dtf, _ = timed(env, n_l, 64)
-        c = env.counters.sum(dim=0).to(torch.float64)
-        tf = torch.tensor([dtf], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(c, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
-        out["fused_rollout"] = {"value": float(c[0].item()) / float(tf.item()), "unit": "env steps/s",
+        totf = reduce_counters(env.counters, dtf)
+        out["fused_rollout"] = {"value": totf["steps_per_second"], "unit": "env steps/s",
                                 "iterations_per_launch": 64, "launches": n_l,
                                 "note": "policy+step x64 per launch, observation written once per launch"}
-        if world == 1:
+        if world == 1 and args.workload == "shared":
             env4k = make_env(4096)
             for _ in range(args.warmup):
                 env4k.rollout(args.policy, n_iter=1, autoreset=True)
             env4k.counters.zero_()
-            dt4, ms4 = timed(env4k, args.steps, 1, record_events=True)
+            dt4, ms4 = timed(env4k, args.steps, 1)
             out["configs1_batch4096"] = {"value": float(env4k.counters[:, 0].sum().item()) / dt4,
                                          "unit": "env steps/s", "kernel_ms": ms4}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "shared":
         out["cpu_baseline"] = cpu_baseline(args.instance, args.seed)
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -145,6 +145,14 @@ const char *jss_error_string(int code);
 #define JSS_OPT_KERNEL 0
 #define JSS_KERNEL_AUTO 0
 #define JSS_KERNEL_WAVE 1
+/* JSS_OPT_ABLATE (profiling aid, results become WRONG): bit mask of phases the kernels skip, used by
+ * tools/gpu_ablate.sh to attribute kernel time.  0 = normal operation. */
+#define JSS_OPT_ABLATE 1
+#define JSS_ABLATE_CHECK_NO_OP 1
+#define JSS_ABLATE_PRIORITIZE 2
+#define JSS_ABLATE_OBS 4
+#define JSS_ABLATE_SELECT 8
+#define JSS_ABLATE_ADVANCE 16
 int jss_set_option(int option, int value);
 
 /* reset every env (which == NULL) or the envs with which[i] != 0 */

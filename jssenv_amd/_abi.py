@@ -21,6 +21,7 @@ ACTION_SKIP = -1
 POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6}
 ROLLOUT_AUTORESET = 1
 OPT_KERNEL, KERNEL_AUTO, KERNEL_WAVE = 0, 0, 1
+OPT_ABLATE = 1
 
 SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_set_option", "jss_reset", "jss_step", "jss_advance", "jss_policy", "jss_rollout")
 

@@ -34,7 +34,6 @@ namespace jss {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
-constexpr int kMaxBlocks = 2048;  // 8192 waves = every wave slot of the chip (256 CUs x 32)
 constexpr int kBig = 0x3fffffff;
 constexpr int kDurMask = 0xffff;
 
@@ -58,9 +57,13 @@ struct Params {
     int32_t stride;       // LDS row stride of the op table (= mmax: rows are copied verbatim)
     int32_t region_ints;  // LDS ints per staged table
     int32_t shared_table; // 1: one table for the whole batch, staged once per workgroup
+    int32_t ablate;          // JSS_OPT_ABLATE mask (profiling aid)
     int32_t obs_off_ints;    // packed kernel: LDS offset (ints, multiple of 4) of the observation images
     int32_t obs_wave_floats; // packed kernel: floats per wave image (multiple of 4)
 };
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
 // a / b for small non-negative integers as float32: reciprocal (v_rcp_f32 + one Newton step) and
 // one residual correction of the quotient -- the core of the IEEE division sequence without its
@@ -75,25 +78,37 @@ __device__ __forceinline__ float div_by(float a, float b, float rb) {
     return __builtin_fmaf(__builtin_fmaf(-q, b, a), rb, q);
 }
 
-__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        int o = __shfl_xor(v, off);
-        v = o < v ? o : v;
-    }
-    return __builtin_amdgcn_readfirstlane(v);
+#define JSS_DPP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xF, 0xF, false)
+
+// min / max over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ int row_min(int v) {
+    v = imin(v, JSS_DPP(v, 0xB1));   // quad_perm [1,0,3,2]   lane ^ 1
+    v = imin(v, JSS_DPP(v, 0x4E));   // quad_perm [2,3,0,1]   lane ^ 2
+    v = imin(v, JSS_DPP(v, 0x141));  // row_half_mirror       quads 0<->1, 2<->3 (quads are uniform by now)
+    v = imin(v, JSS_DPP(v, 0x140));  // row_mirror            halves of the row
+    return v;
+}
+__device__ __forceinline__ int row_max(int v) {
+    v = imax(v, JSS_DPP(v, 0xB1));
+    v = imax(v, JSS_DPP(v, 0x4E));
+    v = imax(v, JSS_DPP(v, 0x141));
+    v = imax(v, JSS_DPP(v, 0x140));
+    return v;
 }
 
+// wave-wide: four row results combined on the scalar unit
+__device__ __forceinline__ int wave_min(int v) {
+    v = row_min(v);
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return imin(imin(a, b), imin(c, d));
+}
 __device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        int o = __shfl_xor(v, off);
-        v = o > v ? o : v;
-    }
-    return __builtin_amdgcn_readfirstlane(v);
+    v = row_max(v);
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return imax(imax(a, b), imax(c, d));
 }
 
 // LDS writes of one wave consumed by other lanes of the same wave

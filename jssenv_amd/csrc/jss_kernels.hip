@@ -29,6 +29,7 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
 }
 
 int g_kernel_choice = JSS_KERNEL_AUTO;
+int g_ablate = 0;
 
 // Kernel flavour for a batch shape: the packed kernel needs every env's jobs AND machines to fit
 // a 16- or 32-lane group.
@@ -45,6 +46,7 @@ int launch(Params &p, void *stream) {
     p.stride = p.d.mmax;
     p.region_ints = p.d.jmax * p.stride;
     p.shared_table = p.d.n_tables == 1 ? 1 : 0;
+    p.ablate = g_ablate;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int G = packed_group(p.d);
     if (G) {
@@ -62,8 +64,7 @@ int launch(Params &p, void *stream) {
     }
     const int n_regions = p.shared_table ? 1 : kWavesPerBlock;
     const size_t shmem = sizeof(int32_t) * (size_t)n_regions * p.region_ints + sizeof(float) * kWavesPerBlock * p.d.jmax * 7;
-    int blocks = (p.d.batch + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    const int blocks = (p.d.batch + kWavesPerBlock - 1) / kWavesPerBlock;
     if (p.d.jmax <= kWave)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_kernel<1, MODE>), dim3(blocks), dim3(kBlock), shmem, st, p);
     else
@@ -80,6 +81,10 @@ int jss_abi_version(void) { return JSS_ABI_VERSION; }
 int jss_set_option(int option, int value) {
     if (option == JSS_OPT_KERNEL && value >= JSS_KERNEL_AUTO && value <= JSS_KERNEL_WAVE) {
         g_kernel_choice = value;
+        return 0;
+    }
+    if (option == JSS_OPT_ABLATE) {
+        g_ablate = value;
         return 0;
     }
     return JSS_E_KIND;

@@ -57,24 +57,16 @@ __device__ __forceinline__ int grp_read(int v, int idx, int gbase) {
     return __builtin_amdgcn_ds_bpermute((gbase + (idx & (G - 1))) << 2, v);
 }
 
-#define JSS_DPP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xF, 0xF, false)
-
 template <int G>
 __device__ __forceinline__ int grp_min(int v) {
-    v = imin(v, JSS_DPP(v, 0xB1));   // quad_perm [1,0,3,2]   lane ^ 1
-    v = imin(v, JSS_DPP(v, 0x4E));   // quad_perm [2,3,0,1]   lane ^ 2
-    v = imin(v, JSS_DPP(v, 0x141));  // row_half_mirror       quads 0<->1, 2<->3 (quads are uniform by now)
-    v = imin(v, JSS_DPP(v, 0x140));  // row_mirror            halves of the 16-lane row
-    if (G == 32) v = imin(v, __builtin_amdgcn_ds_swizzle(v, 0x401F));  // lane ^ 16
+    v = row_min(v);                                                       // a DPP row is one env at G = 16
+    if (G == 32) v = imin(v, __builtin_amdgcn_ds_swizzle(v, 0x401F));     // lane ^ 16
     return v;
 }
 
 template <int G>
 __device__ __forceinline__ int grp_max(int v) {
-    v = imax(v, JSS_DPP(v, 0xB1));
-    v = imax(v, JSS_DPP(v, 0x4E));
-    v = imax(v, JSS_DPP(v, 0x141));
-    v = imax(v, JSS_DPP(v, 0x140));
+    v = row_max(v);
     if (G == 32) v = imax(v, __builtin_amdgcn_ds_swizzle(v, 0x401F));
     return v;
 }
@@ -106,9 +98,15 @@ __device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G> &c, const Para
 // ---------------------------------------------------------------------------------------
 // increase_time_step(): jss_env.py:495-637 for the groups with `act`; returns hole_planning.
 // ---------------------------------------------------------------------------------------
+// time to the next event of my env = earliest machine release (:517-522; the reference's queue is
+// {t + tm[m] : tm[m] > 0}); kBig when no machine is busy (empty queue)
 template <int G>
-__device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act) {
-    const int d = grp_min<G>(e.tm > 0 ? e.tm : kBig);                    // :517-522 next event = earliest release
+__device__ __forceinline__ int p_next_event(const PEnv<G> &e) {
+    return grp_min<G>(e.tm > 0 ? e.tm : kBig);
+}
+
+template <int G>
+__device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act, int d) {
     const int idle_machines = __popc(grp_ballot<G>(c.mvalid && e.tm < d, c.gbase));
     const int hole = d * idle_machines;                                  // :606-608 (tm < d only when tm == 0)
     bool fin = false;
@@ -177,7 +175,8 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool
     if (on) e.noop = 0;                                                  // :278
     const uint32_t lm = grp_ballot<G>(e.legal, c.gbase);
     const int nl = __popc(lm);
-    const bool busy = grp_any<G>(e.tm > 0, c.gbase);
+    const int d_next = p_next_event(e);                                  // also next_time_step[0] - t of :293
+    const bool busy = d_next < kBig;                                     // :285 len(next_time_step) > 0
     bool gate = on && nl >= 1 && nl <= 4 && busy;                        // :284-288 (nb_machine_legal checked below)
     if (__ballot(gate) == 0) return;
     // PASS 1 (:305-321): the <= 4 legal jobs in ascending job index; every lane of the group
@@ -202,7 +201,7 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool
         }
     }
     gate = gate && n_ml <= 3;                                            // :286
-    const int nxt = e.t + grp_min<G>(e.tm > 0 ? e.tm : kBig);            // :293 next_time_step[0]
+    const int nxt = e.t + d_next;                                        // :293 next_time_step[0]
     int mh = e.t;                                                        // :296
     int mv0 = e.t + c.max_time_op, mv1 = mv0, mv2 = mv0;                 // :300-302
     bool early = false;
@@ -280,16 +279,17 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params
     const bool stepping = alloc || is_nope;
     for (;;) {                                                           // :429-430 / :469-470
         const bool none_legal = !grp_any<G>(e.legal, c.gbase);
-        const bool busy = grp_any<G>(e.tm > 0, c.gbase);
+        const int d = p_next_event(e);
+        const bool busy = d < kBig;
         bool act = stepping && none_legal;
         if (act && !busy && is_nope) e.err |= JSS_ERR_NOPE_IDLE;         // reference: IndexError (:517)
         act = act && busy;
-        if (__ballot(act) == 0) break;
-        const int hole = p_advance(e, c, act);
+        if (__ballot(act) == 0 || (p.ablate & JSS_ABLATE_ADVANCE)) break;
+        const int hole = p_advance(e, c, act, d);
         if (act) rn -= hole;
     }
-    p_prioritize(e, c, stepping);                                        // :432 / :471
-    p_check_no_op(e, c, stepping);                                       // :433 / :472
+    if (!(p.ablate & JSS_ABLATE_PRIORITIZE)) p_prioritize(e, c, stepping);      // :432 / :471
+    if (!(p.ablate & JSS_ABLATE_CHECK_NO_OP)) p_check_no_op(e, c, stepping);    // :433 / :472
     return rn;
 }
 
@@ -520,9 +520,10 @@ __global__ __launch_bounds__(kBlock) void jss_packed_kernel(Params p) {
         }
     } else if (MODE == kAdvance) {
         const bool on = c.alive && selected;
-        const bool busy = grp_any<G>(e.tm > 0, c.gbase);
+        const int d = p_next_event(e);
+        const bool busy = d < kBig;
         if (on && !busy) e.err |= JSS_ERR_NOPE_IDLE;                     // reference: IndexError (:517)
-        const int hole = p_advance(e, c, on && busy);
+        const int hole = p_advance(e, c, on && busy, d);
         if (on && c.gl == 0 && p.hole) p.hole[c.b] = busy ? hole : 0;
     } else if (MODE == kPolicy) {
         const int a = p_select(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_id_base + c.b),
@@ -544,7 +545,9 @@ __global__ __launch_bounds__(kBlock) void jss_packed_kernel(Params p) {
                 hd.episode += 1;
                 hd.step = 0;
             }
-            int a = p_select(e, c, p.kind, p.seed, p.explore_q16, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
+            int a = (p.ablate & JSS_ABLATE_SELECT)
+                        ? __ffs(grp_ballot<G>(e.legal, c.gbase)) - 1
+                        : p_select(e, c, p.kind, p.seed, p.explore_q16, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
             if (!do_step) a = JSS_ACTION_SKIP;
             const int rn = p_step(e, c, p, a);
             const bool done1 = !grp_any<G>(e.legal, c.gbase);            // collective: outside the divergent branch
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(kBlock) void jss_packed_kernel(Params p) {
         }
     }
     p_store(e, c, p, hd);
-    p_store_obs(e, c, p, scratch, first_env, wave_whole);
+    if (!(p.ablate & JSS_ABLATE_OBS)) p_store_obs(e, c, p, scratch, first_env, wave_whole);
 }
 
 }  // namespace jss

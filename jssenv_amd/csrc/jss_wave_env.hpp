@@ -398,26 +398,45 @@ struct Header {
 };
 
 template <int JPL>
-__device__ __forceinline__ Header load_env(Env<JPL> &e, const Ctx &c, const Params &p) {
+struct RawEnv {  // loads issued before the op table is staged; unpacked after the barrier
+    int4 h;
+    int4 lo[JPL], hi[JPL];
+    int tm;
+};
+
+template <int JPL>
+__device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params &p) {
+    RawEnv<JPL> r;
     const int jm = p.d.jmax;
-    const int4 h = reinterpret_cast<const int4 *>(p.s.env)[c.b];
-    const int4 *js = reinterpret_cast<const int4 *>(p.s.job) + (size_t)c.b * jm * 2;
-    e.tm = c.lane < p.d.mmax ? p.s.machine[(size_t)c.b * p.d.mmax + c.lane] : 0;
-    if (c.lane >= c.M) e.tm = 0;
+    r.h = reinterpret_cast<const int4 *>(p.s.env)[b];
+    const int4 *js = reinterpret_cast<const int4 *>(p.s.job) + (size_t)b * jm * 2;
+    r.tm = p.s.machine[(size_t)b * p.d.mmax + (lane < p.d.mmax ? lane : 0)];
+#pragma unroll
+    for (int s = 0; s < JPL; ++s) {
+        const int j = s * kWave + lane;
+        const int jc = j < jm ? j : 0;
+        r.lo[s] = js[jc * 2];
+        r.hi[s] = js[jc * 2 + 1];
+    }
+    return r;
+}
+
+template <int JPL>
+__device__ __forceinline__ Header unpack_env(Env<JPL> &e, const Ctx &c, const RawEnv<JPL> &r) {
     Header hd;
-    hd.clock = __builtin_amdgcn_readfirstlane(h.x);
-    hd.episode = __builtin_amdgcn_readfirstlane(h.y);
-    hd.step = __builtin_amdgcn_readfirstlane(h.z);
-    hd.status = __builtin_amdgcn_readfirstlane(h.w);
+    hd.clock = __builtin_amdgcn_readfirstlane(r.h.x);
+    hd.episode = __builtin_amdgcn_readfirstlane(r.h.y);
+    hd.step = __builtin_amdgcn_readfirstlane(r.h.z);
+    hd.status = __builtin_amdgcn_readfirstlane(r.h.w);
     e.t = hd.clock;
     e.err = hd.status & 0xFF;
     e.noop = (hd.status & JSS_STATUS_NOOP) ? 1 : 0;
+    e.tm = c.lane < c.M ? r.tm : 0;
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         const bool v = j < c.J;
-        const int jc = j < jm ? j : 0;
-        const int4 lo = js[jc * 2], hi = js[jc * 2 + 1];
+        const int4 lo = r.lo[s], hi = r.hi[s];
         e.valid[s] = __ballot(v);
         e.todo[s] = v ? lo.x : 0;
         e.cur[s] = v ? lo.y : -1;
@@ -492,131 +511,123 @@ __global__ __launch_bounds__(kBlock) void jss_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n_waves = gridDim.x * kWavesPerBlock;
     const int n_regions = p.shared_table ? 1 : kWavesPerBlock;
     int32_t *table = lds + (p.shared_table ? 0 : wave * p.region_ints);
     float *scratch = reinterpret_cast<float *>(lds + n_regions * p.region_ints) + wave * (p.d.jmax * 7);
 
+    const int b_raw = blockIdx.x * kWavesPerBlock + wave;                 // one env per wave
+    const bool alive = b_raw < p.d.batch;
+    const int b = alive ? b_raw : p.d.batch - 1;
+    // 1. state loads first: they depend on nothing but the env index
+    const RawEnv<JPL> raw = issue_loads<JPL>(b, lane, p);
+    int a_in = JSS_ACTION_SKIP;
+    if (MODE == kStep) a_in = __builtin_amdgcn_readfirstlane(p.actions[b]);
+    bool selected = true;
+    if ((MODE == kReset || MODE == kAdvance) && p.which) selected = __builtin_amdgcn_readfirstlane((int)p.which[b]) != 0;
+    // 2. instance constants + op table -> LDS
+    const int tid = __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : (p.d.n_tables == 1 ? 0 : b));
+    Ctx c;
+    c.b = b;
+    c.lane = lane;
+    c.J = __builtin_amdgcn_readfirstlane(p.d.jobs[tid]);
+    c.M = __builtin_amdgcn_readfirstlane(p.d.machines[tid]);
+    c.max_time_op = __builtin_amdgcn_readfirstlane(p.d.max_time_op[tid]);
+    c.max_time_jobs = __builtin_amdgcn_readfirstlane(p.d.max_time_jobs[tid]);
+    c.sum_op = __builtin_amdgcn_readfirstlane(p.d.sum_op[tid]);
+    c.ops = table;
+    c.stride = p.stride;
     if (p.shared_table) {
         const int n0 = p.d.jobs[0] * p.d.mmax;
         for (int i = threadIdx.x; i < n0; i += kBlock) lds[i] = p.d.ops[i];
-        __syncthreads();
+    } else {
+        const int32_t *src = p.d.ops + (size_t)tid * p.d.jmax * p.d.mmax;
+        const int n = c.J * p.d.mmax;
+        for (int i = lane; i < n; i += kWave) table[i] = src[i];
     }
+    __syncthreads();
+    if (!alive) return;
 
-    int staged = -1;
-    for (int b = blockIdx.x * kWavesPerBlock + wave; b < p.d.batch; b += n_waves) {
-        const int tid = __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : (p.d.n_tables == 1 ? 0 : b));
-        Ctx c;
-        c.b = b;
-        c.lane = lane;
-        c.J = __builtin_amdgcn_readfirstlane(p.d.jobs[tid]);
-        c.M = __builtin_amdgcn_readfirstlane(p.d.machines[tid]);
-        c.max_time_op = __builtin_amdgcn_readfirstlane(p.d.max_time_op[tid]);
-        c.max_time_jobs = __builtin_amdgcn_readfirstlane(p.d.max_time_jobs[tid]);
-        c.sum_op = __builtin_amdgcn_readfirstlane(p.d.sum_op[tid]);
-        c.ops = table;
-        c.stride = p.stride;
-        if (!p.shared_table && staged != tid) {
-            wave_lds_sync();  // previous env's readers are done with the region
-            const int32_t *src = p.d.ops + (size_t)tid * p.d.jmax * p.d.mmax;
-            const int n = c.J * p.d.mmax;
-            for (int i = lane; i < n; i += kWave) table[i] = src[i];
-            wave_lds_sync();
-            staged = tid;
+    Env<JPL> e;
+    Header hd = unpack_env(e, c, raw);
+    if (MODE == kReset) {
+        if (!selected) return;
+        hd.episode += 1;
+        hd.step = 0;
+        reset_env(e, c, p);
+        if (lane == 0) {
+            p.o.reward[b] = 0.f;
+            p.o.done[b] = 0;
         }
-
-        Env<JPL> e;
-        if (MODE == kReset) {
-            if (p.which && p.which[b] == 0) continue;
-            Header hd;
-            hd.episode = __builtin_amdgcn_readfirstlane(p.s.env[(size_t)b * 4 + JSS_H_EPISODE]) + 1;
-            hd.step = 0;
-            reset_env(e, c, p);
-            if (lane == 0) {
-                p.o.reward[b] = 0.f;
-                p.o.done[b] = 0;
-            }
-            store_env(e, c, p, hd);
-            store_obs(e, c, p, scratch);
-        } else if (MODE == kStep) {
-            Header hd = load_env(e, c, p);
-            const int a = __builtin_amdgcn_readfirstlane(p.actions[b]);
-            const int rn = step_env(e, c, p, a);
-            const bool called = a != JSS_ACTION_SKIP;
-            const bool done = !any_legal(e);
-            if (called) hd.step += 1;
-            if (lane == 0) {
-                p.o.reward[b] = (float)rn / (float)c.max_time_op;        // :483-493 (0 for skipped / ignored actions)
-                p.o.done[b] = done ? 1 : 0;                              // :639-653
-                if (called && done) p.o.makespan[b] = e.t;               // last_time_step :650
-                if (p.s.counters && called) {
-                    int64_t *cn = p.s.counters + (size_t)b * 4;
-                    cn[0] += 1;
-                    cn[3] += rn;
-                    if (done) {
-                        cn[1] += 1;
-                        cn[2] += e.t;
-                    }
+    } else if (MODE == kStep) {
+        const int rn = step_env(e, c, p, a_in);
+        const bool called = a_in != JSS_ACTION_SKIP;
+        const bool done = !any_legal(e);
+        if (called) hd.step += 1;
+        if (lane == 0) {
+            p.o.reward[b] = (float)rn / (float)c.max_time_op;            // :483-493 (0 for skipped / ignored actions)
+            p.o.done[b] = done ? 1 : 0;                                  // :639-653
+            if (called && done) p.o.makespan[b] = e.t;                   // last_time_step :650
+            if (p.s.counters && called) {
+                int64_t *cn = p.s.counters + (size_t)b * 4;
+                cn[0] += 1;
+                cn[3] += rn;
+                if (done) {
+                    cn[1] += 1;
+                    cn[2] += e.t;
                 }
             }
-            store_env(e, c, p, hd);
-            store_obs(e, c, p, scratch);
-        } else if (MODE == kAdvance) {
-            if (p.which && p.which[b] == 0) continue;
-            const Header hd = load_env(e, c, p);
-            int hole = 0;
-            if (__ballot(e.tm > 0) == 0) e.err |= JSS_ERR_NOPE_IDLE;    // reference: IndexError (:517)
-            else hole = advance(e, c);
-            if (lane == 0 && p.hole) p.hole[b] = hole;
-            store_env(e, c, p, hd);
-            store_obs(e, c, p, scratch);
-        } else if (MODE == kPolicy) {
-            const Header hd = load_env(e, c, p);
-            const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_id_base + b),
-                                        (uint32_t)hd.episode, (uint32_t)hd.step);
-            if (lane == 0) p.actions_out[b] = a;
-        } else {  // kRollout / kRollout1: n_iter x (policy + step), state stays in registers
-            Header hd = load_env(e, c, p);
-            const uint64_t env_id = (uint64_t)(p.d.env_id_base + b);
-            int n_steps = 0, n_done = 0, sum_makespan = 0, sum_rn = 0;
-            int last_rn = 0, last_makespan = -1;
-            const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;
-            for (int it = 0; it < n_iter; ++it) {
-                if (!any_legal(e)) {                                     // done (:639-653)
-                    if (!(p.flags & JSS_ROLLOUT_AUTORESET)) break;       // frozen
-                    reset_env(e, c, p);
-                    hd.episode += 1;
-                    hd.step = 0;
-                    continue;
-                }
-                const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, env_id, (uint32_t)hd.episode,
-                                            (uint32_t)hd.step);
-                last_rn = step_env(e, c, p, a);
-                hd.step += 1;
-                n_steps += 1;
-                sum_rn += last_rn;
-                if (!any_legal(e)) {
-                    n_done += 1;
-                    sum_makespan += e.t;
-                    last_makespan = e.t;
-                }
+        }
+    } else if (MODE == kAdvance) {
+        if (!selected) return;
+        int hole = 0;
+        if (__ballot(e.tm > 0) == 0) e.err |= JSS_ERR_NOPE_IDLE;        // reference: IndexError (:517)
+        else hole = advance(e, c);
+        if (lane == 0 && p.hole) p.hole[b] = hole;
+    } else if (MODE == kPolicy) {
+        const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_id_base + b),
+                                    (uint32_t)hd.episode, (uint32_t)hd.step);
+        if (lane == 0) p.actions_out[b] = a;
+        return;
+    } else {  // kRollout / kRollout1: n_iter x (policy + step), state stays in registers
+        const uint64_t env_id = (uint64_t)(p.d.env_id_base + b);
+        int n_steps = 0, n_done = 0, sum_makespan = 0, sum_rn = 0;
+        int last_rn = 0, last_makespan = -1;
+        const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;
+        for (int it = 0; it < n_iter; ++it) {
+            if (!any_legal(e)) {                                         // done (:639-653)
+                if (!(p.flags & JSS_ROLLOUT_AUTORESET)) break;           // frozen
+                reset_env(e, c, p);
+                hd.episode += 1;
+                hd.step = 0;
+                continue;
             }
-            if (lane == 0) {
-                if (n_steps) p.o.reward[b] = (float)last_rn / (float)c.max_time_op;
-                p.o.done[b] = any_legal(e) ? 0 : 1;
-                if (last_makespan >= 0) p.o.makespan[b] = last_makespan;
-                if (p.s.counters) {
-                    int64_t *cn = p.s.counters + (size_t)b * 4;
-                    cn[0] += n_steps;
-                    cn[1] += n_done;
-                    cn[2] += sum_makespan;
-                    cn[3] += sum_rn;
-                }
+            const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, env_id, (uint32_t)hd.episode,
+                                        (uint32_t)hd.step);
+            last_rn = step_env(e, c, p, a);
+            hd.step += 1;
+            n_steps += 1;
+            sum_rn += last_rn;
+            if (!any_legal(e)) {
+                n_done += 1;
+                sum_makespan += e.t;
+                last_makespan = e.t;
             }
-            store_env(e, c, p, hd);
-            store_obs(e, c, p, scratch);
+        }
+        if (lane == 0) {
+            if (n_steps) p.o.reward[b] = (float)last_rn / (float)c.max_time_op;
+            p.o.done[b] = any_legal(e) ? 0 : 1;
+            if (last_makespan >= 0) p.o.makespan[b] = last_makespan;
+            if (p.s.counters) {
+                int64_t *cn = p.s.counters + (size_t)b * 4;
+                cn[0] += n_steps;
+                cn[1] += n_done;
+                cn[2] += sum_makespan;
+                cn[3] += sum_rn;
+            }
         }
     }
+    store_env(e, c, p, hd);
+    if (!(p.ablate & JSS_ABLATE_OBS)) store_obs(e, c, p, scratch);
 }
 
 }  // namespace jss
