@@ -87,7 +87,14 @@ def main():
                          "synthetic50x20: BASELINE config 4, one Taillard-LCG instance per env; "
                          "mixed: BASELINE config 5, env i <- ta(1 + i %% 80), padded 100x20")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--eager", action="store_true", help="launch from Python per step instead of replaying a hipGraph")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
+                    help="graph: replay a hipGraph of the K launches; eager: one Python/ctypes launch per step; "
+                         "auto: whichever is faster on a short probe (graphs win when the kernel is shorter than "
+                         "the ~7 us host enqueue, eager wins at large batches)")
+    ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="debug: every rank uses cuda:0 (exercises the multi-process path on a 1-GPU box; use with "
+                         "--dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -102,11 +109,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = args.dist_backend or "nccl"   # "nccl" is RCCL on ROCm
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
 
     inst = builtin_instance(args.instance)
     B = args.batch
@@ -139,12 +154,12 @@ def main():
         e.counters.zero_()
         return e
 
-    def timed(env, n_launch, n_iter):
+    def timed(env, n_launch, n_iter, mode):
         """Time n_launch launches of jss_rollout(n_iter).  Returns (max-over-ranks-able wall seconds,
         GPU ms per launch from HIP events on the launch stream)."""
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         graph = None
-        if not args.eager:
+        if mode == "graph":
             # the launches go to torch's current stream, so a torch CUDAGraph captures them: one host call
             # replays all n_launch kernels (the Python+ctypes enqueue costs ~7 us per launch otherwise)
             side = torch.cuda.Stream(device=dev)
@@ -155,8 +170,7 @@ def main():
                     for _ in range(n_launch):
                         env.rollout(args.policy, n_iter=n_iter, autoreset=True)
             torch.cuda.current_stream(dev).wait_stream(side)
-        if world > 1:
-            dist.barrier()
+        barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record()
@@ -167,8 +181,7 @@ def main():
                 env.rollout(args.policy, n_iter=n_iter, autoreset=True)
         ev1.record()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        barrier()
         dt = time.perf_counter() - t0
         return dt, ev0.elapsed_time(ev1) / n_launch
 
@@ -176,10 +189,23 @@ def main():
     for _ in range(args.warmup):
         env.rollout(args.policy, n_iter=1, autoreset=True)
     torch.cuda.synchronize()
+
+    def pick_mode(e):
+        if args.launch != "auto":
+            return args.launch
+        probe = {m: timed(e, 40, 1, m)[0] for m in ("graph", "eager")}
+        t = torch.tensor([probe["graph"], probe["eager"]], dtype=torch.float64)
+        if world > 1:   # every rank must take the same decision
+            t = t.to(dev) if backend == "nccl" else t
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return "graph" if float(t[0]) <= float(t[1]) else "eager"
+
+    mode = pick_mode(env)
     env.counters.zero_()
-    dt, kernel_ms = timed(env, args.steps, 1)
+    dt, kernel_ms = timed(env, args.steps, 1, mode)
     # the only collectives: SUM of the 4 counters and MAX of the wall time, over RCCL/xGMI
-    tot = reduce_counters(env.counters, dt)
+    on_host = world > 1 and backend != "nccl"
+    tot = reduce_counters(env.counters.cpu() if on_host else env.counters, dt)
     steps_total, episodes, makespan_sum, reward_num = tot["steps"], tot["episodes"], tot["makespan_sum"], tot["reward_num_sum"]
     dt_max = tot["seconds"]
     value = steps_total / dt_max
@@ -205,7 +231,7 @@ def main():
         "metric": "env steps/sec (batched)", "value": value, "unit": "env steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "launch": "eager" if args.eager else "hipGraph replay of the K launches",
+        "launch": "eager (one ctypes launch per step)" if mode == "eager" else "hipGraph replay of the K launches",
         "config": {"workload": f"{wl_label}, {args.policy} masked "
                                f"policy fused with step(), batch {B} envs per GPU, one launch per env step, "
                                f"full obs/mask/reward/done written every step, auto-restart",
@@ -225,8 +251,8 @@ def main():
         # fused multi-step rollout: 64 iterations per launch, state in registers, outputs once per launch
         env.counters.zero_()
         n_l = max(4, args.steps // 16)
-        dtf, _ = timed(env, n_l, 64)
-        totf = reduce_counters(env.counters, dtf)
+        dtf, _ = timed(env, n_l, 64, "eager")
+        totf = reduce_counters(env.counters.cpu() if on_host else env.counters, dtf)
         out["fused_rollout"] = {"value": totf["steps_per_second"], "unit": "env steps/s",
                                 "iterations_per_launch": 64, "launches": n_l,
                                 "note": "policy+step x64 per launch, observation written once per launch"}
@@ -234,10 +260,11 @@ def main():
             env4k = make_env(4096)
             for _ in range(args.warmup):
                 env4k.rollout(args.policy, n_iter=1, autoreset=True)
+            mode4 = pick_mode(env4k)
             env4k.counters.zero_()
-            dt4, ms4 = timed(env4k, args.steps, 1)
+            dt4, ms4 = timed(env4k, args.steps, 1, mode4)
             out["configs1_batch4096"] = {"value": float(env4k.counters[:, 0].sum().item()) / dt4,
-                                         "unit": "env steps/s", "kernel_ms": ms4}
+                                         "unit": "env steps/s", "kernel_ms": ms4, "launch": mode4}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "shared":
         out["cpu_baseline"] = cpu_baseline(args.instance, args.seed)

@@ -92,3 +92,15 @@ def test_instances_roundtrip_and_taillard():
 def test_parser_rejects_malformed(text):
     with pytest.raises(ValueError):
         I.parse_instance_text(text)
+
+
+def test_render_rows_from_solution():
+    from jssenv_amd.render import gantt_rows
+    inst = I.builtin_instance("ta01")
+    sol = np.full((15, 15), -1)
+    sol[2, 0], sol[2, 1], sol[7, 0] = 0, 40, 5
+    rows = gantt_rows(sol, inst, 1000.0)
+    assert [r["Task"] for r in rows] == ["Job 2", "Job 2", "Job 7"]
+    assert rows[0]["Resource"] == f"Machine {inst.machine[2, 0]}"
+    assert (rows[1]["Finish"] - rows[1]["Start"]).total_seconds() == inst.duration[2, 1]
+    assert gantt_rows(np.full((15, 15), -1), inst, 0.0) == []
