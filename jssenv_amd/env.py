@@ -66,6 +66,12 @@ class HipBackend:
     def shift_right(self, x, n):
         return x >> n
 
+    def where(self, cond, a, b):
+        return self.torch.where(cond, self.torch.as_tensor(a, dtype=b.dtype, device=self.device), b)
+
+    def copy_into(self, dst, src_numpy):
+        dst.copy_(self.torch.from_numpy(np.ascontiguousarray(src_numpy)).to(self.device))
+
 
 class BatchedJssEnv:
     """B independent job-shop envs on one GPU.
@@ -161,18 +167,27 @@ class BatchedJssEnv:
         self._is_reset = True
         return self._obs()
 
-    def step(self, actions):
+    def step(self, actions, autoreset: bool = False):
         """step() of jss_env.py:403-481, one action per env (J = NOPE, -1 = leave the env untouched).
 
-        Returns (obs, reward (B,) float32, done (B,) uint8, truncated=False, info={})."""
+        Returns (obs, reward (B,) float32, done (B,) uint8, truncated=False, info={}).
+        autoreset=True gives gymnasium.vector "next-step" semantics: an env that reported done on the
+        previous call is reset by this call instead of being stepped (its action is ignored, reward 0,
+        done 0) -- one extra masked jss_reset launch, no host synchronisation."""
         if not self._is_reset:
             raise RuntimeError("call reset() before step()")
         be = self.backend
         a = be.as_device(actions, "int32")
         if tuple(a.shape) != (self.batch,):
             raise ValueError("actions must have shape (B,)")
+        if autoreset:
+            was_done = self.done.clone() if hasattr(self.done, "clone") else self.done.copy()
+            a = be.where(was_done != 0, -1, a)
         _abi.check(be.lib, be.lib.jss_step(C.byref(self._desc), C.byref(self._state), be.ptr(a), C.byref(self._out),
                                            be.stream()), "jss_step")
+        if autoreset:
+            _abi.check(be.lib, be.lib.jss_reset(C.byref(self._desc), C.byref(self._state), C.byref(self._out),
+                                                be.ptr(was_done), be.stream()), "jss_reset")
         return self._obs(), self.reward, self.done, False, {}
 
     def increase_time_step(self, which=None):
@@ -269,6 +284,28 @@ class BatchedJssEnv:
         """Host dict of the per-env counters summed over the batch."""
         c = self.backend.numpy(self.counters).sum(axis=0)
         return {"steps": int(c[0]), "episodes": int(c[1]), "makespan_sum": int(c[2]), "reward_num_sum": int(c[3])}
+
+    # -- checkpoint / resume (SURVEY row N3): the state is a handful of tensors --------------------
+    _STATE_TENSORS = ("env_header", "job_state", "machine_state", "solution", "counters", "real_obs", "action_mask",
+                      "reward", "done", "makespan")
+
+    def state_dict(self):
+        """Host copy of everything needed to resume: state + last outputs + the batch description."""
+        n = self.backend.numpy
+        d = {k: n(getattr(self, k)) for k in self._STATE_TENSORS}
+        d["meta"] = {"batch": self.batch, "jmax": self.jmax, "mmax": self.mmax, "seed": self.seed,
+                     "env_id_base": self.env_id_base, "instances": [i.name for i in self.instances],
+                     "table_of_env": self.table_of_env_host.copy(), "ops": self.packed.ops.copy()}
+        return d
+
+    def load_state_dict(self, d):
+        m = d["meta"]
+        if (m["batch"], m["jmax"], m["mmax"]) != (self.batch, self.jmax, self.mmax) or \
+                not np.array_equal(m["ops"], self.packed.ops) or not np.array_equal(m["table_of_env"], self.table_of_env_host):
+            raise ValueError("checkpoint belongs to a different batch (shape or instances differ)")
+        for k in self._STATE_TENSORS:
+            self.backend.copy_into(getattr(self, k), d[k])
+        self.seed, self._is_reset = int(m["seed"]), True
 
     def host_state(self, i: int = 0):
         """Everything about env i as NumPy, sliced to its true (J, M)."""

@@ -59,3 +59,9 @@ class EmuBackend:
 
     def shift_right(self, x, n):
         return x >> n
+
+    def where(self, cond, a, b):
+        return np.where(cond, np.asarray(a, dtype=b.dtype), b).astype(b.dtype)
+
+    def copy_into(self, dst, src_numpy):
+        dst[...] = src_numpy

@@ -16,6 +16,13 @@ from oracle import OracleEnv
 OBS_TOL = 1e-6
 
 
+def reward_close(got, want):
+    """reward = integer numerator / max_time_op as float32.  It is not confined to [0, 1] (|r| reaches
+    tens on wide instances), so float32 rounding alone exceeds 1e-6 absolute there: the bar is 1e-6
+    relative (1e-6 absolute below 1).  The exact integer numerator is checked through `counters`."""
+    return abs(got - want) <= OBS_TOL * max(1.0, abs(want))
+
+
 def assert_matches_oracle(h, orc, where, fresh_col0=True, check_outputs=True):
     """h = BatchedJssEnv.host_state(i); orc = OracleEnv in the same state."""
     J = orc.jobs
@@ -73,7 +80,7 @@ def replay_golden_through_facade(backend, golden_name, inst, max_rows=None, chec
         else:
             _, r1, d1, t1, info = env.step(a)
             _, r2, d2, _, _ = orc.step(a)
-            assert abs(r1 - g["reward"][i]) <= OBS_TOL and abs(r1 - r2) <= OBS_TOL, f"{where}: reward {r1} vs {g['reward'][i]}"
+            assert reward_close(r1, g["reward"][i]) and reward_close(r1, r2), f"{where}: reward {r1} vs {g['reward'][i]}"
             assert d1 == bool(g["done"][i]) == d2, f"{where}: done"
             assert t1 is False and info == {}
         # golden rows (the reference's own values) ...
@@ -138,7 +145,7 @@ def case_batch_lockstep(backend, inst_names, batch, n_steps, kind="random", seed
             if acts[i] == -1:
                 continue
             _, r, d, _, _ = o.step(int(acts[i]))
-            assert abs(float(reward[i]) - r) <= OBS_TOL, f"iter {it} env {i}: reward {reward[i]} vs {r}"
+            assert reward_close(float(reward[i]), r), f"iter {it} env {i}: reward {reward[i]} vs {r}"
             assert bool(done[i]) == d, f"iter {it} env {i}: done"
             done_seen[i] |= d
         if it % check_every == 0 or it == n_steps - 1:
@@ -340,3 +347,90 @@ def case_dispatching_deterministic(backend, rules=("SPT", "FIFO", "MWR", "LWR", 
     assert set(D.DISPATCHING_RULES) == {"SPT", "FIFO", "MWR", "LWR", "MOR", "LOR", "CR"}
     res = D.compare_rules(JssEnv({"instance_path": "ta01"}, _backend=backend), rules=["SPT"], num_episodes=1)
     assert set(res["SPT"]) == {"avg_reward", "avg_makespan"} and res["SPT"]["avg_makespan"] > 0
+
+
+# -----------------------------------------------------------------------------------------
+# edge shapes: the limits include/jss_hip.h promises (J <= 128, M <= 64, durations <= 65535)
+# -----------------------------------------------------------------------------------------
+def random_instance(rng, jobs, machines, max_dur=99, permutation=True, name=None):
+    if permutation:
+        machine = np.stack([rng.permutation(machines) for _ in range(jobs)]).astype(np.int32)
+    else:  # machines may repeat inside a job (the reference's parser does not forbid it)
+        machine = rng.integers(0, machines, size=(jobs, machines)).astype(np.int32)
+    duration = rng.integers(1, max_dur + 1, size=(jobs, machines)).astype(np.int32)
+    return I.Instance(name or f"rnd_{jobs}x{machines}", machine, duration)
+
+
+EDGE_SHAPES = [(1, 2), (2, 2), (3, 7), (5, 16), (16, 16), (16, 5), (17, 3), (32, 32), (32, 2), (33, 4), (8, 40),
+               (64, 6), (65, 3), (12, 64), (128, 2)]
+
+
+def case_edge_shapes(backend, shapes=EDGE_SHAPES, steps=40, seed=2024, batch_per_shape=3):
+    rng = np.random.default_rng(seed)
+    for (J, M) in shapes:
+        insts = [random_instance(rng, J, M, max_dur=(65535 if (J + M) % 5 == 0 else 99),
+                                 permutation=((J * M) % 3 != 0)) for _ in range(batch_per_shape)]
+        env, orcs = case_batch_lockstep(backend, insts, batch=batch_per_shape, n_steps=steps, kind="random",
+                                        seed=seed + J, nope_every=5, check_every=4)
+        # and a fused rollout on the same shapes (auto-restart crosses episode boundaries on the tiny ones)
+        env2 = BatchedJssEnv(insts, seed=seed, env_id_base=77, _backend=backend)
+        orcs2 = [OracleEnv(i, strict=True) for i in insts]
+        env2.reset()
+        env2.rollout("random", n_iter=steps, seed=seed)
+        for i, o in enumerate(orcs2):
+            o.reset()
+            o.rollout("random", seed, 77 + i, steps, episode=1)
+            assert_matches_oracle(env2.host_state(i), o, f"edge {J}x{M} rollout env {i}")
+
+
+def case_vector_env_features(backend):
+    """step(autoreset=True) (gymnasium.vector next-step semantics) and state_dict round trip."""
+    inst = I.builtin_instance("ta01")
+    B, seed = 6, 3
+    env = BatchedJssEnv(inst, batch=B, seed=seed, _backend=backend)
+    orcs = [OracleEnv(inst, strict=True) for _ in range(B)]
+    env.reset()
+    for o in orcs:
+        o.reset()
+    prev_done = np.zeros(B, dtype=bool)
+    resets = 0
+    ckpt = None
+    for it in range(330):
+        acts = env.backend.numpy(env.policy("random")).astype(np.int64)
+        _, reward, done, _, _ = env.step(acts, autoreset=True)
+        done = env.backend.numpy(done).astype(bool)
+        for i, o in enumerate(orcs):
+            if prev_done[i]:
+                o.reset()
+                resets += 1
+                assert not done[i]
+            elif acts[i] >= 0:
+                _, r, d, _, _ = o.step(int(acts[i]))
+                assert d == done[i]
+        prev_done = done
+        if it % 30 == 0:
+            for i, o in enumerate(orcs):
+                assert_matches_oracle(env.host_state(i), o, f"autoreset iter {it} env {i}")
+        if it == 100:
+            ckpt = env.state_dict()
+            expect = [env.host_state(i) for i in range(B)]
+    assert resets >= B
+    # resume the checkpoint in a fresh env object: same state, and the same future
+    env2 = BatchedJssEnv(inst, batch=B, seed=seed, _backend=backend)
+    env2.load_state_dict(ckpt)
+    for i in range(B):
+        h = env2.host_state(i)
+        assert h["clock"] == expect[i]["clock"] and (h["job_state"] == expect[i]["job_state"]).all()
+        assert (h["solution"] == expect[i]["solution"]).all() and h["step_in_episode"] == expect[i]["step_in_episode"]
+    env.load_state_dict(ckpt)
+    env.rollout("random", n_iter=50)
+    env2.rollout("random", n_iter=50)
+    for i in range(B):
+        a, b = env.host_state(i), env2.host_state(i)
+        assert a["clock"] == b["clock"] and (a["job_state"] == b["job_state"]).all() and (a["obs"] == b["obs"]).all()
+    other = BatchedJssEnv(I.builtin_instance("ta02"), batch=B, _backend=backend)
+    try:
+        other.load_state_dict(ckpt)
+        raise AssertionError("checkpoint of another instance must be rejected")
+    except ValueError:
+        pass

@@ -163,3 +163,11 @@ def test_config4_synthetic_50x20(hip):
 def test_dispatching_module(hip):
     P.case_dispatching_seeded(hip)
     P.case_dispatching_deterministic(hip, insts=("ta01", "ta41"))
+
+
+def test_edge_shapes(hip):
+    P.case_edge_shapes(hip, steps=300, batch_per_shape=5)
+
+
+def test_vector_env_features(hip):
+    P.case_vector_env_features(hip)

@@ -78,3 +78,11 @@ def test_state_invariants(emu):
 def test_dispatching_module(emu):
     P.case_dispatching_seeded(emu, keys=["trace_FIFO_ta01_0", "trace_SPT_ta01_1"])
     P.case_dispatching_deterministic(emu, rules=("SPT", "CR"))
+
+
+def test_edge_shapes(emu):
+    P.case_edge_shapes(emu, steps=24, batch_per_shape=2)
+
+
+def test_vector_env_features(emu):
+    P.case_vector_env_features(emu)
