@@ -153,6 +153,8 @@ const char *jss_error_string(int code);
 #define JSS_ABLATE_OBS 4
 #define JSS_ABLATE_SELECT 8
 #define JSS_ABLATE_ADVANCE 16
+/* JSS_OPT_LDS_PAD (profiling aid): extra dynamic LDS bytes per workgroup, to cap occupancy in experiments. */
+#define JSS_OPT_LDS_PAD 2
 int jss_set_option(int option, int value);
 
 /* reset every env (which == NULL) or the envs with which[i] != 0 */

@@ -22,6 +22,7 @@ POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR":
 ROLLOUT_AUTORESET = 1
 OPT_KERNEL, KERNEL_AUTO, KERNEL_WAVE = 0, 0, 1
 OPT_ABLATE = 1
+OPT_LDS_PAD = 2
 
 SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_set_option", "jss_reset", "jss_step", "jss_advance", "jss_policy", "jss_rollout")
 
@@ -43,7 +44,8 @@ class JssOut(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libjss_hip.so")
+    """In-tree libjss_hip.so; JSSENV_AMD_LIB points development builds at another build of the same ABI."""
+    return os.environ.get("JSSENV_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libjss_hip.so")
 
 
 def bind(lib):

@@ -30,6 +30,7 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
 
 int g_kernel_choice = JSS_KERNEL_AUTO;
 int g_ablate = 0;
+int g_lds_pad = 0;
 
 // Kernel flavour for a batch shape: the packed kernel needs every env's jobs AND machines to fit
 // a 16- or 32-lane group.
@@ -54,7 +55,7 @@ int launch(Params &p, void *stream) {
         const int n_regions = p.shared_table ? 1 : envs_per_block;
         p.obs_off_ints = (n_regions * p.region_ints + 3) & ~3;
         p.obs_wave_floats = ((kWave / G) * p.d.jmax * 7 + 3) & ~3;
-        const size_t shmem = sizeof(int32_t) * (size_t)p.obs_off_ints + sizeof(float) * kWavesPerBlock * p.obs_wave_floats;
+        const size_t shmem = sizeof(int32_t) * (size_t)p.obs_off_ints + sizeof(float) * kWavesPerBlock * p.obs_wave_floats + g_lds_pad;
         const int blocks = (p.d.batch + envs_per_block - 1) / envs_per_block;
         if (G == 16)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed_kernel<16, MODE>), dim3(blocks), dim3(kBlock), shmem, st, p);
@@ -81,6 +82,10 @@ int jss_abi_version(void) { return JSS_ABI_VERSION; }
 int jss_set_option(int option, int value) {
     if (option == JSS_OPT_KERNEL && value >= JSS_KERNEL_AUTO && value <= JSS_KERNEL_WAVE) {
         g_kernel_choice = value;
+        return 0;
+    }
+    if (option == JSS_OPT_LDS_PAD && value >= 0 && value <= 150000) {
+        g_lds_pad = value;
         return 0;
     }
     if (option == JSS_OPT_ABLATE) {
