@@ -91,6 +91,9 @@ def main():
                     help="graph: replay a hipGraph of the K launches; eager: one Python/ctypes launch per step; "
                          "auto: whichever is faster on a short probe (graphs win when the kernel is shorter than "
                          "the ~7 us host enqueue, eager wins at large batches)")
+    ap.add_argument("--bucketed", action="store_true",
+                    help="mixed workload only: one compact sub-batch per shape class (BucketedJssEnv) instead of "
+                         "padding every env to 100x20")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="debug: every rank uses cuda:0 (exercises the multi-process path on a 1-GPU box; use with "
@@ -139,6 +142,13 @@ def main():
 
     def make_env(batch):
         insts, _, _ = instances_for(batch)
+        if args.bucketed and args.workload == "mixed":
+            from jssenv_amd import BucketedJssEnv
+            e = BucketedJssEnv(insts, batch=batch, device=dev, seed=args.seed, env_id_base=rank * batch)
+            e.reset()
+            e.rollout(args.policy, n_iter=333, autoreset=True)
+            e.zero_counters()
+            return e
         e = BatchedJssEnv(insts, batch=batch, device=dev, seed=args.seed, env_id_base=rank * batch)
         e.reset()
         # Spread the episode phases (a fresh batch is in lock step: every env at step 0) so the timed
@@ -151,7 +161,7 @@ def main():
                 a = torch.where(ids > r, a, torch.full_like(a, -1))
                 e.step(a)
         e.rollout(args.policy, n_iter=64, autoreset=True)
-        e.counters.zero_()
+        e.zero_counters()
         return e
 
     def timed(env, n_launch, n_iter, mode):
@@ -201,11 +211,11 @@ def main():
         return "graph" if float(t[0]) <= float(t[1]) else "eager"
 
     mode = pick_mode(env)
-    env.counters.zero_()
+    env.zero_counters()
     dt, kernel_ms = timed(env, args.steps, 1, mode)
     # the only collectives: SUM of the 4 counters and MAX of the wall time, over RCCL/xGMI
     on_host = world > 1 and backend != "nccl"
-    tot = reduce_counters(env.counters.cpu() if on_host else env.counters, dt)
+    tot = reduce_counters(env.counter_totals().cpu() if on_host else env.counter_totals(), dt)
     steps_total, episodes, makespan_sum, reward_num = tot["steps"], tot["episodes"], tot["makespan_sum"], tot["reward_num_sum"]
     dt_max = tot["seconds"]
     value = steps_total / dt_max
@@ -218,6 +228,9 @@ def main():
     jm, mm = env.jmax, env.mmax
     kernel_name = ("jss_packed_kernel<%d,kRollout1>" % (16 if max(jm, mm) <= 16 else 32)
                    if max(jm, mm) <= 32 else "jss_kernel<%d,kRollout1>" % (1 if jm <= 64 else 2))
+    if args.bucketed and args.workload == "mixed":
+        kernel_name = "four launches per step: jss_packed_kernel<16|32,kRollout1>, jss_kernel<1|2,kRollout1>"
+        wl_label += ", shape-bucketed (no padding)"
     traffic = None
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.isfile(prof):
@@ -249,10 +262,10 @@ def main():
 
     if not args.no_extras:
         # fused multi-step rollout: 64 iterations per launch, state in registers, outputs once per launch
-        env.counters.zero_()
+        env.zero_counters()
         n_l = max(4, args.steps // 16)
         dtf, _ = timed(env, n_l, 64, "eager")
-        totf = reduce_counters(env.counters.cpu() if on_host else env.counters, dtf)
+        totf = reduce_counters(env.counter_totals().cpu() if on_host else env.counter_totals(), dtf)
         out["fused_rollout"] = {"value": totf["steps_per_second"], "unit": "env steps/s",
                                 "iterations_per_launch": 64, "launches": n_l,
                                 "note": "policy+step x64 per launch, observation written once per launch"}

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define JSS_ABI_VERSION 2
+#define JSS_ABI_VERSION 3
 
 #define JSS_MAX_JOBS 128
 #define JSS_MAX_MACHINES 64
@@ -117,6 +117,7 @@ typedef struct JssDesc {
     const int32_t *sum_op;       /* [n_tables] jss_env.py:88                                */
     const int32_t *table_of_env; /* [B] instance of env i; NULL: 0 if n_tables==1 else i    */
     int64_t env_id_base;         /* global id of env 0 (keys the RNG stream under sharding) */
+    const int64_t *env_ids;      /* [B] explicit global ids (shape-bucketed batches); NULL: env_id_base + i */
 } JssDesc;
 
 typedef struct JssState {

@@ -9,6 +9,7 @@ with hand-written HIP kernels (``csrc/jss_kernels.hip``) behind a C ABI
 from .instances import (Instance, available_instances, builtin_instance, load_instance_file,  # noqa: F401
                         parse_instance_text, synthetic_batch, taillard_instance)
 from .env import BatchedJssEnv, HipBackend, JssEnv, make  # noqa: F401
+from .bucketed import BucketedJssEnv  # noqa: F401
 
 __version__ = "0.1.0"
 

@@ -1,0 +1,133 @@
+"""Shape-bucketed batches: ragged instance mixes without the padding cost.
+
+``BatchedJssEnv`` pads every env of a batch to the largest (Jmax, Mmax), and the kernel
+flavour is chosen from that padded shape: one 15x15 env in a batch that also holds a 100x20
+instance runs on the two-jobs-per-lane wave kernel with 85 % of its lanes idle.
+``BucketedJssEnv`` splits the envs into shape classes
+
+    class 0: J, M <= 16   -> packed kernel, 4 envs per wavefront
+    class 1: J, M <= 32   -> packed kernel, 2 envs per wavefront
+    class 2: J <= 64      -> one wavefront per env
+    class 3: J <= 128     -> one wavefront per env, two jobs per lane
+
+each backed by its own compactly padded ``BatchedJssEnv`` (own tensors, own launches, all
+on the caller's stream).  Env ``i`` of the wrapper lives at ``slot[i]`` of bucket
+``bucket_of[i]``; the per-env RNG key stays the global env id, so a bucketed run is the same
+random process as the padded one.  Outputs stay per bucket (an RL policy on ragged
+instances batches by shape anyway); ``gather()`` assembles padded (B, Jmax, ...) views on
+demand.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .env import BatchedJssEnv
+from .instances import resolve_instance
+
+
+def shape_class(jobs: int, machines: int) -> int:
+    if jobs <= 16 and machines <= 16:
+        return 0
+    if jobs <= 32 and machines <= 32:
+        return 1
+    return 2 if jobs <= 64 else 3
+
+
+class BucketedJssEnv:
+    def __init__(self, instances: Sequence, batch: Optional[int] = None, device=None, seed: int = 0,
+                 env_id_base: int = 0, concurrent: bool = True, _backend=None):
+        insts = [resolve_instance(i) for i in instances]
+        n = len(insts)
+        self.batch = B = int(batch) if batch is not None else n
+        self.table_of_env = np.arange(B) % n
+        cls = np.array([shape_class(i.jobs, i.machines) for i in insts])
+        self.bucket_of = cls[self.table_of_env]
+        self.slot = np.zeros(B, dtype=np.int64)
+        self.buckets: List[Optional[BatchedJssEnv]] = [None] * 4
+        self.members: List[np.ndarray] = [np.zeros(0, dtype=np.int64)] * 4
+        self.jmax = max(i.jobs for i in insts)
+        self.mmax = max(i.machines for i in insts)
+        for k in range(4):
+            env_ids = np.flatnonzero(self.bucket_of == k)
+            self.members[k] = env_ids
+            if env_ids.size == 0:
+                continue
+            self.slot[env_ids] = np.arange(env_ids.size)
+            tables = sorted(set(self.table_of_env[env_ids].tolist()))
+            remap = {t: i for i, t in enumerate(tables)}
+            sub = BatchedJssEnv([insts[t] for t in tables], batch=env_ids.size, device=device, seed=seed,
+                                table_of_env=[remap[t] for t in self.table_of_env[env_ids]], _backend=_backend)
+            # RNG streams are keyed by the GLOBAL env id: give the bucket an explicit id list when its
+            # members are not a contiguous range
+            sub.set_env_ids(env_id_base + env_ids)
+            self.buckets[k] = sub
+
+        # one side stream per bucket: the buckets are independent env sets, so their launches may overlap.
+        # Every call forks from / joins back to the caller's current stream, so callers see ordinary
+        # stream-ordered semantics (and a graph capture of the caller's stream records the fork/join too).
+        self._torch = getattr(self._each()[0][1].backend, "torch", None) if concurrent else None
+        self._streams = None
+        if self._torch is not None and len(self._each()) > 1:
+            dev = self._each()[0][1].backend.device
+            self._streams = {k: self._torch.cuda.Stream(device=dev) for k, _ in self._each()}
+
+    def _each(self):
+        return [(k, b) for k, b in enumerate(self.buckets) if b is not None]
+
+    def _fan_out(self, fn):
+        """fn(k, bucket) per bucket, each on its own stream when available."""
+        if self._streams is None:
+            return {k: fn(k, b) for k, b in self._each()}
+        t = self._torch
+        main = t.cuda.current_stream()
+        fork = t.cuda.Event()
+        fork.record(main)
+        out = {}
+        for k, b in self._each():
+            st = self._streams[k]
+            st.wait_event(fork)
+            with t.cuda.stream(st):
+                out[k] = fn(k, b)
+            done = t.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
+        return out
+
+    def reset(self):
+        return self._fan_out(lambda k, b: b.reset())
+
+    def rollout(self, kind="random", n_iter=1, seed=None, autoreset=True, explore=0.0):
+        self._fan_out(lambda k, b: b.rollout(kind, n_iter=n_iter, seed=seed, autoreset=autoreset, explore=explore))
+
+    def policy(self, kind="random", seed=None, explore=0.0):
+        return self._fan_out(lambda k, b: b.policy(kind, seed=seed, explore=explore))
+
+    def step(self, actions_per_bucket):
+        return self._fan_out(lambda k, b: b.step(actions_per_bucket[k]))
+
+    def synchronize(self):
+        for _, b in self._each():
+            b.synchronize()
+
+    def counter_totals(self):
+        parts = [b.counter_totals() for _, b in self._each()]
+        tot = parts[0]
+        for x in parts[1:]:
+            tot = tot + x
+        return tot
+
+    def zero_counters(self):
+        for _, b in self._each():
+            b.zero_counters()
+
+    def stats(self):
+        tot = {"steps": 0, "episodes": 0, "makespan_sum": 0, "reward_num_sum": 0}
+        for _, b in self._each():
+            for key, v in b.stats().items():
+                tot[key] += v
+        return tot
+
+    def host_state(self, i: int):
+        return self.buckets[self.bucket_of[i]].host_state(int(self.slot[i]))

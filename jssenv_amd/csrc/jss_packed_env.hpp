@@ -526,12 +526,12 @@ __global__ __launch_bounds__(kBlock) void jss_packed_kernel(Params p) {
         const int hole = p_advance(e, c, on && busy, d);
         if (on && c.gl == 0 && p.hole) p.hole[c.b] = busy ? hole : 0;
     } else if (MODE == kPolicy) {
-        const int a = p_select(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_id_base + c.b),
+        const int a = p_select(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_ids ? p.d.env_ids[c.b] : p.d.env_id_base + c.b),
                                (uint32_t)hd.episode, (uint32_t)hd.step);
         if (c.alive && c.gl == 0) p.actions_out[c.b] = a;
         return;
     } else {  // kRollout / kRollout1
-        const uint64_t env_id = (uint64_t)(p.d.env_id_base + c.b);
+        const uint64_t env_id = (uint64_t)(p.d.env_ids ? p.d.env_ids[c.b] : p.d.env_id_base + c.b);
         int n_steps = 0, n_done = 0, last_rn = 0, last_makespan = -1, sum_makespan = 0, sum_rn = 0;
         const bool autoreset = (p.flags & JSS_ROLLOUT_AUTORESET) != 0;
         const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;

@@ -584,12 +584,12 @@ __global__ __launch_bounds__(kBlock) void jss_kernel(Params p) {
         else hole = advance(e, c);
         if (lane == 0 && p.hole) p.hole[b] = hole;
     } else if (MODE == kPolicy) {
-        const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_id_base + b),
+        const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_ids ? p.d.env_ids[b] : p.d.env_id_base + b),
                                     (uint32_t)hd.episode, (uint32_t)hd.step);
         if (lane == 0) p.actions_out[b] = a;
         return;
     } else {  // kRollout / kRollout1: n_iter x (policy + step), state stays in registers
-        const uint64_t env_id = (uint64_t)(p.d.env_id_base + b);
+        const uint64_t env_id = (uint64_t)(p.d.env_ids ? p.d.env_ids[b] : p.d.env_id_base + b);
         int n_steps = 0, n_done = 0, sum_makespan = 0, sum_rn = 0;
         int last_rn = 0, last_makespan = -1;
         const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;

@@ -133,11 +133,20 @@ class BatchedJssEnv:
 
         p = be.ptr
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._jobs), p(self._machines), p(self._max_time_op),
-                                  p(self._max_time_jobs), p(self._sum_op), p(self._table_of_env), self.env_id_base)
+                                  p(self._max_time_jobs), p(self._sum_op), p(self._table_of_env), self.env_id_base, None)
         self._state = _abi.JssState(p(self.env_header), p(self.job_state), p(self.machine_state), p(self.solution),
                                     p(self.counters))
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
         self._is_reset = False
+
+    def set_env_ids(self, ids):
+        """Explicit global env ids (int64, one per env) keying the per-env RNG streams; used by
+        BucketedJssEnv, whose buckets hold non-contiguous slices of the global batch."""
+        ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64))
+        if ids.shape != (self.batch,):
+            raise ValueError("env ids must have shape (B,)")
+        self._env_ids = self.backend.from_numpy(ids)
+        self._desc.env_ids = self.backend.ptr(self._env_ids)
 
     # -- raw ABI handles (bench.py launches through these) -------------------------------
     @property
@@ -279,6 +288,13 @@ class BatchedJssEnv:
     @property
     def action_illegal_no_op(self):
         return self.backend.shift_right(self.job_state[:, :, _abi.F_FLAGS], 1) & 1
+
+    def counter_totals(self):
+        """Device tensor [4]: env steps, finished episodes, sum of makespans, sum of reward numerators."""
+        return self.counters.sum(0)
+
+    def zero_counters(self):
+        self.counters[...] = 0
 
     def stats(self):
         """Host dict of the per-env counters summed over the batch."""

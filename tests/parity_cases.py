@@ -434,3 +434,30 @@ def case_vector_env_features(backend):
         raise AssertionError("checkpoint of another instance must be rejected")
     except ValueError:
         pass
+
+
+def case_bucketed_equals_padded(backend, n_envs=24, n_iter=260, seed=13):
+    """BucketedJssEnv (per-shape-class tensors and kernels) is the same random process as the padded batch."""
+    from jssenv_amd.bucketed import BucketedJssEnv, shape_class
+    names = ["ta01", "ta11", "ta21", "ta31", "ta41", "ta51", "ta61", "ta71"]
+    insts = [I.builtin_instance(n) for n in names]
+    assert [shape_class(i.jobs, i.machines) for i in insts] == [0, 1, 1, 1, 1, 2, 2, 3]
+    padded = BatchedJssEnv(insts, batch=n_envs, seed=seed, env_id_base=500, _backend=backend)
+    bucketed = BucketedJssEnv(insts, batch=n_envs, seed=seed, env_id_base=500, _backend=backend)
+    padded.reset()
+    bucketed.reset()
+    padded.rollout("random", n_iter=n_iter)
+    bucketed.rollout("random", n_iter=n_iter)
+    for i in range(n_envs):
+        a, b = padded.host_state(i), bucketed.host_state(i)
+        assert a["clock"] == b["clock"] and (a["job_state"] == b["job_state"]).all(), f"env {i}"
+        assert (a["solution"] == b["solution"]).all() and (a["mask"] == b["mask"]).all() and (a["tm"] == b["tm"]).all()
+        assert np.abs(a["obs"] - b["obs"]).max() == 0 and a["episode"] == b["episode"]
+    sa, sb = padded.stats(), bucketed.stats()
+    assert sa == sb and sa["steps"] > 0
+    # and both agree with the oracle
+    for i in (0, 5, 7, 23):
+        o = OracleEnv(insts[i % len(insts)], strict=True)
+        o.reset()
+        o.rollout("random", seed, 500 + i, n_iter, episode=1)
+        assert_matches_oracle(bucketed.host_state(i), o, f"bucketed env {i}")

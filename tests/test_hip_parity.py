@@ -171,3 +171,7 @@ def test_edge_shapes(hip):
 
 def test_vector_env_features(hip):
     P.case_vector_env_features(hip)
+
+
+def test_bucketed_equals_padded(hip):
+    P.case_bucketed_equals_padded(hip, n_envs=400, n_iter=900)

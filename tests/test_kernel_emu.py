@@ -86,3 +86,7 @@ def test_edge_shapes(emu):
 
 def test_vector_env_features(emu):
     P.case_vector_env_features(emu)
+
+
+def test_bucketed_equals_padded(emu):
+    P.case_bucketed_equals_padded(emu, n_envs=24, n_iter=60)
