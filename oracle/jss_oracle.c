@@ -516,6 +516,16 @@ int orc_policy(const OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32
     return best;
 }
 
+int orc_policy_explore(const OrcEnv *e, int kind, uint64_t seed, uint32_t explore_q16, uint64_t env_id, uint32_t episode,
+                       uint32_t step) {
+    int a = orc_policy(e, kind, seed, env_id, episode, step);
+    if (kind != ORC_POLICY_RANDOM && a >= 0 && explore_q16 != 0 && e->legal_actions[e->jobs]) { /* dispatching.py:113 */
+        uint32_t r = orc_rng_u32(seed ^ ORC_EXPLORE_SEED_XOR, env_id, episode, step);
+        if ((r >> 16) < explore_q16) a = e->jobs;
+    }
+    return a;
+}
+
 long orc_rollout(OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32_t *episode, uint32_t *step_in_episode,
                  long iterations, long counters[3], double *reward_sum) {
     long executed = 0;

@@ -78,6 +78,11 @@ const double  *orc_state(const OrcEnv *e);                         /* [J*7] */
 
 uint32_t orc_rng_u32(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step);
 int orc_policy(const OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step);
+/* same with the rules' NOPE exploration (dispatching.py:113): when NOPE is legal, answer NOPE with
+ * probability explore_q16 / 65536, drawn from the counter RNG keyed with seed ^ ORC_EXPLORE_SEED_XOR */
+#define ORC_EXPLORE_SEED_XOR 0x5851F42D4C957F2DULL
+int orc_policy_explore(const OrcEnv *e, int kind, uint64_t seed, uint32_t explore_q16, uint64_t env_id, uint32_t episode,
+                       uint32_t step);
 
 /* Run `steps` policy+step iterations with auto-restart (an env found done is
  * reset instead of stepped; that iteration is not counted).  Accumulates

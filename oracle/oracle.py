@@ -64,6 +64,8 @@ def _load():
     lib.orc_rng_u32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     lib.orc_policy.restype = C.c_int
     lib.orc_policy.argtypes = [P, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+    lib.orc_policy_explore.restype = C.c_int
+    lib.orc_policy_explore.argtypes = [P, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
     lib.orc_rollout.restype = C.c_long
     lib.orc_rollout.argtypes = [P, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                 C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_double)]
@@ -163,9 +165,10 @@ class OracleEnv:
             raise IndexError("pop from empty list")  # what the reference raises (jss_env.py:517)
         return hole.value
 
-    def policy(self, kind, seed=0, env_id=0, episode=0, step=0):
+    def policy(self, kind, seed=0, env_id=0, episode=0, step=0, explore=0.0):
         k = POLICY_IDS[kind] if isinstance(kind, str) else int(kind)
-        return int(self._lib.orc_policy(self._h, k, seed, env_id, episode, step))
+        q16 = int(round(explore * 65536))
+        return int(self._lib.orc_policy_explore(self._h, k, seed, q16, env_id, episode, step))
 
     def rollout(self, kind, seed, env_id, iterations, episode=0, step_in_episode=0):
         """Returns dict(steps, episodes, makespan_sum, reward_sum, episode, step_in_episode)."""

@@ -130,8 +130,7 @@ def case_batch_lockstep(backend, inst_names, batch, n_steps, kind="random", seed
     for it in range(n_steps):
         acts = be.numpy(env.policy(kind, explore=explore)).astype(np.int64)
         for i, o in enumerate(orcs):  # the device selector must agree with the oracle's (same counter RNG)
-            want = o.policy(kind, seed=seed, env_id=1000 + i, episode=o.episode, step=o.step_in_episode) \
-                if explore == 0.0 else None
+            want = o.policy(kind, seed=seed, env_id=1000 + i, episode=o.episode, step=o.step_in_episode, explore=explore)
             if want is not None:
                 assert acts[i] == want, f"iter {it} env {i}: policy {kind} chose {acts[i]}, oracle {want}"
         if nope_every and it % nope_every == nope_every - 1:

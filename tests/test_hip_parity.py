@@ -175,3 +175,9 @@ def test_vector_env_features(hip):
 
 def test_bucketed_equals_padded(hip):
     P.case_bucketed_equals_padded(hip, n_envs=400, n_iter=900)
+
+
+def test_rules_with_exploration(hip):
+    """the rules' 10 % NOPE exploration (dispatching.py:113) drawn from the counter RNG on the device"""
+    env, orcs = P.case_batch_lockstep(hip, ["ta01", "ta21"], batch=4, n_steps=1200, kind="SPT", check_every=9, explore=0.1)
+    env, orcs = P.case_batch_lockstep(hip, ["ta71"], batch=2, n_steps=1200, kind="FIFO", check_every=9, explore=0.25)
