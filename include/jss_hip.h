@@ -28,9 +28,10 @@
  *     tensors).  The library never allocates, frees or synchronises.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*).
  *   - return value: 0 = launched, <0 = argument error (JSS_E_*), >0 = hipError_t.
- *   - one wavefront (64 lanes) simulates one env: job j lives on lane j % 64 (slot
- *     j / 64), machine m on lane m.  Limits: jobs <= 128, machines <= 64,
- *     durations in [1, 65535].
+ *   - kernels: when every env of the batch has jobs, machines <= 32, 64/G envs share a
+ *     wavefront (G = 16 or 32 lanes per env); otherwise one wavefront simulates one env
+ *     (job j on lane j % 64, slot j / 64; machine m on lane m).  Limits: jobs <= 128,
+ *     machines <= 64, durations in [1, 65535].
  *
  * Data layout (all row-major, batch outermost)
  *   op table      int32 [n_tables][jmax][mmax]   machine << 16 | duration, 0 = padding

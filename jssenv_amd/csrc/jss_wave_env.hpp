@@ -315,10 +315,10 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
             e.legal[s] &= ~same;                                         // :455-463
             e.blocked[s] &= ~same;                                       // :464-467
         }
-        while (!any_legal(e) && __ballot(e.tm > 0) != 0) rn -= advance(e, c);  // :469-470
+        while (!any_legal(e) && __ballot(e.tm > 0) != 0 && !(p.ablate & JSS_ABLATE_ADVANCE)) rn -= advance(e, c);  // :469-470
     }
-    prioritize(e, c);                                                    // :432 / :471
-    check_no_op(e, c);                                                   // :433 / :472
+    if (!(p.ablate & JSS_ABLATE_PRIORITIZE)) prioritize(e, c);           // :432 / :471
+    if (!(p.ablate & JSS_ABLATE_CHECK_NO_OP)) check_no_op(e, c);         // :433 / :472
     return rn;
 }
 

@@ -11,7 +11,11 @@ from jssenv_amd import BatchedJssEnv, _abi  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 inst = sys.argv[2] if len(sys.argv) > 2 else "ta01"
-env = BatchedJssEnv(inst, batch=B, device="cuda:0")
+if inst == "synthetic50x20":
+    from jssenv_amd import synthetic_batch
+    env = BatchedJssEnv(synthetic_batch(B, 50, 20), device="cuda:0")
+else:
+    env = BatchedJssEnv(inst, batch=B, device="cuda:0")
 env.reset()
 ids = torch.arange(B, device="cuda:0") % 16
 for r in range(15):
