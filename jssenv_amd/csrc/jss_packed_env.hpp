@@ -438,8 +438,9 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, 
 // ---------------------------------------------------------------------------------------
 // the packed kernel
 // ---------------------------------------------------------------------------------------
+// launch bounds: every mode but the multi-iteration rollout fits 64 VGPRs without spilling -> 8 waves per SIMD
 template <int G, int MODE>
-__global__ __launch_bounds__(kBlock) void jss_packed_kernel(Params p) {
+__global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : 8) void jss_packed_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     constexpr int E = kWave / G;                      // envs per wave
     constexpr int EB = E * kWavesPerBlock;            // envs per workgroup

@@ -507,7 +507,7 @@ __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const
 // the kernel: one mode per instantiation
 // ---------------------------------------------------------------------------------------
 template <int JPL, int MODE>
-__global__ __launch_bounds__(kBlock) void jss_kernel(Params p) {
+__global__ __launch_bounds__(kBlock, (MODE == kRollout && JPL == 2) ? 6 : 8) void jss_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -181,3 +181,19 @@ def test_rules_with_exploration(hip):
     """the rules' 10 % NOPE exploration (dispatching.py:113) drawn from the counter RNG on the device"""
     env, orcs = P.case_batch_lockstep(hip, ["ta01", "ta21"], batch=4, n_steps=1200, kind="SPT", check_every=9, explore=0.1)
     env, orcs = P.case_batch_lockstep(hip, ["ta71"], batch=2, n_steps=1200, kind="FIFO", check_every=9, explore=0.25)
+
+
+def test_largest_shape_per_env_tables(hip):
+    """128 jobs x 64 machines, one table per env: ~145 KB of dynamic LDS per workgroup must launch."""
+    rng = np.random.default_rng(0)
+    from jssenv_amd import BatchedJssEnv
+    from oracle import OracleEnv
+    insts = [P.random_instance(rng, 128, 64, max_dur=999) for _ in range(3)]
+    env = BatchedJssEnv(insts, seed=1, _backend=hip)
+    env.reset()
+    env.rollout("random", n_iter=400)
+    for i, inst in enumerate(insts):
+        o = OracleEnv(inst, strict=True)
+        o.reset()
+        o.rollout("random", 1, i, 400, episode=1)
+        P.assert_matches_oracle(env.host_state(i), o, f"128x64 env {i}")

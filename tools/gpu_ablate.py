@@ -62,3 +62,16 @@ for _ in range(500):
 t_enq = (time.perf_counter() - t0) / 500 * 1e6
 torch.cuda.synchronize()
 print(f"eager enqueue+run {t_enq:.2f} us per launch (host path)")
+
+# the two-kernel path an RL trainer with its own policy uses: jss_policy + jss_step
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+st = torch.cuda.Stream()
+with torch.cuda.stream(st):
+    with torch.cuda.graph(g, stream=st):
+        for _ in range(100):
+            env.step(env.policy("random"))
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+print(f"policy + step (2 launches) {e0.elapsed_time(e1) / 100 * 1e3:.2f} us per env step")
