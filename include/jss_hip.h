@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define JSS_ABI_VERSION 3
+#define JSS_ABI_VERSION 4
 
 #define JSS_MAX_JOBS 128
 #define JSS_MAX_MACHINES 64
@@ -119,6 +119,9 @@ typedef struct JssDesc {
     const int32_t *table_of_env; /* [B] instance of env i; NULL: 0 if n_tables==1 else i    */
     int64_t env_id_base;         /* global id of env 0 (keys the RNG stream under sharding) */
     const int64_t *env_ids;      /* [B] explicit global ids (shape-bucketed batches); NULL: env_id_base + i */
+    const uint16_t *ops16;       /* optional compact copy of `ops`: machine << 10 | duration, legal when every
+                                    duration <= 1023.  When set, kernels stage the LDS table from it (half the
+                                    bytes: matters for batches with one instance per env); `ops` stays required */
 } JssDesc;
 
 typedef struct JssState {

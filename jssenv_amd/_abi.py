@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_JOBS, MAX_MACHINES = 128, 64
 F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_FLAGS, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
 FLAG_LEGAL, FLAG_BLOCKED = 1, 2
@@ -32,7 +32,7 @@ _p = C.c_void_p
 class JssDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("jmax", C.c_int32), ("mmax", C.c_int32), ("n_tables", C.c_int32),
                 ("ops", _p), ("jobs", _p), ("machines", _p), ("max_time_op", _p), ("max_time_jobs", _p),
-                ("sum_op", _p), ("table_of_env", _p), ("env_id_base", C.c_int64), ("env_ids", _p)]
+                ("sum_op", _p), ("table_of_env", _p), ("env_id_base", C.c_int64), ("env_ids", _p), ("ops16", _p)]
 
 
 class JssState(C.Structure):

@@ -111,6 +111,36 @@ __device__ __forceinline__ int wave_max(int v) {
     return imax(imax(a, b), imax(c, d));
 }
 
+// Op table -> LDS as int32 (machine << 16 | duration), from the int32 table or, when the batch
+// provides it, from the 16-bit copy (machine << 10 | duration): half the HBM bytes per staged table.
+__device__ __forceinline__ void stage_table(int32_t *dst, const int32_t *ops, const uint16_t *ops16, size_t first,
+                                            int n, int start, int step) {
+    if (ops16) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(ops16 + first);  // `first` is even: tables are jmax*mmax
+        if ((first & 1) == 0) {                                                   // entries with jmax*mmax even or table 0
+            const int pairs = n >> 1;
+            for (int i = start; i < pairs; i += step) {
+                const uint32_t w = src[i];
+                const uint32_t a = w & 0xFFFFu, b = w >> 16;
+                dst[2 * i] = (int32_t)(((a >> 10) << 16) | (a & 1023u));
+                dst[2 * i + 1] = (int32_t)(((b >> 10) << 16) | (b & 1023u));
+            }
+            if ((n & 1) && start == 0) {
+                const uint32_t a = ops16[first + n - 1];
+                dst[n - 1] = (int32_t)(((a >> 10) << 16) | (a & 1023u));
+            }
+        } else {
+            for (int i = start; i < n; i += step) {
+                const uint32_t a = ops16[first + i];
+                dst[i] = (int32_t)(((a >> 10) << 16) | (a & 1023u));
+            }
+        }
+    } else {
+        const int32_t *src = ops + first;
+        for (int i = start; i < n; i += step) dst[i] = src[i];
+    }
+}
+
 // LDS writes of one wave consumed by other lanes of the same wave
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

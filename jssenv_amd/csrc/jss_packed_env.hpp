@@ -479,11 +479,10 @@ __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : 8) void jss_packed_k
     c.ops = table;
     if (p.shared_table) {
         const int n0 = p.d.jobs[0] * p.d.mmax;
-        for (int i = threadIdx.x; i < n0; i += kBlock) lds[i] = p.d.ops[i];
+        stage_table(lds, p.d.ops, p.d.ops16, 0, n0, (int)threadIdx.x, kBlock);
     } else {
-        const int32_t *src = p.d.ops + (size_t)tid * p.d.jmax * p.d.mmax;
         const int n = c.J * p.d.mmax;
-        for (int i = c.gl; i < n; i += G) table[i] = src[i];
+        stage_table(table, p.d.ops, p.d.ops16, (size_t)tid * p.d.jmax * p.d.mmax, n, c.gl, G);
     }
     __syncthreads();
 

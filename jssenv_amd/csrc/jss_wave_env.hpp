@@ -538,11 +538,10 @@ __global__ __launch_bounds__(kBlock, (MODE == kRollout && JPL == 2) ? 6 : 8) voi
     c.stride = p.stride;
     if (p.shared_table) {
         const int n0 = p.d.jobs[0] * p.d.mmax;
-        for (int i = threadIdx.x; i < n0; i += kBlock) lds[i] = p.d.ops[i];
+        stage_table(lds, p.d.ops, p.d.ops16, 0, n0, (int)threadIdx.x, kBlock);
     } else {
-        const int32_t *src = p.d.ops + (size_t)tid * p.d.jmax * p.d.mmax;
         const int n = c.J * p.d.mmax;
-        for (int i = lane; i < n; i += kWave) table[i] = src[i];
+        stage_table(table, p.d.ops, p.d.ops16, (size_t)tid * p.d.jmax * p.d.mmax, n, lane, kWave);
     }
     __syncthreads();
     if (!alive) return;

@@ -117,6 +117,12 @@ class BatchedJssEnv:
         self._max_time_jobs = be.from_numpy(pk.max_time_jobs)
         self._sum_op = be.from_numpy(pk.sum_op)
         self._table_of_env = None if table_of_env is None else be.from_numpy(self.table_of_env_host)
+        # compact 16-bit copy of the op tables (machine << 10 | duration) when every duration fits 10 bits:
+        # halves the bytes a kernel stages per table, which matters when every env has its own instance
+        self._ops16 = None
+        if n > 1 and int(pk.max_time_op.max()) <= 1023:
+            ops16 = (((pk.ops >> 16) << 10) | (pk.ops & 0xFFFF)).astype(np.uint16)
+            self._ops16 = be.from_numpy(ops16.view(np.int16))
         # state (include/jss_hip.h JssState)
         J, M = self.jmax, self.mmax
         self.env_header = be.zeros((B, 4), "int32")          # clock, episode, step_in_episode, status
@@ -133,7 +139,8 @@ class BatchedJssEnv:
 
         p = be.ptr
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._jobs), p(self._machines), p(self._max_time_op),
-                                  p(self._max_time_jobs), p(self._sum_op), p(self._table_of_env), self.env_id_base, None)
+                                  p(self._max_time_jobs), p(self._sum_op), p(self._table_of_env), self.env_id_base, None,
+                                  p(self._ops16))
         self._state = _abi.JssState(p(self.env_header), p(self.job_state), p(self.machine_state), p(self.solution),
                                     p(self.counters))
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
