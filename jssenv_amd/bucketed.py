@@ -72,6 +72,10 @@ class BucketedJssEnv:
         if self._torch is not None and len(self._each()) > 1:
             dev = self._each()[0][1].backend.device
             self._streams = {k: self._torch.cuda.Stream(device=dev) for k, _ in self._each()}
+            # events are allocated once and re-recorded every call (no allocation/destruction while a
+            # hipGraph capture of the caller's stream is in progress)
+            self._fork_event = self._torch.cuda.Event()
+            self._join_events = {k: self._torch.cuda.Event() for k, _ in self._each()}
 
     def _each(self):
         return [(k, b) for k, b in enumerate(self.buckets) if b is not None]
@@ -82,17 +86,16 @@ class BucketedJssEnv:
             return {k: fn(k, b) for k, b in self._each()}
         t = self._torch
         main = t.cuda.current_stream()
-        fork = t.cuda.Event()
-        fork.record(main)
+        self._fork_event.record(main)
         out = {}
         for k, b in self._each():
             st = self._streams[k]
-            st.wait_event(fork)
+            st.wait_event(self._fork_event)
             with t.cuda.stream(st):
                 out[k] = fn(k, b)
-            done = t.cuda.Event()
-            done.record(st)
-            main.wait_event(done)
+            self._join_events[k].record(st)
+        for k, _ in self._each():
+            main.wait_event(self._join_events[k])
         return out
 
     def reset(self):
