@@ -169,7 +169,8 @@ def main():
         GPU ms per launch from HIP events on the launch stream)."""
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         graph = None
-        if mode == "graph":
+        bucketed = hasattr(env, "rollout_steps")
+        if mode == "graph" and not bucketed:
             # the launches go to torch's current stream, so a torch CUDAGraph captures them: one host call
             # replays all n_launch kernels (the Python+ctypes enqueue costs ~7 us per launch otherwise)
             side = torch.cuda.Stream(device=dev)
@@ -186,6 +187,8 @@ def main():
         ev0.record()
         if graph is not None:
             graph.replay()
+        elif bucketed:   # one fork/join around the window, every bucket's launches on its own stream
+            env.rollout_steps(args.policy, steps=n_launch, n_iter=n_iter, autoreset=True)
         else:
             for _ in range(n_launch):
                 env.rollout(args.policy, n_iter=n_iter, autoreset=True)
@@ -201,6 +204,8 @@ def main():
     torch.cuda.synchronize()
 
     def pick_mode(e):
+        if hasattr(e, "rollout_steps"):
+            return "eager"
         if args.launch != "auto":
             return args.launch
         probe = {m: timed(e, 40, 1, m)[0] for m in ("graph", "eager")}
@@ -244,7 +249,8 @@ def main():
         "metric": "env steps/sec (batched)", "value": value, "unit": "env steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "launch": "eager (one ctypes launch per step)" if mode == "eager" else "hipGraph replay of the K launches",
+        "launch": ("per-bucket streams, eager launches, one fork/join around the K steps" if hasattr(env, "rollout_steps")
+                   else "eager (one ctypes launch per step)" if mode == "eager" else "hipGraph replay of the K launches"),
         "config": {"workload": f"{wl_label}, {args.policy} masked "
                                f"policy fused with step(), batch {B} envs per GPU, one launch per env step, "
                                f"full obs/mask/reward/done written every step, auto-restart",
@@ -285,7 +291,16 @@ def main():
         out["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    # orderly teardown: graphs were local to timed(); drop the envs (and the bucketed env's side streams)
+    # while the runtime is still fully alive
+    torch.cuda.synchronize()
+    if hasattr(env, "close"):
+        env.close()
+    del env
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
     if world > 1:
         dist.destroy_process_group()
 

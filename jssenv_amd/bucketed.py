@@ -77,6 +77,14 @@ class BucketedJssEnv:
             self._fork_event = self._torch.cuda.Event()
             self._join_events = {k: self._torch.cuda.Event() for k, _ in self._each()}
 
+    def close(self):
+        """Drop the side streams/events (after a synchronize) so nothing multi-stream is left for
+        interpreter shutdown to tear down in an arbitrary order."""
+        self.synchronize()
+        self._streams = None
+        self._fork_event = None
+        self._join_events = None
+
     def _each(self):
         return [(k, b) for k, b in enumerate(self.buckets) if b is not None]
 
@@ -103,6 +111,15 @@ class BucketedJssEnv:
 
     def rollout(self, kind="random", n_iter=1, seed=None, autoreset=True, explore=0.0):
         self._fan_out(lambda k, b: b.rollout(kind, n_iter=n_iter, seed=seed, autoreset=autoreset, explore=explore))
+
+    def rollout_steps(self, kind="random", steps=1, n_iter=1, seed=None, autoreset=True, explore=0.0):
+        """`steps` consecutive rollout(n_iter) launches per bucket with ONE fork/join around the whole
+        window: bucket k's launch i+1 depends only on bucket k's launch i, so the buckets run ahead of
+        each other on their own streams (no per-step synchronisation, no graph capture needed)."""
+        def run(k, b):
+            for _ in range(steps):
+                b.rollout(kind, n_iter=n_iter, seed=seed, autoreset=autoreset, explore=explore)
+        self._fan_out(run)
 
     def policy(self, kind="random", seed=None, explore=0.0):
         return self._fan_out(lambda k, b: b.policy(kind, seed=seed, explore=explore))
