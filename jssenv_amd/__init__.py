@@ -10,6 +10,7 @@ from .instances import (Instance, available_instances, builtin_instance, load_in
                         parse_instance_text, synthetic_batch, taillard_instance)
 from .env import BatchedJssEnv, HipBackend, JssEnv, make  # noqa: F401
 from .bucketed import BucketedJssEnv  # noqa: F401
+from .vector import JssVectorEnv  # noqa: F401
 
 __version__ = "0.1.0"
 

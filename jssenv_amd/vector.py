@@ -1,0 +1,69 @@
+"""gymnasium.vector-style facade over BatchedJssEnv.
+
+The reference ships a single env only (its README loop steps one ``JssEnv``); RL code that
+wants many of them wraps it in ``gymnasium.vector.SyncVectorEnv``.  ``JssVectorEnv`` offers
+that calling convention directly on the batched engine:
+
+    envs = JssVectorEnv("ta01", num_envs=4096, device="cuda:0")
+    obs, info = envs.reset(seed=0)
+    obs, rewards, terminations, truncations, infos = envs.step(actions)
+
+* observations are the dict ``{"real_obs": (N, J, 7) float32, "action_mask": (N, J+1) bool}``
+  as device tensors (``to_numpy=True`` returns host copies);
+* autoreset follows gymnasium >= 1.0's default ("next step"): an env that terminated is reset by
+  the following ``step`` call, whose action for that env is ignored;
+* ``truncations`` is all False (the reference never truncates, jss_env.py:438), ``infos`` is
+  ``{}`` (jss_env.py:439); the final makespans are in ``envs.makespan``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+from .env import BatchedJssEnv
+
+
+class JssVectorEnv:
+    def __init__(self, instances, num_envs: Optional[int] = None, device=None, to_numpy: bool = False, _backend=None):
+        self.env = BatchedJssEnv(instances, batch=num_envs, device=device, _backend=_backend)
+        self.num_envs = self.env.batch
+        self.to_numpy = to_numpy
+        self.jobs_per_env = self.env.jobs_per_env
+        try:
+            import gymnasium as gym
+            J = self.env.jmax
+            self.single_action_space = gym.spaces.Discrete(J + 1)
+            self.single_observation_space = gym.spaces.Dict({
+                "action_mask": gym.spaces.Box(0, 1, shape=(J + 1,)),
+                "real_obs": gym.spaces.Box(low=0.0, high=1.0, shape=(J, 7), dtype=float),
+            })
+        except Exception:  # gymnasium is optional
+            self.single_action_space = self.single_observation_space = None
+
+    def _out(self, x):
+        return self.env.backend.numpy(x) if self.to_numpy else x
+
+    def _obs(self):
+        return {"real_obs": self._out(self.env.real_obs), "action_mask": self._out(self.env.action_mask != 0)}
+
+    def reset(self, *, seed: Optional[int] = None, options=None):
+        if seed is not None:
+            self.env.seed = int(seed)
+        self.env.reset()
+        return self._obs(), {}
+
+    def step(self, actions):
+        _, reward, done, _, _ = self.env.step(actions, autoreset=True)
+        terminations = done != 0
+        truncations = terminations & False
+        return self._obs(), self._out(reward), self._out(terminations), self._out(truncations), {}
+
+    def sample_actions(self, kind="random", explore: float = 0.0):
+        """Per-env actions from the on-device selectors (random masked, FIFO, SPT, ...)."""
+        return self.env.policy(kind, explore=explore)
+
+    @property
+    def makespan(self):
+        return self._out(self.env.makespan)
+
+    def close(self):
+        self.env.synchronize()

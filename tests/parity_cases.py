@@ -460,3 +460,22 @@ def case_bucketed_equals_padded(backend, n_envs=24, n_iter=260, seed=13):
         o.reset()
         o.rollout("random", seed, 500 + i, n_iter, episode=1)
         assert_matches_oracle(bucketed.host_state(i), o, f"bucketed env {i}")
+
+
+def case_vector_facade(backend):
+    from jssenv_amd.vector import JssVectorEnv
+    envs = JssVectorEnv("ta01", num_envs=5, to_numpy=True, _backend=backend)
+    obs, info = envs.reset(seed=4)
+    assert info == {} and obs["real_obs"].shape == (5, 15, 7) and obs["action_mask"].shape == (5, 16)
+    assert obs["action_mask"][:, :15].all() and not obs["action_mask"][:, 15].any()
+    finished = np.zeros(5, dtype=int)
+    prev_term = np.zeros(5, dtype=bool)
+    for it in range(600):
+        a = envs.env.backend.numpy(envs.sample_actions("random"))
+        assert all(obs["action_mask"][i, a[i]] for i in range(5) if not prev_term[i])
+        obs, rew, term, trunc, info = envs.step(a)
+        assert not trunc.any() and rew.shape == (5,)
+        assert not (term & prev_term).any()          # a terminated env is reset by the next step
+        finished += term
+        prev_term = term
+    assert (finished >= 1).all() and (envs.makespan > 1000).all()

@@ -197,3 +197,7 @@ def test_largest_shape_per_env_tables(hip):
         o.reset()
         o.rollout("random", 1, i, 400, episode=1)
         P.assert_matches_oracle(env.host_state(i), o, f"128x64 env {i}")
+
+
+def test_vector_facade(hip):
+    P.case_vector_facade(hip)

@@ -96,3 +96,7 @@ def test_rules_with_exploration(emu):
     """the rules' 10 % NOPE exploration (dispatching.py:113) drawn from the counter RNG on the device"""
     env, orcs = P.case_batch_lockstep(emu, ["ta01", "ta21"], batch=4, n_steps=70, kind="SPT", check_every=9, explore=0.1)
     env, orcs = P.case_batch_lockstep(emu, ["ta71"], batch=2, n_steps=70, kind="FIFO", check_every=9, explore=0.25)
+
+
+def test_vector_facade(emu):
+    P.case_vector_facade(emu)
