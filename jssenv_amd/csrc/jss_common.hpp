@@ -60,6 +60,7 @@ struct Params {
     int32_t ablate;          // JSS_OPT_ABLATE mask (profiling aid)
     int32_t obs_off_ints;    // packed kernel: LDS offset (ints, multiple of 4) of the observation images
     int32_t obs_wave_floats; // packed kernel: floats per wave image (multiple of 4)
+    int32_t mv_off_ints;     // packed kernel: LDS offset (ints) of the per-lane max_horizon_machine table
 };
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -94,6 +95,14 @@ __device__ __forceinline__ int row_max(int v) {
     v = imax(v, JSS_DPP(v, 0x4E));
     v = imax(v, JSS_DPP(v, 0x141));
     v = imax(v, JSS_DPP(v, 0x140));
+    return v;
+}
+
+__device__ __forceinline__ int row_or(int v) {
+    v |= JSS_DPP(v, 0xB1);
+    v |= JSS_DPP(v, 0x4E);
+    v |= JSS_DPP(v, 0x141);
+    v |= JSS_DPP(v, 0x140);
     return v;
 }
 

@@ -55,7 +55,8 @@ int launch(Params &p, void *stream) {
         const int n_regions = p.shared_table ? 1 : envs_per_block;
         p.obs_off_ints = (n_regions * p.region_ints + 3) & ~3;
         p.obs_wave_floats = ((kWave / G) * p.d.jmax * 7 + 3) & ~3;
-        const size_t shmem = sizeof(int32_t) * (size_t)p.obs_off_ints + sizeof(float) * kWavesPerBlock * p.obs_wave_floats + g_lds_pad;
+        p.mv_off_ints = p.obs_off_ints + kWavesPerBlock * p.obs_wave_floats;
+        const size_t shmem = sizeof(int32_t) * ((size_t)p.mv_off_ints + kBlock) + g_lds_pad;
         const int blocks = (p.d.batch + envs_per_block - 1) / envs_per_block;
         if (G == 16)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed_kernel<16, MODE>), dim3(blocks), dim3(kBlock), shmem, st, p);

@@ -168,10 +168,19 @@ __device__ __forceinline__ void p_prioritize(PEnv<G> &e, const PCtx<G> &c, bool 
 }
 
 // ---------------------------------------------------------------------------------------
-// _check_no_op(): jss_env.py:256-401 for the groups with `on`
+// _check_no_op(): jss_env.py:256-401 for the groups with `on`.
+//
+// Pass 1 of the reference walks the (<= 4) legal jobs in ascending index and keeps, per machine,
+// max_horizon_machine[m] = min(t + max_time_op, end of every legal job on m seen so far), and
+// max_horizon = max over the jobs of that running value at the job's own turn (order dependent).
+// Here each lane keeps the piece it owns: a legal job lane its own running-prefix value `h`
+// (min over the legal jobs with a lower or equal index on its machine), a machine lane its
+// machine's final minimum `mv`.  One round per legal job broadcasts that job's (machine, end).
+// Pass 2 looks max_horizon_machine up in a per-group LDS table (`mvtab`, one int per lane) because
+// the walk is divergent, and collects the covered machines as a bit mask (M <= G <= 32).
 // ---------------------------------------------------------------------------------------
 template <int G>
-__device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool on) {
+__device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool on, int32_t *mvtab) {
     if (on) e.noop = 0;                                                  // :278
     const uint32_t lm = grp_ballot<G>(e.legal, c.gbase);
     const int nl = __popc(lm);
@@ -179,77 +188,65 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool
     const bool busy = d_next < kBig;                                     // :285 len(next_time_step) > 0
     bool gate = on && nl >= 1 && nl <= 4 && busy;                        // :284-288 (nb_machine_legal checked below)
     if (__ballot(gate) == 0) return;
-    // PASS 1 (:305-321): the <= 4 legal jobs in ascending job index; every lane of the group
-    // computes the same sequence (max_horizon sees the running prefix, so the order matters)
-    int cf[4];
-    {
-        uint32_t bits = lm;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int l = bits ? __ffs(bits) - 1 : 0;
-            cf[i] = grp_read<G>(e.cur, l, c.gbase);
-            bits &= bits - 1;
+    const int nxt = e.t + d_next;                                        // :293
+    const int cap = e.t + c.max_time_op;                                 // :300-302
+    const int my_m = e.cur >> 16;
+    const int my_end = e.t + (e.cur & kDurMask);                         // :310
+    // PASS 1 (:305-321)
+    int h = imin(cap, my_end);   // legal job lane: max_horizon_machine[my_m] right after my own turn
+    int mv = cap;                // machine lane: max_horizon_machine[gl] after the whole pass
+    bool m_legal = false;        // machine lane: machine_legal[gl]
+    uint32_t bits = lm;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        const bool has = gate && bits != 0;
+        if (__ballot(has) == 0) break;
+        const int l = bits ? __ffs(bits) - 1 : 0;
+        const int cf = grp_read<G>(e.cur, l, c.gbase);
+        const int m_r = cf >> 16, end_r = e.t + (cf & kDurMask);
+        if (has && e.legal && l < c.gl && m_r == my_m) h = imin(h, end_r);   // :318 earlier job on my machine
+        if (has && c.gl == m_r) {                                            // :318 / machine_legal
+            mv = imin(mv, end_r);
+            m_legal = true;
         }
+        bits &= bits - 1;
     }
-    int mm0 = -1, mm1 = -1, mm2 = -1, n_ml = 0;                          // the legal machines (:286 needs their count)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = cf[i] >> 16;
-        if (i < nl && m != mm0 && m != mm1 && m != mm2) {
-            if (n_ml == 0) mm0 = m; else if (n_ml == 1) mm1 = m; else if (n_ml == 2) mm2 = m;
-            ++n_ml;
-        }
-    }
-    gate = gate && n_ml <= 3;                                            // :286
-    const int nxt = e.t + d_next;                                        // :293 next_time_step[0]
-    int mh = e.t;                                                        // :296
-    int mv0 = e.t + c.max_time_op, mv1 = mv0, mv2 = mv0;                 // :300-302
-    bool early = false;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i < nl && !early) {
-            const int m = cf[i] >> 16;
-            const int end = e.t + (cf[i] & kDurMask);                    // :310
-            if (end < nxt) {
-                early = true;                                            // :314-315 return, NOPE stays illegal
-            } else {
-                int h;
-                if (m == mm0) { mv0 = imin(mv0, end); h = mv0; }         // :318
-                else if (m == mm1) { mv1 = imin(mv1, end); h = mv1; }
-                else { mv2 = imin(mv2, end); h = mv2; }
-                mh = imax(mh, h);                                        // :321
-            }
-        }
-    }
-    gate = gate && !early;
+    const uint32_t legal_machines = grp_ballot<G>(m_legal, c.gbase);
+    gate = gate && __popc(legal_machines) <= 3;                          // :286 nb_machine_legal <= 3
+    const bool ends_early = grp_any<G>(e.legal && my_end < nxt, c.gbase);  // collective: evaluate on every lane
+    gate = gate && !ends_early;                                          // :314-315 some legal job ends before the next event
+    const int mh = grp_max<G>(e.legal ? h : e.t);                        // :296, :321 max_horizon
+    // max_horizon_machine of the legal machines for the divergent walk; others never qualify (:348)
+    mvtab[c.lane] = m_legal ? mv : -kBig;
+    wave_lds_sync();
     // PASS 2 (:324-401): every illegal job walks its future ops
     const bool caseA = c.jvalid && !e.legal && e.left > 0 && e.todo + 1 < c.M;      // :327-330
     const bool caseB = c.jvalid && !e.legal && !caseA && !e.blocked && e.todo < c.M; // :366-369
-    const int tm_need = grp_read<G>(e.tm, e.cur >> 16, c.gbase);                      // :376
+    const int tm_need = grp_read<G>(e.tm, my_m, c.gbase);                             // :376
     int k = caseA ? e.todo + 1 : e.todo;                                              // :332 / :370
     int tn = caseA ? e.t + e.left : e.t + tm_need;                                    // :334-337 / :374-377
-    int u = 0;
+    int u = 0;                                                                        // machine_next as a bit mask
     if (gate && (caseA || caseB)) {
+        const int32_t *tab = mvtab + c.gbase;
         while (k < c.M - 1 && mh > tn) {                                              // :340-342 / :380-382
             const int op = c.ops[c.gl * c.stride + k];
             const int m = op >> 16;
-            if (m == mm0 && mv0 > tn) u |= 1;                                         // :346-351
-            if (m == mm1 && mv1 > tn) u |= 2;
-            if (m == mm2 && mv2 > tn) u |= 4;
+            if (tab[m] > tn) u |= 1 << m;                                             // :346-351
             tn += op & kDurMask;                                                      // :362
             ++k;
         }
     }
-    const int covered = (grp_any<G>(u & 1, c.gbase) ? 1 : 0) + (grp_any<G>(u & 2, c.gbase) ? 1 : 0) +
-                        (grp_any<G>(u & 4, c.gbase) ? 1 : 0);
-    if (gate && covered == n_ml) e.noop = 1;                                          // :357-359 / :395-397
+    int covered = row_or(u);                                                          // union over the group
+    if (G == 32) covered |= __builtin_amdgcn_ds_swizzle(covered, 0x401F);
+    if (gate && (uint32_t)covered == legal_machines) e.noop = 1;                      // :357-359 / :395-397
+    wave_lds_sync();                                                                  // mvtab is reused by the next call
 }
 
 // ---------------------------------------------------------------------------------------
 // step(): jss_env.py:403-481.  `a` is group-uniform.  Returns the reward numerator.
 // ---------------------------------------------------------------------------------------
 template <int G>
-__device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params &p, int a) {
+__device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params &p, int a, int32_t *mvtab) {
     const bool is_nope = c.alive && a == c.J;                            // :419
     const bool is_job = c.alive && a >= 0 && a < c.J;
     if (c.alive && (a < JSS_ACTION_SKIP || a > c.J)) e.err |= JSS_ERR_BAD_ACTION;
@@ -279,6 +276,7 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params
     const bool stepping = alloc || is_nope;
     for (;;) {                                                           // :429-430 / :469-470
         const bool none_legal = !grp_any<G>(e.legal, c.gbase);
+        if (__ballot(stepping && none_legal) == 0) break;                // nobody waits for an event: skip the min
         const int d = p_next_event(e);
         const bool busy = d < kBig;
         bool act = stepping && none_legal;
@@ -289,7 +287,7 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params
         if (act) rn -= hole;
     }
     if (!(p.ablate & JSS_ABLATE_PRIORITIZE)) p_prioritize(e, c, stepping);      // :432 / :471
-    if (!(p.ablate & JSS_ABLATE_CHECK_NO_OP)) p_check_no_op(e, c, stepping);    // :433 / :472
+    if (!(p.ablate & JSS_ABLATE_CHECK_NO_OP)) p_check_no_op(e, c, stepping, mvtab);  // :433 / :472
     return rn;
 }
 
@@ -449,6 +447,7 @@ __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : 8) void jss_packed_k
     const int grp_in_block = threadIdx.x / G;
     // obs image of this wave: E * jmax * 7 floats, 16-byte aligned (p.obs_off_ints is a multiple of 4)
     float *scratch = reinterpret_cast<float *>(lds + p.obs_off_ints) + wave * p.obs_wave_floats;
+    int32_t *mvtab = lds + p.mv_off_ints + wave * kWave;                 // one int per lane, see p_check_no_op
 
     PCtx<G> c;
     c.lane = lane;
@@ -500,7 +499,7 @@ __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : 8) void jss_packed_k
             }
         }
     } else if (MODE == kStep) {
-        const int rn = p_step(e, c, p, a_in);
+        const int rn = p_step(e, c, p, a_in, mvtab);
         const bool called = a_in != JSS_ACTION_SKIP;
         const bool done = !grp_any<G>(e.legal, c.gbase);
         if (called) hd.step += 1;
@@ -549,7 +548,7 @@ __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : 8) void jss_packed_k
                         ? __ffs(grp_ballot<G>(e.legal, c.gbase)) - 1
                         : p_select(e, c, p.kind, p.seed, p.explore_q16, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
             if (!do_step) a = JSS_ACTION_SKIP;
-            const int rn = p_step(e, c, p, a);
+            const int rn = p_step(e, c, p, a, mvtab);
             const bool done1 = !grp_any<G>(e.legal, c.gbase);            // collective: outside the divergent branch
             if (do_step) {
                 last_rn = rn;
