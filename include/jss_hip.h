@@ -158,6 +158,12 @@ const char *jss_error_string(int code);
 #define JSS_ABLATE_OBS 4
 #define JSS_ABLATE_SELECT 8
 #define JSS_ABLATE_ADVANCE 16
+/* JSS_OPT_PERSIST: k > 0 routes shared-instance batches in jss_step / jss_rollout(n_iter == 1) to a persistent
+ * packed kernel with k waves per SIMD that loop over env sets and prefetch the next set's state (default 0 = one
+ * env set per wave: on MI355X the persistent form measured 17 % slower, the step is bound by per-wave latency
+ * and wants the 8 waves per SIMD the one-shot kernel gets).  JSS_OPT_CU_COUNT overrides the detected compute-unit count (tests). */
+#define JSS_OPT_PERSIST 3
+#define JSS_OPT_CU_COUNT 4
 /* JSS_OPT_LDS_PAD (profiling aid): extra dynamic LDS bytes per workgroup, to cap occupancy in experiments. */
 #define JSS_OPT_LDS_PAD 2
 int jss_set_option(int option, int value);

@@ -23,6 +23,8 @@ ROLLOUT_AUTORESET = 1
 OPT_KERNEL, KERNEL_AUTO, KERNEL_WAVE = 0, 0, 1
 OPT_ABLATE = 1
 OPT_LDS_PAD = 2
+OPT_PERSIST = 3
+OPT_CU_COUNT = 4
 
 SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_set_option", "jss_reset", "jss_step", "jss_advance", "jss_policy", "jss_rollout")
 

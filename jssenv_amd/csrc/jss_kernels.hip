@@ -31,6 +31,22 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
 int g_kernel_choice = JSS_KERNEL_AUTO;
 int g_ablate = 0;
 int g_lds_pad = 0;
+int g_persist = 0;   // waves per SIMD of the persistent kernel; 0 = off (default: measured slower, profiles/README.md)
+int g_cu_count = 0;  // 0 = ask the runtime
+
+int compute_units() {
+    if (g_cu_count > 0) return g_cu_count;
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cached = n;
+        else
+            cached = 256;
+    }
+    return cached;
+}
 
 // Kernel flavour for a batch shape: the packed kernel needs every env's jobs AND machines to fit
 // a 16- or 32-lane group.
@@ -58,6 +74,18 @@ int launch(Params &p, void *stream) {
         p.mv_off_ints = p.obs_off_ints + kWavesPerBlock * p.obs_wave_floats;
         const size_t shmem = sizeof(int32_t) * ((size_t)p.mv_off_ints + kBlock) + g_lds_pad;
         const int blocks = (p.d.batch + envs_per_block - 1) / envs_per_block;
+        // persistent variant: shared instance, step-per-launch modes, more env sets than resident waves
+        if ((MODE == kStep || MODE == kRollout1) && p.shared_table && g_persist > 0) {
+            const int pblocks = compute_units() * g_persist;              // one wave per SIMD per workgroup
+            if (blocks > pblocks) {
+                constexpr int PM = (MODE == kStep) ? kStep : kRollout1;   // only these two are instantiated
+                if (G == 16)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed_persistent<16, PM>), dim3(pblocks), dim3(kBlock), shmem, st, p);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed_persistent<32, PM>), dim3(pblocks), dim3(kBlock), shmem, st, p);
+                return (int)hipGetLastError();
+            }
+        }
         if (G == 16)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed_kernel<16, MODE>), dim3(blocks), dim3(kBlock), shmem, st, p);
         else
@@ -87,6 +115,14 @@ int jss_set_option(int option, int value) {
     }
     if (option == JSS_OPT_LDS_PAD && value >= 0 && value <= 150000) {
         g_lds_pad = value;
+        return 0;
+    }
+    if (option == JSS_OPT_PERSIST && value >= 0 && value <= 8) {
+        g_persist = value;
+        return 0;
+    }
+    if (option == JSS_OPT_CU_COUNT && value >= 0) {
+        g_cu_count = value;
         return 0;
     }
     if (option == JSS_OPT_ABLATE) {

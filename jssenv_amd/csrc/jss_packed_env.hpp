@@ -434,59 +434,11 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, 
 }
 
 // ---------------------------------------------------------------------------------------
-// the packed kernel
+// mode bodies: everything between "state unpacked into registers" and "state stored"
 // ---------------------------------------------------------------------------------------
-// launch bounds: every mode but the multi-iteration rollout fits 64 VGPRs without spilling -> 8 waves per SIMD
 template <int G, int MODE>
-__global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : 8) void jss_packed_kernel(Params p) {
-    HIP_DYNAMIC_SHARED(int32_t, lds)
-    constexpr int E = kWave / G;                      // envs per wave
-    constexpr int EB = E * kWavesPerBlock;            // envs per workgroup
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const int grp_in_block = threadIdx.x / G;
-    // obs image of this wave: E * jmax * 7 floats, 16-byte aligned (p.obs_off_ints is a multiple of 4)
-    float *scratch = reinterpret_cast<float *>(lds + p.obs_off_ints) + wave * p.obs_wave_floats;
-    int32_t *mvtab = lds + p.mv_off_ints + wave * kWave;                 // one int per lane, see p_check_no_op
-
-    PCtx<G> c;
-    c.lane = lane;
-    c.gl = lane & (G - 1);
-    c.gbase = lane & ~(G - 1);
-    const int b_raw = blockIdx.x * EB + grp_in_block;
-    const int first_env = blockIdx.x * EB + wave * E;
-    const bool wave_whole = first_env + E <= p.d.batch;
-    c.alive = b_raw < p.d.batch;
-    c.b = c.alive ? b_raw : p.d.batch - 1;
-    // 1. state loads first: they depend on nothing but the env index
-    const PRaw<G> raw = p_issue_loads<G>(c.b, c.gl, p);
-    int a_in = JSS_ACTION_SKIP;
-    if (MODE == kStep) a_in = p.actions[c.b];
-    bool selected = true;
-    if ((MODE == kReset || MODE == kAdvance) && p.which) selected = p.which[c.b] != 0;
-    // 2. instance constants + op table -> LDS
-    const int tid = p.shared_table ? 0 : (p.d.table_of_env ? p.d.table_of_env[c.b] : c.b);
-    c.J = p.d.jobs[tid];
-    c.M = p.d.machines[tid];
-    c.max_time_op = p.d.max_time_op[tid];
-    c.max_time_jobs = p.d.max_time_jobs[tid];
-    c.sum_op = p.d.sum_op[tid];
-    c.jvalid = c.gl < c.J;
-    c.mvalid = c.gl < c.M;
-    c.stride = p.stride;
-    int32_t *table = lds + (p.shared_table ? 0 : grp_in_block * p.region_ints);
-    c.ops = table;
-    if (p.shared_table) {
-        const int n0 = p.d.jobs[0] * p.d.mmax;
-        stage_table(lds, p.d.ops, p.d.ops16, 0, n0, (int)threadIdx.x, kBlock);
-    } else {
-        const int n = c.J * p.d.mmax;
-        stage_table(table, p.d.ops, p.d.ops16, (size_t)tid * p.d.jmax * p.d.mmax, n, c.gl, G);
-    }
-    __syncthreads();
-
-    PEnv<G> e;
-    PHeader hd = p_unpack(e, c, raw);
+__device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c, const Params &p, int a_in, bool selected,
+                                       int32_t *mvtab) {
     if (MODE == kReset) {
         const bool on = c.alive && selected;          // untouched groups are written back unchanged
         p_reset(e, c, p, on);
@@ -525,10 +477,10 @@ __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : 8) void jss_packed_k
         const int hole = p_advance(e, c, on && busy, d);
         if (on && c.gl == 0 && p.hole) p.hole[c.b] = busy ? hole : 0;
     } else if (MODE == kPolicy) {
-        const int a = p_select(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_ids ? p.d.env_ids[c.b] : p.d.env_id_base + c.b),
-                               (uint32_t)hd.episode, (uint32_t)hd.step);
+        const int a = p_select(e, c, p.kind, p.seed, p.explore_q16,
+                               (uint64_t)(p.d.env_ids ? p.d.env_ids[c.b] : p.d.env_id_base + c.b), (uint32_t)hd.episode,
+                               (uint32_t)hd.step);
         if (c.alive && c.gl == 0) p.actions_out[c.b] = a;
-        return;
     } else {  // kRollout / kRollout1
         const uint64_t env_id = (uint64_t)(p.d.env_ids ? p.d.env_ids[c.b] : p.d.env_id_base + c.b);
         int n_steps = 0, n_done = 0, last_rn = 0, last_makespan = -1, sum_makespan = 0, sum_rn = 0;
@@ -576,8 +528,135 @@ __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : 8) void jss_packed_k
             }
         }
     }
+}
+
+// instance constants of table `tid` into the per-lane context
+template <int G>
+__device__ __forceinline__ void p_load_constants(PCtx<G> &c, const Params &p, int tid) {
+    c.J = p.d.jobs[tid];
+    c.M = p.d.machines[tid];
+    c.max_time_op = p.d.max_time_op[tid];
+    c.max_time_jobs = p.d.max_time_jobs[tid];
+    c.sum_op = p.d.sum_op[tid];
+    c.jvalid = c.gl < c.J;
+    c.mvalid = c.gl < c.M;
+    c.stride = p.stride;
+}
+
+// ---------------------------------------------------------------------------------------
+// the packed kernel, one env set (E = 64/G envs) per wave
+// ---------------------------------------------------------------------------------------
+// launch bounds: every mode but the multi-iteration rollout fits 64 VGPRs without spilling -> 8 waves per SIMD
+template <int G, int MODE>
+__global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : 8) void jss_packed_kernel(Params p) {
+    HIP_DYNAMIC_SHARED(int32_t, lds)
+    constexpr int E = kWave / G;                      // envs per wave
+    constexpr int EB = E * kWavesPerBlock;            // envs per workgroup
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int grp_in_block = threadIdx.x / G;
+    // obs image of this wave: E * jmax * 7 floats, 16-byte aligned (p.obs_off_ints is a multiple of 4)
+    float *scratch = reinterpret_cast<float *>(lds + p.obs_off_ints) + wave * p.obs_wave_floats;
+    int32_t *mvtab = lds + p.mv_off_ints + wave * kWave;                 // one int per lane, see p_check_no_op
+
+    PCtx<G> c;
+    c.lane = lane;
+    c.gl = lane & (G - 1);
+    c.gbase = lane & ~(G - 1);
+    const int b_raw = blockIdx.x * EB + grp_in_block;
+    const int first_env = blockIdx.x * EB + wave * E;
+    const bool wave_whole = first_env + E <= p.d.batch;
+    c.alive = b_raw < p.d.batch;
+    c.b = c.alive ? b_raw : p.d.batch - 1;
+    // 1. state loads first: they depend on nothing but the env index
+    const PRaw<G> raw = p_issue_loads<G>(c.b, c.gl, p);
+    int a_in = JSS_ACTION_SKIP;
+    if (MODE == kStep) a_in = p.actions[c.b];
+    bool selected = true;
+    if ((MODE == kReset || MODE == kAdvance) && p.which) selected = p.which[c.b] != 0;
+    // 2. instance constants + op table -> LDS
+    const int tid = p.shared_table ? 0 : (p.d.table_of_env ? p.d.table_of_env[c.b] : c.b);
+    p_load_constants(c, p, tid);
+    int32_t *table = lds + (p.shared_table ? 0 : grp_in_block * p.region_ints);
+    c.ops = table;
+    if (p.shared_table) {
+        const int n0 = p.d.jobs[0] * p.d.mmax;
+        stage_table(lds, p.d.ops, p.d.ops16, 0, n0, (int)threadIdx.x, kBlock);
+    } else {
+        const int n = c.J * p.d.mmax;
+        stage_table(table, p.d.ops, p.d.ops16, (size_t)tid * p.d.jmax * p.d.mmax, n, c.gl, G);
+    }
+    __syncthreads();
+
+    PEnv<G> e;
+    PHeader hd = p_unpack(e, c, raw);
+    p_body<G, MODE>(e, hd, c, p, a_in, selected, mvtab);
+    if (MODE == kPolicy) return;
     p_store(e, c, p, hd);
     if (!(p.ablate & JSS_ABLATE_OBS)) p_store_obs(e, c, p, scratch, first_env, wave_whole);
+}
+
+// ---------------------------------------------------------------------------------------
+// persistent variant for shared-instance batches (kStep / kRollout1): a fixed number of waves per
+// SIMD, each looping over env sets.  The next set's state loads are issued BEFORE the current set is
+// computed and stored, so HBM traffic and VALU work overlap inside every wave instead of relying on
+// waves being out of phase (with one set per wave, the two rounds of waves of a 65 536-env launch run
+// load -> compute -> store in near lock step: profiles/README.md).
+// ---------------------------------------------------------------------------------------
+template <int G, int MODE>
+__global__ __launch_bounds__(kBlock, 4) void jss_packed_persistent(Params p) {
+    HIP_DYNAMIC_SHARED(int32_t, lds)
+    constexpr int E = kWave / G;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *scratch = reinterpret_cast<float *>(lds + p.obs_off_ints) + wave * p.obs_wave_floats;
+    int32_t *mvtab = lds + p.mv_off_ints + wave * kWave;
+
+    PCtx<G> c;
+    c.lane = lane;
+    c.gl = lane & (G - 1);
+    c.gbase = lane & ~(G - 1);
+    const int e_in_wave = lane / G;
+    const int n_sets = (p.d.batch + E - 1) / E;
+    const int n_waves = gridDim.x * kWavesPerBlock;
+    int set = blockIdx.x * kWavesPerBlock + wave;                        // wave-uniform
+    const int last = p.d.batch - 1;
+    // first set's loads, then the shared op table
+    int b_next = imin((set < n_sets ? set : 0) * E + e_in_wave, last);
+    PRaw<G> raw = p_issue_loads<G>(b_next, c.gl, p);
+    int a_in = MODE == kStep ? p.actions[b_next] : JSS_ACTION_SKIP;
+    p_load_constants(c, p, 0);
+    c.ops = lds;
+    stage_table(lds, p.d.ops, p.d.ops16, 0, p.d.jobs[0] * p.d.mmax, (int)threadIdx.x, kBlock);
+    __syncthreads();
+    if (set >= n_sets) return;
+
+    for (;;) {
+        const int first_env = set * E;
+        const int b_raw = first_env + e_in_wave;
+        c.alive = b_raw < p.d.batch;
+        c.b = c.alive ? b_raw : last;
+        const bool wave_whole = first_env + E <= p.d.batch;
+        // prefetch: the next set's state is in flight while this one is computed and stored
+        const int next = set + n_waves;
+        const bool has_next = next < n_sets;                             // wave-uniform
+        PRaw<G> raw_next = raw;
+        int a_next = JSS_ACTION_SKIP;
+        if (has_next) {
+            b_next = imin(next * E + e_in_wave, last);
+            raw_next = p_issue_loads<G>(b_next, c.gl, p);
+            if (MODE == kStep) a_next = p.actions[b_next];
+        }
+        PEnv<G> e;
+        PHeader hd = p_unpack(e, c, raw);
+        p_body<G, MODE>(e, hd, c, p, a_in, true, mvtab);
+        p_store(e, c, p, hd);
+        if (!(p.ablate & JSS_ABLATE_OBS)) p_store_obs(e, c, p, scratch, first_env, wave_whole);
+        if (!has_next) break;
+        raw = raw_next;
+        a_in = a_next;
+        set = next;
+    }
 }
 
 }  // namespace jss

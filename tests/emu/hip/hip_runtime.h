@@ -43,6 +43,9 @@ typedef void *hipStream_t;
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+#define hipDeviceAttributeMultiprocessorCount 0
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
+static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 2; return 0; }  // a 2-CU "device"
 
 struct dim3 {
     unsigned x, y, z;

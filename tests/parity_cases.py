@@ -479,3 +479,20 @@ def case_vector_facade(backend):
         finished += term
         prev_term = term
     assert (finished >= 1).all() and (envs.makespan > 1000).all()
+
+
+def case_persistent_kernel(backend, batch=41, n_steps=40):
+    """The persistent packed kernel (env sets looped per wave with prefetch of the next set) must be
+    indistinguishable from the one-set-per-wave kernel: force it with a 1-CU, 1-wave-per-SIMD 'device' so
+    that a small batch already needs several sets per wave, including a partial tail set."""
+    lib = backend.lib
+    assert lib.jss_set_option(_abi.OPT_CU_COUNT, 1) == 0 and lib.jss_set_option(_abi.OPT_PERSIST, 1) == 0
+    try:
+        # jss_step path (kStep) with oracle lock step, forced NOPEs and skipped envs
+        case_batch_lockstep(backend, ["ta01"], batch=batch, n_steps=n_steps, kind="random", nope_every=6, check_every=8)
+        # jss_rollout(n_iter=1) path (kRollout1) with auto-restart, G = 32 flavour too
+        case_rollout(backend, ["ta01"], batch=batch, n_iter=0, chunks=(1,) * n_steps)
+        case_rollout(backend, ["ta21"], batch=19, n_iter=0, chunks=(1,) * (n_steps // 2), kind="SPT")
+    finally:
+        lib.jss_set_option(_abi.OPT_CU_COUNT, 0)
+        lib.jss_set_option(_abi.OPT_PERSIST, 0)

@@ -201,3 +201,7 @@ def test_largest_shape_per_env_tables(hip):
 
 def test_vector_facade(hip):
     P.case_vector_facade(hip)
+
+
+def test_persistent_kernel(hip):
+    P.case_persistent_kernel(hip, batch=173, n_steps=400)

@@ -100,3 +100,7 @@ def test_rules_with_exploration(emu):
 
 def test_vector_facade(emu):
     P.case_vector_facade(emu)
+
+
+def test_persistent_kernel(emu):
+    P.case_persistent_kernel(emu, batch=41, n_steps=24)
