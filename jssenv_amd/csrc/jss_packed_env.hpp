@@ -98,6 +98,13 @@ __device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G> &c, const Para
 // ---------------------------------------------------------------------------------------
 // increase_time_step(): jss_env.py:495-637 for the groups with `act`; returns hole_planning.
 // ---------------------------------------------------------------------------------------
+// op after my job's current one (-1 when the current op is the job's last): read from LDS ahead of time so
+// its latency hides behind the event-time reduction instead of sitting in increase_time_step's chain
+template <int G>
+__device__ __forceinline__ int p_prefetch_next_op(const PEnv<G> &e, const PCtx<G> &c) {
+    return (c.jvalid && e.todo + 1 < c.M) ? c.ops[c.gl * c.stride + e.todo + 1] : -1;
+}
+
 // time to the next event of my env = earliest machine release (:517-522; the reference's queue is
 // {t + tm[m] : tm[m] > 0}); kBig when no machine is busy (empty queue)
 template <int G>
@@ -106,7 +113,7 @@ __device__ __forceinline__ int p_next_event(const PEnv<G> &e) {
 }
 
 template <int G>
-__device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act, int d) {
+__device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act, int d, int next_op) {
     const int idle_machines = __popc(grp_ballot<G>(c.mvalid && e.tm < d, c.gbase));
     const int hole = d * idle_machines;                                  // :606-608 (tm < d only when tm == 0)
     bool fin = false;
@@ -128,7 +135,7 @@ __device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act,
             e.idle_last += d;                                            // :597
         }
         e.tm = imax(0, e.tm - d);                                        // :611
-        if (fin) e.cur = e.todo < c.M ? c.ops[c.gl * c.stride + e.todo] : -1;  // :562-566 / :581
+        if (fin) e.cur = next_op;                                        // :562-566 / :581 (prefetched by the caller)
     }
     // time left on the machine my job needs (after the update): feature-4 numerator
     // max(0, tm_old[need] - d) (:569-578) and the "machine is free" test of :616 in one read
@@ -196,20 +203,34 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool
     int h = imin(cap, my_end);   // legal job lane: max_horizon_machine[my_m] right after my own turn
     int mv = cap;                // machine lane: max_horizon_machine[gl] after the whole pass
     bool m_legal = false;        // machine lane: machine_legal[gl]
-    uint32_t bits = lm;
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-        const bool has = gate && bits != 0;
-        if (__ballot(has) == 0) break;
-        const int l = bits ? __ffs(bits) - 1 : 0;
-        const int cf = grp_read<G>(e.cur, l, c.gbase);
-        const int m_r = cf >> 16, end_r = e.t + (cf & kDurMask);
-        if (has && e.legal && l < c.gl && m_r == my_m) h = imin(h, end_r);   // :318 earlier job on my machine
-        if (has && c.gl == m_r) {                                            // :318 / machine_legal
-            mv = imin(mv, end_r);
-            m_legal = true;
+    // the (<= 4) legal jobs' current ops: four independent cross-lane reads in flight at once
+    int cf[4];
+    bool has[4];
+    {
+        uint32_t bits = lm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            has[r] = gate && bits != 0;
+            const int l = bits ? __ffs(bits) - 1 : 0;
+            cf[r] = grp_read<G>(e.cur, l, c.gbase);
+            bits &= bits - 1;
         }
-        bits &= bits - 1;
+    }
+    // time left on the machine my own job needs (:376), issued here so its latency hides behind pass 1
+    const int tm_need = grp_read<G>(e.tm, my_m, c.gbase);
+    {
+        uint32_t bits = lm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = bits ? __ffs(bits) - 1 : 0;
+            const int m_r = cf[r] >> 16, end_r = e.t + (cf[r] & kDurMask);
+            if (has[r] && e.legal && l < c.gl && m_r == my_m) h = imin(h, end_r);   // :318 earlier job on my machine
+            if (has[r] && c.gl == m_r) {                                            // :318 / machine_legal
+                mv = imin(mv, end_r);
+                m_legal = true;
+            }
+            bits &= bits - 1;
+        }
     }
     const uint32_t legal_machines = grp_ballot<G>(m_legal, c.gbase);
     gate = gate && __popc(legal_machines) <= 3;                          // :286 nb_machine_legal <= 3
@@ -222,7 +243,6 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool
     // PASS 2 (:324-401): every illegal job walks its future ops
     const bool caseA = c.jvalid && !e.legal && e.left > 0 && e.todo + 1 < c.M;      // :327-330
     const bool caseB = c.jvalid && !e.legal && !caseA && !e.blocked && e.todo < c.M; // :366-369
-    const int tm_need = grp_read<G>(e.tm, my_m, c.gbase);                             // :376
     int k = caseA ? e.todo + 1 : e.todo;                                              // :332 / :370
     int tn = caseA ? e.t + e.left : e.t + tm_need;                                    // :334-337 / :374-377
     int u = 0;                                                                        // machine_next as a bit mask
@@ -277,13 +297,14 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params
     for (;;) {                                                           // :429-430 / :469-470
         const bool none_legal = !grp_any<G>(e.legal, c.gbase);
         if (__ballot(stepping && none_legal) == 0) break;                // nobody waits for an event: skip the min
+        const int next_op = p_prefetch_next_op(e, c);
         const int d = p_next_event(e);
         const bool busy = d < kBig;
         bool act = stepping && none_legal;
         if (act && !busy && is_nope) e.err |= JSS_ERR_NOPE_IDLE;         // reference: IndexError (:517)
         act = act && busy;
         if (__ballot(act) == 0 || (p.ablate & JSS_ABLATE_ADVANCE)) break;
-        const int hole = p_advance(e, c, act, d);
+        const int hole = p_advance(e, c, act, d, next_op);
         if (act) rn -= hole;
     }
     if (!(p.ablate & JSS_ABLATE_PRIORITIZE)) p_prioritize(e, c, stepping);      // :432 / :471
@@ -471,10 +492,11 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c
         }
     } else if (MODE == kAdvance) {
         const bool on = c.alive && selected;
+        const int next_op = p_prefetch_next_op(e, c);
         const int d = p_next_event(e);
         const bool busy = d < kBig;
         if (on && !busy) e.err |= JSS_ERR_NOPE_IDLE;                     // reference: IndexError (:517)
-        const int hole = p_advance(e, c, on && busy, d);
+        const int hole = p_advance(e, c, on && busy, d, next_op);
         if (on && c.gl == 0 && p.hole) p.hole[c.b] = busy ? hole : 0;
     } else if (MODE == kPolicy) {
         const int a = p_select(e, c, p.kind, p.seed, p.explore_q16,
@@ -546,9 +568,9 @@ __device__ __forceinline__ void p_load_constants(PCtx<G> &c, const Params &p, in
 // ---------------------------------------------------------------------------------------
 // the packed kernel, one env set (E = 64/G envs) per wave
 // ---------------------------------------------------------------------------------------
-// launch bounds: every mode but the multi-iteration rollout fits 64 VGPRs without spilling -> 8 waves per SIMD
+// launch bounds: the largest occupancy each mode reaches without spilling (8 waves per SIMD = 64 VGPRs)
 template <int G, int MODE>
-__global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : 8) void jss_packed_kernel(Params p) {
+__global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : (MODE == kStep ? 7 : 8)) void jss_packed_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     constexpr int E = kWave / G;                      // envs per wave
     constexpr int EB = E * kWavesPerBlock;            // envs per workgroup
