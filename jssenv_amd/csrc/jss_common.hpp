@@ -150,6 +150,16 @@ __device__ __forceinline__ void stage_table(int32_t *dst, const int32_t *ops, co
     }
 }
 
+// counters[4] += (steps, episodes, makespans, reward numerators) as result-less atomics: a plain `+=` is
+// a load the wave has to wait for (~600 cycles at the end of every wave); these are fire-and-forget.
+__device__ __forceinline__ void add_counters(int64_t *cn, int steps, int episodes, int makespan_sum, int reward_num) {
+    unsigned long long *u = reinterpret_cast<unsigned long long *>(cn);
+    if (steps) atomicAdd(u + 0, (unsigned long long)(long long)steps);
+    if (episodes) atomicAdd(u + 1, (unsigned long long)(long long)episodes);
+    if (makespan_sum) atomicAdd(u + 2, (unsigned long long)(long long)makespan_sum);
+    if (reward_num) atomicAdd(u + 3, (unsigned long long)(long long)reward_num);   // two's complement: negative adds wrap correctly
+}
+
 // LDS writes of one wave consumed by other lanes of the same wave
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -157,9 +167,10 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// Counter RNG, identical to oracle/jss_oracle.c orc_rng_u32: four rounds of a 32-bit
-// finaliser keyed by (seed, env, episode, step).  32-bit on purpose: the packed kernel
-// evaluates it per lane on the VALU, where a 64-bit multiply costs 4+ instructions.
+// Counter RNG, identical to oracle/jss_oracle.c orc_rng_u32: the key words are combined with odd
+// multipliers (independent multiplies, issued back to back) and pushed through two rounds of a 32-bit
+// finaliser.  32-bit and short on purpose: the packed kernel evaluates it per lane on the VALU and the
+// dependent chain of the policy sits on every wave's critical path (profiles/README.md).
 __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7FEB352Du;
@@ -169,10 +180,9 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step) {
-    uint32_t h = fmix32((uint32_t)seed ^ (uint32_t)env_id);
-    h = fmix32(h ^ ((uint32_t)(seed >> 32) + 0x9E3779B9u * (uint32_t)(env_id >> 32)));
-    h = fmix32(h ^ episode);
-    return fmix32(h + step);
+    const uint32_t a = (uint32_t)seed + (uint32_t)env_id * 0x9E3779B9u + episode * 0x85EBCA6Bu + step * 0xC2B2AE35u;
+    const uint32_t b = (uint32_t)(seed >> 32) ^ ((uint32_t)(env_id >> 32) * 0x27D4EB2Fu);
+    return fmix32(fmix32(a) ^ b);
 }
 constexpr uint64_t kExploreSeedXor = 0x5851F42D4C957F2DULL;
 

@@ -481,13 +481,7 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c
             p.o.done[c.b] = done ? 1 : 0;                                // :639-653
             if (called && done) p.o.makespan[c.b] = e.t;                 // :650
             if (p.s.counters && called) {
-                int64_t *cn = p.s.counters + (size_t)c.b * 4;
-                cn[0] += 1;
-                cn[3] += rn;
-                if (done) {
-                    cn[1] += 1;
-                    cn[2] += e.t;
-                }
+                add_counters(p.s.counters + (size_t)c.b * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
             }
         }
     } else if (MODE == kAdvance) {
@@ -542,11 +536,7 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c
             p.o.done[c.b] = done ? 1 : 0;
             if (last_makespan >= 0) p.o.makespan[c.b] = last_makespan;
             if (p.s.counters) {
-                int64_t *cn = p.s.counters + (size_t)c.b * 4;
-                cn[0] += n_steps;
-                cn[1] += n_done;
-                cn[2] += sum_makespan;
-                cn[3] += sum_rn;
+                add_counters(p.s.counters + (size_t)c.b * 4, n_steps, n_done, sum_makespan, sum_rn);
             }
         }
     }

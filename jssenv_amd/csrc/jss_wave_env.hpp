@@ -567,13 +567,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kRollout && JPL == 2) ? 6 : 8) voi
             p.o.done[b] = done ? 1 : 0;                                  // :639-653
             if (called && done) p.o.makespan[b] = e.t;                   // last_time_step :650
             if (p.s.counters && called) {
-                int64_t *cn = p.s.counters + (size_t)b * 4;
-                cn[0] += 1;
-                cn[3] += rn;
-                if (done) {
-                    cn[1] += 1;
-                    cn[2] += e.t;
-                }
+                add_counters(p.s.counters + (size_t)b * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
             }
         }
     } else if (MODE == kAdvance) {
@@ -617,11 +611,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kRollout && JPL == 2) ? 6 : 8) voi
             p.o.done[b] = any_legal(e) ? 0 : 1;
             if (last_makespan >= 0) p.o.makespan[b] = last_makespan;
             if (p.s.counters) {
-                int64_t *cn = p.s.counters + (size_t)b * 4;
-                cn[0] += n_steps;
-                cn[1] += n_done;
-                cn[2] += sum_makespan;
-                cn[3] += sum_rn;
+                add_counters(p.s.counters + (size_t)b * 4, n_steps, n_done, sum_makespan, sum_rn);
             }
         }
     }

@@ -446,7 +446,7 @@ const double *orc_state(const OrcEnv *e) { return e->state; }
 /* action selectors ---------------------------------------------------------- */
 
 /* Counter RNG shared with the device policy kernels (jssenv_amd/csrc/jss_common.hpp
- * rng_u32): four rounds of a 32-bit finaliser keyed by (seed, env, episode, step). */
+ * rng_u32): key words combined with odd multipliers, two rounds of a 32-bit finaliser. */
 static uint32_t fmix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7FEB352Du;
@@ -457,10 +457,9 @@ static uint32_t fmix32(uint32_t x) {
 }
 
 uint32_t orc_rng_u32(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step) {
-    uint32_t h = fmix32((uint32_t)seed ^ (uint32_t)env_id);
-    h = fmix32(h ^ ((uint32_t)(seed >> 32) + 0x9E3779B9u * (uint32_t)(env_id >> 32)));
-    h = fmix32(h ^ episode);
-    return fmix32(h + step);
+    const uint32_t a = (uint32_t)seed + (uint32_t)env_id * 0x9E3779B9u + episode * 0x85EBCA6Bu + step * 0xC2B2AE35u;
+    const uint32_t b = (uint32_t)(seed >> 32) ^ ((uint32_t)(env_id >> 32) * 0x27D4EB2Fu);
+    return fmix32(fmix32(a) ^ b);
 }
 
 static long remaining_work(const OrcEnv *e, int job) { /* dispatching.py:187-189 */

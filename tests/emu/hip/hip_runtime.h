@@ -292,6 +292,12 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_m
     });
 }
 
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
+    unsigned long long old = *p;
+    *p = old + v;
+    return old;
+}
+
 // ---- scalar helpers that hip_runtime.h provides as device functions --------------------
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
