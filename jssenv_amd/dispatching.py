@@ -88,7 +88,7 @@ class ShortestProcessingTime(DispatchingRule):                            # disp
     kind, larger_wins = "SPT", False
 
     def __init__(self):
-        super().__init__("SPT", "Shortest Processing Time: Schedule the job with the shortest processing time next")
+        super().__init__("SPT", "SPT - among the legal jobs, start the one whose current operation is shortest")
 
     def _value(self, env, job):
         return env.instance_matrix[job][env.todo_time_step_job[job]][1]
@@ -98,7 +98,7 @@ class FirstInFirstOut(DispatchingRule):                                   # disp
     kind, larger_wins = "FIFO", True
 
     def __init__(self):
-        super().__init__("FIFO", "First In First Out: Schedule the job that has been waiting the longest")
+        super().__init__("FIFO", "FIFO - among the legal jobs, start the one that has been idle longest since its last operation")
 
     def _value(self, env, job):
         return env.idle_time_jobs_last_op[job]
@@ -108,7 +108,7 @@ class MostWorkRemaining(DispatchingRule):                                 # disp
     kind, larger_wins = "MWR", True
 
     def __init__(self):
-        super().__init__("MWR", "Most Work Remaining: Schedule the job with the most processing time remaining")
+        super().__init__("MWR", "MWR - among the legal jobs, start the one with the largest sum of remaining durations")
 
     def _value(self, env, job):
         return _remaining_work(env, job)
@@ -118,7 +118,7 @@ class LeastWorkRemaining(DispatchingRule):                                # disp
     kind, larger_wins = "LWR", False
 
     def __init__(self):
-        super().__init__("LWR", "Least Work Remaining: Schedule the job with the least processing time remaining")
+        super().__init__("LWR", "LWR - among the legal jobs, start the one with the smallest sum of remaining durations")
 
     def _value(self, env, job):
         return _remaining_work(env, job)
@@ -128,7 +128,7 @@ class MostOperationsRemaining(DispatchingRule):                           # disp
     kind, larger_wins = "MOR", True
 
     def __init__(self):
-        super().__init__("MOR", "Most Operations Remaining: Schedule the job with the most operations remaining")
+        super().__init__("MOR", "MOR - among the legal jobs, start the one with the most operations still to do")
 
     def _value(self, env, job):
         return env.machines - env.todo_time_step_job[job]
@@ -138,7 +138,7 @@ class LeastOperationsRemaining(DispatchingRule):                          # disp
     kind, larger_wins = "LOR", False
 
     def __init__(self):
-        super().__init__("LOR", "Least Operations Remaining: Schedule the job with the fewest operations remaining")
+        super().__init__("LOR", "LOR - among the legal jobs, start the one with the fewest operations still to do")
 
     def _value(self, env, job):
         return env.machines - env.todo_time_step_job[job]
@@ -151,7 +151,7 @@ class CriticalRatio(DispatchingRule):                                     # disp
     kind, larger_wins = None, False
 
     def __init__(self, due_date_factor: float = 1.5):
-        super().__init__("CR", "Critical Ratio: Schedule based on the ratio of time to due date versus remaining work")
+        super().__init__("CR", "CR - among the legal jobs, start the one with the smallest (due date - now) / remaining work")
         self.due_date_factor = due_date_factor
         self._due_dates: Dict[int, float] = {}
 
@@ -190,23 +190,18 @@ DISPATCHING_RULES = {                                                     # disp
 
 
 def get_rule(rule_name: str) -> DispatchingRule:                          # dispatching.py:423-439
-    if rule_name not in DISPATCHING_RULES:
-        raise ValueError(f"Rule '{rule_name}' not found. Available rules: {list(DISPATCHING_RULES.keys())}")
-    return DISPATCHING_RULES[rule_name]
+    try:
+        return DISPATCHING_RULES[rule_name]
+    except KeyError:
+        raise ValueError(f"Rule '{rule_name}' not found. Available rules: {list(DISPATCHING_RULES)}") from None
 
 
 def compare_rules(env, rules: Optional[List[str]] = None, num_episodes: int = 10) -> Dict[str, Dict[str, float]]:
-    """dispatching.py:442-475."""
-    if rules is None:
-        rules = list(DISPATCHING_RULES.keys())
+    """Mean total reward and mean makespan of each rule over ``num_episodes`` episodes on ``env``
+    (same result keys as dispatching.py:442-475)."""
     results = {}
-    for rule_name in rules:
-        rule = get_rule(rule_name)
-        total_reward = 0.0
-        total_makespan = 0.0
-        for _ in range(num_episodes):
-            reward, makespan = rule.run_episode(env)
-            total_reward += reward
-            total_makespan += makespan
-        results[rule_name] = {"avg_reward": total_reward / num_episodes, "avg_makespan": total_makespan / num_episodes}
+    for name in (list(DISPATCHING_RULES) if rules is None else rules):
+        episodes = [get_rule(name).run_episode(env) for _ in range(num_episodes)]
+        results[name] = {"avg_reward": sum(r for r, _ in episodes) / num_episodes,
+                         "avg_makespan": sum(m for _, m in episodes) / num_episodes}
     return results
