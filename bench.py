@@ -276,6 +276,18 @@ def main():
                                 "iterations_per_launch": 64, "launches": n_l,
                                 "note": "policy+step x64 per launch, observation written once per launch"}
         if world == 1 and args.workload == "shared":
+            # twice the contract batch: same kernel, four rounds of resident waves instead of two
+            env2x = make_env(2 * B)
+            for _ in range(args.warmup):
+                env2x.rollout(args.policy, n_iter=1, autoreset=True)
+            mode2 = pick_mode(env2x)
+            env2x.zero_counters()
+            dt2, ms2 = timed(env2x, args.steps, 1, mode2)
+            steps2 = float(env2x.counter_totals()[0].item())
+            out["batch_x2"] = {"batch": 2 * B, "value": steps2 / dt2, "unit": "env steps/s", "kernel_ms": ms2,
+                               "roofline_frac": steps2 / args.steps * alg_per_step / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "launch": mode2}
+            del env2x
             env4k = make_env(4096)
             for _ in range(args.warmup):
                 env4k.rollout(args.policy, n_iter=1, autoreset=True)
