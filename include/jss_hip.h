@@ -17,7 +17,7 @@
  *   jss_policy   <- the action selectors callers put in front of step():
  *                   README.md:58-60 (random masked), JSSEnv/dispatching.py
  *                   FIFO :133-156, SPT :92-116, MWR :173-199, LWR :216-242,
- *                   MOR :259-283, LOR :300-324 (exploration handled by the host)
+ *                   MOR :259-283, LOR :300-324, CR :365-408
  *   jss_rollout  <- DispatchingRule.run_episode's loop    dispatching.py:55-75
  *                   (policy + step fused, n iterations per launch, optional
  *                    auto-restart of finished episodes)
@@ -96,7 +96,8 @@ extern "C" {
 #define JSS_POLICY_LWR 4
 #define JSS_POLICY_MOR 5
 #define JSS_POLICY_LOR 6
-#define JSS_N_POLICIES 7
+#define JSS_POLICY_CR 7 /* critical ratio (1.5 * job length - now) / remaining work, dispatching.py:365-408 */
+#define JSS_N_POLICIES 8
 
 /* jss_rollout flags */
 #define JSS_ROLLOUT_AUTORESET 1 /* an env found done is reset instead of stepped (iteration not counted) */

@@ -18,7 +18,7 @@ STATUS_NOOP = 256
 F4_ONE = -1
 ERR_ILLEGAL_ACTION, ERR_NOPE_IDLE, ERR_BAD_ACTION = 1, 2, 4
 ACTION_SKIP = -1
-POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6}
+POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6, "CR": 7}
 ROLLOUT_AUTORESET = 1
 OPT_KERNEL, KERNEL_AUTO, KERNEL_WAVE = 0, 0, 1
 OPT_ABLATE = 1

@@ -184,6 +184,31 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t env_id, uint
     const uint32_t b = (uint32_t)(seed >> 32) ^ ((uint32_t)(env_id >> 32) * 0x27D4EB2Fu);
     return fmix32(fmix32(a) ^ b);
 }
+// CriticalRatio (dispatching.py:365-408): ratio = (1.5 * job_length - now) / remaining_work, smallest first, lowest
+// job index on ties.  Compared exactly as the fraction (3 * job_length - 2 * now) / remaining_work by cross
+// multiplication in int64: two different such fractions differ by > 1e-13 relative, far above a double's 1.1e-16, so
+// the order (and the ties) are the ones the reference's float comparison sees.
+struct CrKey {
+    int num, den, idx;
+};
+__device__ __forceinline__ bool cr_better(const CrKey &a, const CrKey &b) {
+    const long long l = (long long)a.num * b.den, r = (long long)b.num * a.den;
+    return l < r || (l == r && a.idx < b.idx);
+}
+template <int WIDTH>
+__device__ __forceinline__ CrKey cr_argmin(CrKey k) {   // butterfly inside aligned groups of WIDTH lanes
+#pragma unroll
+    for (int off = WIDTH / 2; off > 0; off >>= 1) {
+        CrKey o;
+        o.num = __shfl_xor(k.num, off);
+        o.den = __shfl_xor(k.den, off);
+        o.idx = __shfl_xor(k.idx, off);
+        if (cr_better(o, k)) k = o;
+    }
+    return k;
+}
+constexpr int kCrNone = 1 << 20;
+
 constexpr uint64_t kExploreSeedXor = 0x5851F42D4C957F2DULL;
 
 }  // namespace jss

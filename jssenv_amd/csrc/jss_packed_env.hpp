@@ -329,20 +329,36 @@ __device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G> &c, int 
         const uint32_t hit = grp_ballot<G>(e.legal && below == pick, c.gbase);
         a = hit ? __ffs(hit) - 1 : c.J;                                  // pick >= nl: NOPE (it is legal then)
     } else {
-        const bool larger = (kind == JSS_POLICY_FIFO || kind == JSS_POLICY_MWR || kind == JSS_POLICY_MOR);
-        int v;
-        if (kind == JSS_POLICY_FIFO) v = e.idle_last;
-        else if (kind == JSS_POLICY_SPT) v = e.cur & kDurMask;
-        else if (kind == JSS_POLICY_MOR || kind == JSS_POLICY_LOR) v = c.M - e.todo;
-        else {
-            v = 0;
+        if (kind == JSS_POLICY_CR) {
+            int total = 0, remaining = 0;
             if (e.legal)
-                for (int k = e.todo; k < c.M; ++k) v += c.ops[c.gl * c.stride + k] & kDurMask;
+                for (int k = 0; k < c.M; ++k) {
+                    const int d = c.ops[c.gl * c.stride + k] & kDurMask;
+                    total += d;
+                    if (k >= e.todo) remaining += d;
+                }
+            CrKey key;
+            key.num = e.legal ? 3 * total - 2 * e.t : 0x3fffffff;
+            key.den = e.legal ? remaining : 1;
+            key.idx = e.legal ? c.gl : kCrNone;
+            key = cr_argmin<G>(key);
+            a = key.idx < kCrNone ? key.idx : c.J;                       // no job legal: NOPE
+        } else {
+            const bool larger = (kind == JSS_POLICY_FIFO || kind == JSS_POLICY_MWR || kind == JSS_POLICY_MOR);
+            int v;
+            if (kind == JSS_POLICY_FIFO) v = e.idle_last;
+            else if (kind == JSS_POLICY_SPT) v = e.cur & kDurMask;
+            else if (kind == JSS_POLICY_MOR || kind == JSS_POLICY_LOR) v = c.M - e.todo;
+            else {
+                v = 0;
+                if (e.legal)
+                    for (int k = e.todo; k < c.M; ++k) v += c.ops[c.gl * c.stride + k] & kDurMask;
+            }
+            const int key = e.legal ? (larger ? v : -v) : -kBig;
+            const int best = grp_max<G>(key);
+            const uint32_t hit = grp_ballot<G>(e.legal && key == best, c.gbase);
+            a = hit ? __ffs(hit) - 1 : c.J;                              // no job legal: NOPE
         }
-        const int key = e.legal ? (larger ? v : -v) : -kBig;
-        const int best = grp_max<G>(key);
-        const uint32_t hit = grp_ballot<G>(e.legal && key == best, c.gbase);
-        a = hit ? __ffs(hit) - 1 : c.J;                                  // no job legal: NOPE
         if (e.noop && explore_q16 != 0) {
             const uint32_t r = rng_u32(seed ^ kExploreSeedXor, env_id, episode, step);
             if ((r >> 16) < explore_q16) a = c.J;

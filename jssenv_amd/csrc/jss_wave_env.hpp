@@ -356,32 +356,58 @@ __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, in
         return a;
     }
     if (nl == 0) return c.J;  // only NOPE is legal (dispatching.py:96-97)
-    int key[JPL];
-    const bool larger = (kind == JSS_POLICY_FIFO || kind == JSS_POLICY_MWR || kind == JSS_POLICY_MOR);
-#pragma unroll
-    for (int s = 0; s < JPL; ++s) {
-        const int j = s * kWave + c.lane;
-        const bool lg = (e.legal[s] >> c.lane) & 1;
-        int v;
-        if (kind == JSS_POLICY_FIFO) v = e.idle_last[s];                 // dispatching.py:146
-        else if (kind == JSS_POLICY_SPT) v = e.cur[s] & kDurMask;        // :105-106
-        else if (kind == JSS_POLICY_MOR || kind == JSS_POLICY_LOR) v = c.M - e.todo[s];  // :273 / :314
-        else {                                                           // MWR / LWR :187-189 / :230-232
-            v = 0;
-            if (lg)
-                for (int k = e.todo[s]; k < c.M; ++k) v += c.ops[j * c.stride + k] & kDurMask;
-        }
-        key[s] = lg ? (larger ? v : -v) : -kBig;
-    }
-    int best = key[0];
-#pragma unroll
-    for (int s = 1; s < JPL; ++s) best = imax(best, key[s]);
-    best = wave_max(best);
     int a = -1;
+    if (kind == JSS_POLICY_CR) {                                         // dispatching.py:365-408
+        CrKey best;
+        best.num = 0x3fffffff;
+        best.den = 1;
+        best.idx = kCrNone;
 #pragma unroll
-    for (int s = 0; s < JPL; ++s) {  // strict comparisons in the reference: the first index wins ties
-        const uint64_t hit = __ballot(key[s] == best) & e.legal[s];
-        if (a < 0 && hit) a = s * kWave + __ffsll((unsigned long long)hit) - 1;
+        for (int s = 0; s < JPL; ++s) {
+            const int j = s * kWave + c.lane;
+            const bool lg = (e.legal[s] >> c.lane) & 1;
+            int total = 0, remaining = 0;
+            if (lg)
+                for (int k = 0; k < c.M; ++k) {
+                    const int d = c.ops[j * c.stride + k] & kDurMask;
+                    total += d;
+                    if (k >= e.todo[s]) remaining += d;
+                }
+            CrKey key;
+            key.num = lg ? 3 * total - 2 * e.t : 0x3fffffff;
+            key.den = lg ? remaining : 1;
+            key.idx = lg ? j : kCrNone;
+            if (cr_better(key, best)) best = key;
+        }
+        best = cr_argmin<kWave>(best);
+        a = __builtin_amdgcn_readfirstlane(best.idx);
+    } else {
+        int key[JPL];
+        const bool larger = (kind == JSS_POLICY_FIFO || kind == JSS_POLICY_MWR || kind == JSS_POLICY_MOR);
+#pragma unroll
+        for (int s = 0; s < JPL; ++s) {
+            const int j = s * kWave + c.lane;
+            const bool lg = (e.legal[s] >> c.lane) & 1;
+            int v;
+            if (kind == JSS_POLICY_FIFO) v = e.idle_last[s];                 // dispatching.py:146
+            else if (kind == JSS_POLICY_SPT) v = e.cur[s] & kDurMask;        // :105-106
+            else if (kind == JSS_POLICY_MOR || kind == JSS_POLICY_LOR) v = c.M - e.todo[s];  // :273 / :314
+            else {                                                           // MWR / LWR :187-189 / :230-232
+                v = 0;
+                if (lg)
+                    for (int k = e.todo[s]; k < c.M; ++k) v += c.ops[j * c.stride + k] & kDurMask;
+            }
+            key[s] = lg ? (larger ? v : -v) : -kBig;
+        }
+        int best = key[0];
+#pragma unroll
+        for (int s = 1; s < JPL; ++s) best = imax(best, key[s]);
+        best = wave_max(best);
+#pragma unroll
+        for (int s = 0; s < JPL; ++s) {  // strict comparisons in the reference: the first index wins ties
+            const uint64_t hit = __ballot(key[s] == best) & e.legal[s];
+            if (a < 0 && hit) a = s * kWave + __ffsll((unsigned long long)hit) - 1;
+        }
     }
     if (e.noop && explore_q16 != 0) {                                    // dispatching.py:113: 10 % NOPE when NOPE is legal
         const uint32_t r = rng_u32(seed ^ kExploreSeedXor, env_id, episode, step);

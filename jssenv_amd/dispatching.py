@@ -13,8 +13,8 @@ Same names (``ShortestProcessingTime`` ... ``CriticalRatio``, ``DISPATCHING_RULE
 
 The arg-best itself runs on the GPU (``jss_policy``, csrc ``select_action``/``p_select``)
 when ``env`` is a ``jssenv_amd.JssEnv``; any other env object exposing the reference's
-attributes falls back to the attribute-reading loop of the reference rule.  CriticalRatio is
-float arithmetic with a per-episode cache (:327-408) and stays on the host.
+attributes falls back to the attribute-reading loop of the reference rule (CriticalRatio's float
+ratios with its per-episode due-date cache, :327-408, included).
 
 For whole batches use ``BatchedJssEnv.rollout(kind)`` -- rule + step fused on the device.
 """
@@ -146,9 +146,10 @@ class LeastOperationsRemaining(DispatchingRule):                          # disp
 
 class CriticalRatio(DispatchingRule):                                     # dispatching.py:327-408
     """(due date - now) / remaining work, smallest first; due date = factor x job length, cached
-    per job and dropped when ``current_time_step == 0`` (:373-374).  Host-side float arithmetic."""
+    per job and dropped when ``current_time_step == 0`` (:373-374).  On a jssenv_amd env the arg-min runs on
+    the device as an exact fraction comparison (csrc ``cr_better``); the float path below serves other envs."""
 
-    kind, larger_wins = None, False
+    kind, larger_wins = "CR", False
 
     def __init__(self, due_date_factor: float = 1.5):
         super().__init__("CR", "CR - among the legal jobs, start the one with the smallest (due date - now) / remaining work")

@@ -491,6 +491,24 @@ int orc_policy(const OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32
     int n_jobs_legal = 0;
     for (int j = 0; j < J; ++j) n_jobs_legal += legal[j] ? 1 : 0;
     if (n_jobs_legal == 0) return legal[J] ? J : -1; /* only NOPE legal -> NOPE; nothing legal -> -1 (the rules' min_job = -1) */
+    if (kind == ORC_POLICY_CR) {                /* dispatching.py:376-402, floats exactly as the reference computes them */
+        int min_job = -1;
+        double min_ratio = 1.0 / 0.0;
+        for (int job = 0; job < J; ++job) {
+            if (!legal[job]) continue;
+            long total_time = 0;
+            for (int op = 0; op < e->machines; ++op) total_time += DUR(e, job, op);       /* :357 */
+            double due_date = (double)total_time * 1.5;                                   /* :360 */
+            long remaining_time = remaining_work(e, job);                                 /* :386-388 */
+            double time_remaining = due_date - (double)e->current_time_step;              /* :391 */
+            double ratio = remaining_time > 0 ? time_remaining / (double)remaining_time : 1.0 / 0.0;  /* :395-398 */
+            if (ratio < min_ratio) {                                                      /* :400 */
+                min_ratio = ratio;
+                min_job = job;
+            }
+        }
+        return min_job;
+    }
     int best = -1;
     long best_v = 0;
     for (int job = 0; job < J; ++job) {

@@ -75,6 +75,7 @@ const double  *orc_state(const OrcEnv *e);                         /* [J*7] */
 #define ORC_POLICY_LWR    4 /* dispatching.py:216-242 */
 #define ORC_POLICY_MOR    5 /* dispatching.py:259-283 */
 #define ORC_POLICY_LOR    6 /* dispatching.py:300-324 */
+#define ORC_POLICY_CR     7 /* dispatching.py:365-408, due_date_factor 1.5 */
 
 uint32_t orc_rng_u32(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step);
 int orc_policy(const OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step);

@@ -203,7 +203,7 @@ def case_rollout(backend, inst_names, batch, n_iter, kind="random", seed=5, chun
     return env, orcs
 
 
-def case_rule_makespans(backend, rules=("FIFO", "SPT", "MWR", "LWR", "MOR", "LOR"), insts=("ta01", "ta41")):
+def case_rule_makespans(backend, rules=("FIFO", "SPT", "MWR", "LWR", "MOR", "LOR", "CR"), insts=("ta01", "ta41")):
     """G3: deterministic rule makespans of the live reference, reproduced by device rollouts."""
     g = G.load("rules")
     rnames, inames = [str(r) for r in g["rules"]], [str(i) for i in g["instances"]]

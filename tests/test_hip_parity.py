@@ -39,7 +39,7 @@ def test_batch_ragged_random_policy(hip):
     P.case_batch_lockstep(hip, names, batch=27, n_steps=400, kind="random", nope_every=9, check_every=7)
 
 
-@pytest.mark.parametrize("kind", ["FIFO", "SPT", "MWR", "LWR", "MOR", "LOR"])
+@pytest.mark.parametrize("kind", ["FIFO", "SPT", "MWR", "LWR", "MOR", "LOR", "CR"])
 def test_batch_rules(hip, kind):
     P.case_batch_lockstep(hip, ["ta01", "ta21", "ta72"], batch=6, n_steps=2500, kind=kind, check_every=25)
 

@@ -49,7 +49,7 @@ def test_batch_ragged_random_policy(emu):
                           check_every=3)
 
 
-@pytest.mark.parametrize("kind", ["FIFO", "SPT", "MWR", "LWR", "MOR", "LOR"])
+@pytest.mark.parametrize("kind", ["FIFO", "SPT", "MWR", "LWR", "MOR", "LOR", "CR"])
 def test_batch_rules(emu, kind):
     P.case_batch_lockstep(emu, ["ta01", "ta21"], batch=3, n_steps=60, kind=kind, check_every=5)
 
@@ -63,7 +63,7 @@ def test_rollout_ragged(emu):
 
 
 def test_rule_makespan_ta01(emu):
-    P.case_rule_makespans(emu, rules=("FIFO", "SPT", "MOR"), insts=("ta01",))
+    P.case_rule_makespans(emu, rules=("FIFO", "SPT", "MOR", "CR"), insts=("ta01",))
 
 
 def test_error_semantics(emu):

@@ -36,7 +36,7 @@ def test_rule_table():
     rules, insts = [str(r) for r in g["rules"]], [str(i) for i in g["instances"]]
     for ri, rule in enumerate(rules):
         if rule not in POLICY_IDS:
-            continue  # CR is host-side float arithmetic, covered with the dispatching module
+            continue
         for ii, inst in enumerate(insts):
             env = OracleEnv(I.builtin_instance(inst))
             env.reset()
