@@ -205,3 +205,31 @@ def test_vector_facade(hip):
 
 def test_persistent_kernel(hip):
     P.case_persistent_kernel(hip, batch=173, n_steps=400)
+
+
+def test_headline_batch_65536(hip):
+    """The benchmarked configuration (ta01, 65 536 envs, random masked policy, one launch per step with
+    auto-restart): oracle agreement on a sample and size-independent properties on every env."""
+    from jssenv_amd import BatchedJssEnv, builtin_instance
+    from oracle import OracleEnv
+    inst = builtin_instance("ta01")
+    B, seed, iters = 65536, 17, 310
+    env = BatchedJssEnv(inst, batch=B, seed=seed, env_id_base=5_000_000_000, _backend=hip)   # ids beyond 32 bits
+    env.reset()
+    for _ in range(iters):
+        env.rollout("random", n_iter=1)
+    cnt = env.counters.cpu().numpy()
+    hdr = env.env_header.cpu().numpy()
+    assert int(env.err.max().item()) == 0
+    assert (cnt[:, 0] + hdr[:, 1] - 1 == iters).all()          # every iteration is a step or an auto-reset
+    assert (cnt[:, 1] >= 1).all() and (cnt[:, 1] == hdr[:, 1] - 1 + (env.done.cpu().numpy() != 0)).all()
+    obs = env.real_obs.cpu().numpy()
+    assert obs.min() >= 0.0 and obs.max() <= 1.0 and np.isfinite(obs).all()
+    mask = env.action_mask.cpu().numpy()
+    assert (obs[:, :, 0] == mask[:, :15]).all()
+    for i in list(range(0, B, 4099)) + [B - 1]:
+        o = OracleEnv(inst, strict=True)
+        o.reset()
+        r = o.rollout("random", seed, 5_000_000_000 + i, iters, episode=1)
+        P.assert_matches_oracle(env.host_state(i), o, f"headline env {i}")
+        assert cnt[i, 0] == r["steps"] and cnt[i, 1] == r["episodes"] and cnt[i, 2] == r["makespan_sum"]
