@@ -73,6 +73,9 @@ struct WaveSync {
 };
 
 struct Block {
+    std::vector<const char *> waiting_in;   // per fibre: the collective it last entered (deadlock reports)
+    std::vector<unsigned long long> n_coll; // per fibre: collectives entered so far
+    std::vector<std::vector<const char *>> history;  // per fibre: every collective entered, in order
     std::vector<ucontext_t> ctx;
     std::vector<char *> stacks;
     std::vector<char> finished;
@@ -107,6 +110,12 @@ inline void yield() {
 
 inline int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 inline WaveSync &my_wave() { return cur_block()->waves[threadIdx.x / WAVE]; }
+
+inline void mark(const char *what) {
+    cur_block()->waiting_in[threadIdx.x] = what;
+    cur_block()->n_coll[threadIdx.x]++;
+    cur_block()->history[threadIdx.x].push_back(what);
+}
 
 inline void wave_sync() {
     WaveSync &w = my_wave();
@@ -156,6 +165,9 @@ inline void run_block(Block &b, unsigned bx, dim3 grid, dim3 block) {
     assert(b.nthreads % WAVE == 0 && "emulator needs whole waves");
     b.ctx.assign(b.nthreads, ucontext_t());
     b.finished.assign(b.nthreads, 0);
+    b.waiting_in.assign(b.nthreads, "-");
+    b.n_coll.assign(b.nthreads, 0);
+    b.history.assign(b.nthreads, std::vector<const char *>());
     b.waves.assign(b.nthreads / WAVE, WaveSync());
     b.block_arrived = 0;
     b.live = b.nthreads;
@@ -172,7 +184,32 @@ inline void run_block(Block &b, unsigned bx, dim3 grid, dim3 block) {
     gridDim = grid;
     blockDim = block;
     blockIdx = dim3(bx, 0, 0);
+    unsigned long long passes = 0;
     while (b.live > 0) {
+        if (++passes == 2000000ULL) {   // no kernel of the suite needs this many scheduler passes: lanes of a wave
+                                        // are waiting in DIFFERENT collectives (divergent control flow around one)
+            fprintf(stderr, "emu: deadlock in block %u -- collective each unfinished lane waits in:\n", bx);
+            for (int i = 0; i < b.nthreads; ++i)
+                fprintf(stderr, "  lane %3d: %-32s collectives entered %llu%s\n", i, b.waiting_in[i], b.n_coll[i],
+                        b.finished[i] ? "  (finished)" : "");
+            for (int w = 0; w < b.nthreads / WAVE; ++w)      // first point where a lane's sequence leaves lane 0's
+                for (int i = 1; i < WAVE; ++i) {
+                    const auto &a = b.history[w * WAVE], &c = b.history[w * WAVE + i];
+                    size_t k = 0;
+                    while (k < a.size() && k < c.size() && a[k] == c[k]) ++k;
+                    if (k < a.size() || k < c.size())
+                        fprintf(stderr, "  wave %d lane %d diverges from lane 0 at collective #%zu: %s vs %s (previous: %s)\n", w, i, k,
+                                k < c.size() ? c[k] : "<end>", k < a.size() ? a[k] : "<end>", k ? a[k - 1] : "-");
+                    if (k < a.size() || k < c.size()) {
+                        fprintf(stderr, "    lane 0 :");
+                        for (size_t q = 0; q < a.size() && q < k + 8; ++q) fprintf(stderr, " %s", a[q] + (a[q][0] == '_' ? 2 : 0));
+                        fprintf(stderr, "\n    lane %d:", i);
+                        for (size_t q = 0; q < c.size() && q < k + 8; ++q) fprintf(stderr, " %s", c[q] + (c[q][0] == '_' ? 2 : 0));
+                        fprintf(stderr, "\n");
+                    }
+                }
+            abort();
+        }
         for (int i = 0; i < b.nthreads; ++i) {
             if (b.finished[i]) continue;
             b.current = i;
@@ -201,13 +238,14 @@ inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, 
 #define HIP_DYNAMIC_SHARED(type, var) type *var = reinterpret_cast<type *>(emu::cur_block()->dyn_smem.data());
 
 // ---- workgroup / wave synchronisation ------------------------------------------------
-inline void __syncthreads() { emu::block_sync(); }
-inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
+inline void __syncthreads() { emu::mark("__syncthreads"); emu::block_sync(); }
+inline void __builtin_amdgcn_wave_barrier() { emu::mark("wave_barrier"); emu::wave_sync(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 inline void __builtin_amdgcn_s_barrier() { emu::block_sync(); }
 
 // ---- cross-lane ----------------------------------------------------------------------
 inline unsigned long long __ballot(int pred) {
+    emu::mark("__ballot");
     return emu::exchange((uint64_t)(pred != 0), [](const uint64_t *v) {
         unsigned long long m = 0;
         for (int i = 0; i < emu::WAVE; ++i) m |= (unsigned long long)(v[i] & 1) << i;
@@ -215,27 +253,33 @@ inline unsigned long long __ballot(int pred) {
     });
 }
 inline int __shfl(int v, int src, int width = 64) {
+    emu::mark("__shfl");
     (void)width;
     return emu::exchange((uint64_t)(uint32_t)v, [=](const uint64_t *vals) { return (int)(uint32_t)vals[src & 63]; });
 }
 inline int __shfl_xor(int v, int mask, int width = 64) {
+    emu::mark("__shfl_xor");
     (void)width;
     int me = emu::lane_id();
     return emu::exchange((uint64_t)(uint32_t)v, [=](const uint64_t *vals) { return (int)(uint32_t)vals[(me ^ mask) & 63]; });
 }
 inline int __builtin_amdgcn_readlane(int v, int lane) {
+    emu::mark("__builtin_amdgcn_readlane");
     return emu::exchange((uint64_t)(uint32_t)v, [=](const uint64_t *vals) { return (int)(uint32_t)vals[lane & 63]; });
 }
 inline int __builtin_amdgcn_readfirstlane(int v) {
+    emu::mark("__builtin_amdgcn_readfirstlane");
     return emu::exchange((uint64_t)(uint32_t)v, [=](const uint64_t *vals) { return (int)(uint32_t)vals[0]; });
 }
 inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int v) {
+    emu::mark("__builtin_amdgcn_ds_bpermute");
     return emu::exchange((uint64_t)(uint32_t)v,
                          [=](const uint64_t *vals) { return (int)(uint32_t)vals[(byte_addr >> 2) & 63]; });
 }
 /* ds_swizzle, bit-mask mode (offset bit 15 = 0): within each group of 32 lanes,
  * src = ((lane & and_mask) | or_mask) ^ xor_mask. */
 inline int __builtin_amdgcn_ds_swizzle(int v, int pattern) {
+    emu::mark("__builtin_amdgcn_ds_swizzle");
     int me = emu::lane_id();
     if (pattern & 0x8000) {
         fprintf(stderr, "emu: ds_swizzle quad-perm mode unsupported\n");
@@ -259,6 +303,7 @@ inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) {
 /* DPP (gfx9 encodings, cdna4 ISA "DPP_CTRL"): the subset the kernels use.
  * bound_ctrl=false: an invalid source lane or a masked-off row/bank keeps `old`. */
 inline int __builtin_amdgcn_update_dpp(int old, int src, int dpp_ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    emu::mark("__builtin_amdgcn_update_dpp");
     int me = emu::lane_id();
     return emu::exchange((uint64_t)(uint32_t)src, [=](const uint64_t *vals) {
         int row = me / 16, in_row = me % 16, bank = in_row / 4;
