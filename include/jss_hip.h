@@ -151,7 +151,6 @@ const char *jss_error_string(int code);
 #define JSS_OPT_KERNEL 0
 #define JSS_KERNEL_AUTO 0
 #define JSS_KERNEL_WAVE 1
-#define JSS_KERNEL_PACKED8 2 /* like AUTO, but batches with jmax, mmax <= 16 use 8 envs per wavefront (8 lanes x 2 jobs) */
 /* JSS_OPT_ABLATE (profiling aid, results become WRONG): bit mask of phases the kernels skip, used by
  * tools/gpu_ablate.sh to attribute kernel time.  0 = normal operation. */
 #define JSS_OPT_ABLATE 1

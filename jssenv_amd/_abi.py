@@ -20,7 +20,7 @@ ERR_ILLEGAL_ACTION, ERR_NOPE_IDLE, ERR_BAD_ACTION = 1, 2, 4
 ACTION_SKIP = -1
 POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6, "CR": 7}
 ROLLOUT_AUTORESET = 1
-OPT_KERNEL, KERNEL_AUTO, KERNEL_WAVE, KERNEL_PACKED8 = 0, 0, 1, 2
+OPT_KERNEL, KERNEL_AUTO, KERNEL_WAVE = 0, 0, 1
 OPT_ABLATE = 1
 OPT_LDS_PAD = 2
 OPT_PERSIST = 3

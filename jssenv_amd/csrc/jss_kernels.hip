@@ -4,11 +4,9 @@
 //   jss_common.hpp      parameters, wave helpers, counter RNG
 //   jss_wave_env.hpp    one wavefront per env        (any J <= 128, M <= 64)
 //   jss_packed_env.hpp  64/G envs per wavefront      (J, M <= G, G = 16 or 32)
-//   jss_packed8_env.hpp 8 envs per wavefront         (J, M <= 16: 8 lanes x 2 jobs per lane)
 //
 // No MFMA anywhere: the path is integer indexing, there is no dense contraction.
 #include "jss_common.hpp"
-#include "jss_packed8_env.hpp"
 #include "jss_packed_env.hpp"
 #include "jss_wave_env.hpp"
 
@@ -54,7 +52,7 @@ int compute_units() {
 // a 16- or 32-lane group.
 int packed_group(const JssDesc &d) {
     if (g_kernel_choice == JSS_KERNEL_WAVE) return 0;
-    if (d.jmax <= 16 && d.mmax <= 16) return g_kernel_choice == JSS_KERNEL_PACKED8 ? 8 : 16;
+    if (d.jmax <= 16 && d.mmax <= 16) return 16;
     if (d.jmax <= 32 && d.mmax <= 32) return 32;
     return 0;
 }
@@ -68,17 +66,6 @@ int launch(Params &p, void *stream) {
     p.ablate = g_ablate;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int G = packed_group(p.d);
-    if (G == 8) {
-        const int envs_per_block = kE8 * kWavesPerBlock;
-        const int n_regions = p.shared_table ? 1 : envs_per_block;
-        p.obs_off_ints = (n_regions * p.region_ints + 3) & ~3;
-        p.obs_wave_floats = (kE8 * p.d.jmax * 7 + 3) & ~3;
-        p.mv_off_ints = p.obs_off_ints + kWavesPerBlock * p.obs_wave_floats;
-        const size_t shmem = sizeof(int32_t) * ((size_t)p.mv_off_ints + 2 * kBlock) + g_lds_pad;
-        const int blocks = (p.d.batch + envs_per_block - 1) / envs_per_block;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed8_kernel<MODE>), dim3(blocks), dim3(kBlock), shmem, st, p);
-        return (int)hipGetLastError();
-    }
     if (G) {
         const int envs_per_block = (kWave / G) * kWavesPerBlock;
         const int n_regions = p.shared_table ? 1 : envs_per_block;
@@ -122,7 +109,7 @@ extern "C" {
 int jss_abi_version(void) { return JSS_ABI_VERSION; }
 
 int jss_set_option(int option, int value) {
-    if (option == JSS_OPT_KERNEL && value >= JSS_KERNEL_AUTO && value <= JSS_KERNEL_PACKED8) {
+    if (option == JSS_OPT_KERNEL && value >= JSS_KERNEL_AUTO && value <= JSS_KERNEL_WAVE) {
         g_kernel_choice = value;
         return 0;
     }

@@ -9,7 +9,7 @@ import parity_cases as P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "wave", "packed8"])
+@pytest.fixture(scope="module", params=["auto", "wave"])
 def hip(request):
     """auto: packed kernel (64/G envs per wavefront) where the batch shape fits, wave-per-env
     otherwise; wave: force one wavefront per env everywhere."""
@@ -17,7 +17,7 @@ def hip(request):
     from jssenv_amd.env import HipBackend
     be = HipBackend("cuda:0")
     assert be.name == "hip"
-    assert be.lib.jss_set_option(_abi.OPT_KERNEL, {"auto": _abi.KERNEL_AUTO, "wave": _abi.KERNEL_WAVE, "packed8": _abi.KERNEL_PACKED8}[request.param]) == 0
+    assert be.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_WAVE if request.param == "wave" else _abi.KERNEL_AUTO) == 0
     yield be
     be.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_AUTO)
 

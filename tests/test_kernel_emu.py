@@ -12,14 +12,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu
 import parity_cases as P  # noqa: E402
 
 
-@pytest.fixture(scope="module", params=["auto", "wave", "packed8"])
+@pytest.fixture(scope="module", params=["auto", "wave"])
 def emu(request):
     """auto: 64/G envs per wavefront where the shape fits (ta01 -> G=16, ta21/ta41/dmu16 -> G=32),
     one wavefront per env otherwise (ta51.., ragged batches up to 100 jobs); wave: force the latter."""
     from emu_backend import EmuBackend
     from jssenv_amd import _abi
     be = EmuBackend()
-    assert be.lib.jss_set_option(_abi.OPT_KERNEL, {"auto": _abi.KERNEL_AUTO, "wave": _abi.KERNEL_WAVE, "packed8": _abi.KERNEL_PACKED8}[request.param]) == 0
+    assert be.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_WAVE if request.param == "wave" else _abi.KERNEL_AUTO) == 0
     yield be
     be.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_AUTO)
 

@@ -16,8 +16,6 @@ if inst == "synthetic50x20":
     env = BatchedJssEnv(synthetic_batch(B, 50, 20), device="cuda:0")
 else:
     env = BatchedJssEnv(inst, batch=B, device="cuda:0")
-if os.environ.get("JSS_KERNEL") == "packed8":
-    env.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_PACKED8)
 env.reset()
 ids = torch.arange(B, device="cuda:0") % 16
 for r in range(15):
