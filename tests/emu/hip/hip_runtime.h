@@ -114,7 +114,8 @@ inline WaveSync &my_wave() { return cur_block()->waves[threadIdx.x / WAVE]; }
 inline void mark(const char *what) {
     cur_block()->waiting_in[threadIdx.x] = what;
     cur_block()->n_coll[threadIdx.x]++;
-    cur_block()->history[threadIdx.x].push_back(what);
+    static const bool trace = getenv("JSS_EMU_TRACE") != nullptr;   // full per-lane history: opt-in (slow)
+    if (trace) cur_block()->history[threadIdx.x].push_back(what);
 }
 
 inline void wave_sync() {
@@ -188,7 +189,8 @@ inline void run_block(Block &b, unsigned bx, dim3 grid, dim3 block) {
     while (b.live > 0) {
         if (++passes == 2000000ULL) {   // no kernel of the suite needs this many scheduler passes: lanes of a wave
                                         // are waiting in DIFFERENT collectives (divergent control flow around one)
-            fprintf(stderr, "emu: deadlock in block %u -- collective each unfinished lane waits in:\n", bx);
+            fprintf(stderr, "emu: deadlock in block %u -- collective each lane last entered (rerun with JSS_EMU_TRACE=1 for the "
+                            "first diverging collective per lane):\n", bx);
             for (int i = 0; i < b.nthreads; ++i)
                 fprintf(stderr, "  lane %3d: %-32s collectives entered %llu%s\n", i, b.waiting_in[i], b.n_coll[i],
                         b.finished[i] ? "  (finished)" : "");
