@@ -146,6 +146,27 @@ class BatchedJssEnv:
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
         self._is_reset = False
 
+    def assign_instances(self, env_indices, table_indices):
+        """Give envs ``env_indices`` the instances ``table_indices`` (indices into the ``instances`` this batch
+        was built with) and reset exactly those envs -- per-env instance resampling between episodes.  The batch
+        must have been built with an explicit or modular env -> instance map (more than one instance)."""
+        if self._table_of_env is None:
+            raise ValueError("this batch has a fixed env -> instance map (one shared instance, or one instance per env)")
+        env_indices = np.asarray(env_indices, dtype=np.int64).reshape(-1)
+        table_indices = np.asarray(table_indices, dtype=np.int32).reshape(-1)
+        if env_indices.shape != table_indices.shape:
+            raise ValueError("env_indices and table_indices must have the same length")
+        if env_indices.size and (env_indices.min() < 0 or env_indices.max() >= self.batch or
+                                 table_indices.min() < 0 or table_indices.max() >= self.n_tables):
+            raise ValueError("index out of range")
+        self.table_of_env_host[env_indices] = table_indices
+        self.jobs_per_env = self.packed.jobs[self.table_of_env_host]
+        self.machines_per_env = self.packed.machines[self.table_of_env_host]
+        self.backend.copy_into(self._table_of_env, self.table_of_env_host)
+        which = np.zeros(self.batch, dtype=np.uint8)
+        which[env_indices] = 1
+        return self.reset(which=which)
+
     def set_env_ids(self, ids):
         """Explicit global env ids (int64, one per env) keying the per-env RNG streams; used by
         BucketedJssEnv, whose buckets hold non-contiguous slices of the global batch."""

@@ -496,3 +496,40 @@ def case_persistent_kernel(backend, batch=41, n_steps=40):
     finally:
         lib.jss_set_option(_abi.OPT_CU_COUNT, 0)
         lib.jss_set_option(_abi.OPT_PERSIST, 0)
+
+
+def case_instance_resampling(backend):
+    """assign_instances(): envs switch instance (and shape) between episodes; untouched envs keep running."""
+    insts = [I.builtin_instance(n) for n in ("ta01", "ta11", "ta02")]
+    env = BatchedJssEnv(insts, batch=6, seed=8, env_id_base=40, _backend=backend)     # env i <- instance i % 3
+    orcs = [OracleEnv(insts[i % 3], strict=True) for i in range(6)]
+    env.reset()
+    for o in orcs:
+        o.reset()
+
+    def step_all(n):
+        for _ in range(n):
+            acts = env.backend.numpy(env.policy("random")).astype(np.int64)
+            env.step(acts)
+            for i, o in enumerate(orcs):
+                if acts[i] >= 0:
+                    o.step(int(acts[i]))
+
+    step_all(25)
+    env.assign_instances([1, 4], [2, 1])          # env 1: ta11 -> ta02 (20x15 -> 15x15), env 4: ta11 stays ta11 (fresh)
+    orcs[1] = OracleEnv(insts[2], strict=True)
+    orcs[4] = OracleEnv(insts[1], strict=True)
+    for i in (1, 4):
+        orcs[i].reset()
+        orcs[i].episode = 2                       # second reset of that env slot
+    step_all(25)
+    for i, o in enumerate(orcs):
+        h = env.host_state(i)
+        assert h["jobs"] == o.jobs and h["episode"] == o.episode
+        assert_matches_oracle(h, o, f"resampled env {i} ({o.instance.name})")
+    single = BatchedJssEnv(insts[0], batch=2, _backend=backend)
+    try:
+        single.assign_instances([0], [0])
+        raise AssertionError("a shared-instance batch has no env -> instance map to change")
+    except ValueError:
+        pass

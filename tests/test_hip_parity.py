@@ -233,3 +233,7 @@ def test_headline_batch_65536(hip):
         r = o.rollout("random", seed, 5_000_000_000 + i, iters, episode=1)
         P.assert_matches_oracle(env.host_state(i), o, f"headline env {i}")
         assert cnt[i, 0] == r["steps"] and cnt[i, 1] == r["episodes"] and cnt[i, 2] == r["makespan_sum"]
+
+
+def test_instance_resampling(hip):
+    P.case_instance_resampling(hip)

@@ -104,3 +104,7 @@ def test_vector_facade(emu):
 
 def test_persistent_kernel(emu):
     P.case_persistent_kernel(emu, batch=41, n_steps=24)
+
+
+def test_instance_resampling(emu):
+    P.case_instance_resampling(emu)
