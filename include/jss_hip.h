@@ -1,6 +1,8 @@
 /*
  * include/jss_hip.h -- C ABI of libjss_hip.so, the MI355X (gfx950) batched
- * Job-Shop-Scheduling simulator.
+ * Job-Shop-Scheduling simulator, and of libjss_cpu.so, its host-core twin
+ * (identical symbols and layouts; pointers are host pointers there and `stream`
+ * is ignored).
  *
  * The reference (prosysscience/JSSEnv v1.1.0) is pure Python with no FFI; the
  * boundary this library replaces is the method surface of
@@ -21,6 +23,9 @@
  *   jss_rollout  <- DispatchingRule.run_episode's loop    dispatching.py:55-75
  *                   (policy + step fused, n iterations per launch, optional
  *                    auto-restart of finished episodes)
+ *   jss_rollout_steps <- the same loop issued as n_sub independent sub-batches on
+ *                   n_sub streams, so that consecutive steps of different sub-batches
+ *                   overlap on the device (env instances are independent)
  *
  * Conventions
  *   - plain pointers and sizes only; every pointer in JssDesc/JssState/JssOut is a
@@ -35,14 +40,18 @@
  *
  * Data layout (all row-major, batch outermost)
  *   op table      int32 [n_tables][jmax][mmax]   machine << 16 | duration, 0 = padding
+ *   work table    int32 [n_tables][jmax][mmax]   rem[j][k] = sum of the durations of ops k..M-1 of job j
+ *                                                (MWR / LWR / CR read it; rem[j][0] = job length)
+ *   instance rec  int32 [n_tables][JSS_NI]       JSS_I_*: J, M, the observation's normalisers and their
+ *                                                float32 reciprocals
  *   job state     int32 [B][jmax][JSS_NF]        one 32-byte record per job (JSS_F_* words below):
  *                                                a lane moves its job with two dwordx4 accesses
  *   env header    int32 [B][4]                   JSS_H_*: clock, episode, step, status
  *   machine state int32 [B][mmax]                time_until_available_machine
- *   action_mask   uint8 [B][jmax + 1]            legal_actions (output; rebuilt from the flag words
- *                                                every call); NOPE flag at index J(env)
+ *   action_mask   uint8 [B][jmax + 1]            legal_actions (output; rebuilt from the flag bits
+ *                                                every call); NOPE flag at index J(env), zeros after it
  *   solution      int32 [B][jmax][mmax]          start time of op k of job j, -1 = unscheduled
- *   real_obs      float [B][jmax][7]             the reference's (J,7) observation
+ *   real_obs      float [B][jmax][7]             the reference's (J,7) observation, zero rows after J(env)
  */
 #ifndef JSS_HIP_H
 #define JSS_HIP_H
@@ -53,13 +62,13 @@
 extern "C" {
 #endif
 
-#define JSS_ABI_VERSION 4
+#define JSS_ABI_VERSION 5
 
 #define JSS_MAX_JOBS 128
 #define JSS_MAX_MACHINES 64
 
 /* words of the per-job record */
-#define JSS_F_TODO 0      /* todo_time_step_job                                   */
+#define JSS_F_TODO 0      /* bits 0-7 todo_time_step_job, bit 8 legal_actions[j], bit 9 action_illegal_no_op[j] */
 #define JSS_F_CUR 1       /* current op, machine << 16 | duration; -1 = job finished.
                              needed_machine_jobs == cur >> 16 (arithmetic shift)   */
 #define JSS_F_LEFT 2      /* time_until_finish_current_op_jobs                    */
@@ -68,11 +77,13 @@ extern "C" {
 #define JSS_F_IDLE_LAST 5 /* idle_time_jobs_last_op                               */
 #define JSS_F_F4 6        /* numerator of observation feature 4 (written only when an
                              op finishes, jss_env.py:569-586); JSS_F4_ONE = "1.0"  */
-#define JSS_F_FLAGS 7     /* bit 0 legal_actions[j], bit 1 action_illegal_no_op[j]    */
+#define JSS_F_NEXT 7      /* the op after the current one (op table entry [j][todo + 1]), -1 = none: kept next
+                             to the state so that a step touches the op table only when a job moves on */
 #define JSS_NF 8
 #define JSS_F4_ONE (-1)
-#define JSS_FLAG_LEGAL 1
-#define JSS_FLAG_BLOCKED 2
+#define JSS_TODO_MASK 255
+#define JSS_FLAG_LEGAL 256
+#define JSS_FLAG_BLOCKED 512
 
 /* words of the per-env header */
 #define JSS_H_CLOCK 0    /* current_time_step                                     */
@@ -81,12 +92,25 @@ extern "C" {
 #define JSS_H_STATUS 3   /* bits 0-7 JSS_ERR_*, bit 8 legal_actions[J] (NOPE)     */
 #define JSS_STATUS_NOOP 256
 
+/* words of the per-instance record */
+#define JSS_I_JOBS 0
+#define JSS_I_MACHINES 1
+#define JSS_I_MAX_TIME_OP 2    /* jss_env.py:86 */
+#define JSS_I_MAX_TIME_JOBS 3  /* jss_env.py:89 */
+#define JSS_I_SUM_OP 4         /* jss_env.py:88 */
+#define JSS_I_RCP_MAX_TIME_OP 5   /* float32 bits of 1 / max_time_op  (correctly rounded) */
+#define JSS_I_RCP_MAX_TIME_JOBS 6 /* float32 bits of 1 / max_time_jobs */
+#define JSS_I_RCP_SUM_OP 7        /* float32 bits of 1 / sum_op */
+#define JSS_I_RCP_MACHINES 8      /* float32 bits of 1 / M */
+#define JSS_NI 12              /* record stride in ints (48 bytes: three dwordx4) */
+
 /* per-env error bits (low byte of the header's status word, sticky until reset) */
 #define JSS_ERR_ILLEGAL_ACTION 1 /* job action outside the mask: ignored (reference: silent corruption) */
 #define JSS_ERR_NOPE_IDLE 2      /* NOPE/advance with no busy machine (reference: IndexError, jss_env.py:517) */
 #define JSS_ERR_BAD_ACTION 4     /* action < -1 or > J: ignored (reference: IndexError) */
 
-#define JSS_ACTION_SKIP (-1) /* batched step: leave this env untouched */
+#define JSS_ACTION_SKIP (-1) /* batched step: this env is not stepped; its state, reward, done and makespan
+                                are left as they were (observation and mask are rewritten unchanged) */
 
 /* policies */
 #define JSS_POLICY_RANDOM 0
@@ -106,23 +130,27 @@ extern "C" {
 #define JSS_E_NULL (-1)
 #define JSS_E_SHAPE (-2)
 #define JSS_E_KIND (-3)
+#define JSS_E_LDS (-4) /* the batch shape needs more LDS per workgroup than the device has */
+
+/* JssDesc.kernel: JSS_KERNEL_AUTO packs 64/G envs per wavefront when every env of the batch fits a 16- or
+ * 32-lane group (jmax, mmax <= 32) and uses one wavefront per env otherwise; JSS_KERNEL_WAVE forces one
+ * wavefront per env (A/B runs, tests).  Per call, not per process.  The CPU twin ignores it. */
+#define JSS_KERNEL_AUTO 0
+#define JSS_KERNEL_WAVE 1
 
 typedef struct JssDesc {
     int32_t batch;               /* B: envs in this shard                                   */
     int32_t jmax, mmax;          /* padded job / machine extents of every per-env row       */
     int32_t n_tables;            /* distinct instances                                      */
     const int32_t *ops;          /* [n_tables][jmax][mmax]                                  */
-    const int32_t *jobs;         /* [n_tables] J                                            */
-    const int32_t *machines;     /* [n_tables] M                                            */
-    const int32_t *max_time_op;  /* [n_tables] jss_env.py:86                                */
-    const int32_t *max_time_jobs;/* [n_tables] jss_env.py:89                                */
-    const int32_t *sum_op;       /* [n_tables] jss_env.py:88                                */
+    const int32_t *rem;          /* [n_tables][jmax][mmax] remaining-work table             */
+    const int32_t *inst;         /* [n_tables][JSS_NI] instance records                     */
     const int32_t *table_of_env; /* [B] instance of env i; NULL: 0 if n_tables==1 else i    */
-    int64_t env_id_base;         /* global id of env 0 (keys the RNG stream under sharding) */
     const int64_t *env_ids;      /* [B] explicit global ids (shape-bucketed batches); NULL: env_id_base + i */
-    const uint16_t *ops16;       /* optional compact copy of `ops`: machine << 10 | duration, legal when every
-                                    duration <= 1023.  When set, kernels stage the LDS table from it (half the
-                                    bytes: matters for batches with one instance per env); `ops` stays required */
+    int64_t env_id_base;         /* global id of env 0 (keys the RNG stream under sharding) */
+    int32_t kernel;              /* JSS_KERNEL_*                                            */
+    int32_t threads;             /* libjss_cpu.so: OpenMP threads for this call (0 = runtime default);
+                                    libjss_hip.so ignores it                                */
 } JssDesc;
 
 typedef struct JssState {
@@ -136,7 +164,7 @@ typedef struct JssState {
 
 typedef struct JssOut {
     float *real_obs;      /* [B][jmax][7]; rows J..jmax-1 are written as zeros            */
-    uint8_t *action_mask; /* [B][jmax+1]                                                  */
+    uint8_t *action_mask; /* [B][jmax+1]; bytes J+1..jmax are written as zeros            */
     float *reward;        /* [B] reward of the last step (jss_env.py:483-493)             */
     uint8_t *done;        /* [B] nb_legal_actions == 0 (jss_env.py:639-653)               */
     int32_t *makespan;    /* [B] clock at the last done transition (last_time_step, :650) */
@@ -144,30 +172,8 @@ typedef struct JssOut {
 
 int jss_abi_version(void);
 const char *jss_error_string(int code);
-
-/* process-wide options.  JSS_OPT_KERNEL: JSS_KERNEL_AUTO packs 64/G envs per wavefront when every
- * env of the batch fits a 16- or 32-lane group (jmax, mmax <= 32) and uses one wavefront per env
- * otherwise; JSS_KERNEL_WAVE forces one wavefront per env (A/B runs, tests). */
-#define JSS_OPT_KERNEL 0
-#define JSS_KERNEL_AUTO 0
-#define JSS_KERNEL_WAVE 1
-/* JSS_OPT_ABLATE (profiling aid, results become WRONG): bit mask of phases the kernels skip, used by
- * tools/gpu_ablate.sh to attribute kernel time.  0 = normal operation. */
-#define JSS_OPT_ABLATE 1
-#define JSS_ABLATE_CHECK_NO_OP 1
-#define JSS_ABLATE_PRIORITIZE 2
-#define JSS_ABLATE_OBS 4
-#define JSS_ABLATE_SELECT 8
-#define JSS_ABLATE_ADVANCE 16
-/* JSS_OPT_PERSIST: k > 0 routes shared-instance batches in jss_step / jss_rollout(n_iter == 1) to a persistent
- * packed kernel with k waves per SIMD that loop over env sets and prefetch the next set's state (default 0 = one
- * env set per wave: on MI355X the persistent form measured 17 % slower, the step is bound by per-wave latency
- * and wants the 8 waves per SIMD the one-shot kernel gets).  JSS_OPT_CU_COUNT overrides the detected compute-unit count (tests). */
-#define JSS_OPT_PERSIST 3
-#define JSS_OPT_CU_COUNT 4
-/* JSS_OPT_LDS_PAD (profiling aid): extra dynamic LDS bytes per workgroup, to cap occupancy in experiments. */
-#define JSS_OPT_LDS_PAD 2
-int jss_set_option(int option, int value);
+/* "hip:gfx950" for libjss_hip.so, "cpu:openmp" / "cpu:serial" for libjss_cpu.so */
+const char *jss_backend(void);
 
 /* reset every env (which == NULL) or the envs with which[i] != 0 */
 int jss_reset(const JssDesc *desc, const JssState *state, const JssOut *out, const uint8_t *which, void *stream);
@@ -187,6 +193,27 @@ int jss_policy(const JssDesc *desc, const JssState *state, int kind, uint64_t se
 /* n_iter x (policy + step) per env inside one launch, state held in registers */
 int jss_rollout(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
                 uint32_t explore_q16, int32_t n_iter, int32_t flags, void *stream);
+
+/* n_steps x jss_rollout(n_iter = 1) over the whole batch, issued as n_sub contiguous sub-batches (boundaries at
+ * multiples of 64 envs): step s of sub-batch i is launched on streams[i] and depends only on step s - 1 of the same
+ * sub-batch, so the tail of one sub-batch's launch overlaps the head of another's.  Same results as n_steps calls
+ * of jss_rollout.  The caller orders streams[] against its own stream (fork before, join after).  1 <= n_sub <= 16. */
+int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
+                      uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub, void *const *streams);
+
+#ifdef JSS_PROFILING
+/* Instrumented builds only (tools/build_instrumented.py compiles with -DJSS_PROFILING; the shipped library does
+ * not export this).  JSS_PROF_ABLATE: bit mask of phases the kernels skip -- results become WRONG -- used to
+ * attribute kernel time; JSS_PROF_LDS_PAD: extra dynamic LDS bytes per workgroup, to cap occupancy. */
+#define JSS_PROF_ABLATE 1
+#define JSS_PROF_LDS_PAD 2
+#define JSS_ABLATE_CHECK_NO_OP 1
+#define JSS_ABLATE_PRIORITIZE 2
+#define JSS_ABLATE_OBS 4
+#define JSS_ABLATE_SELECT 8
+#define JSS_ABLATE_ADVANCE 16
+int jss_profiling_set(int option, int value);
+#endif
 
 #ifdef __cplusplus
 }

@@ -1,40 +1,41 @@
 """ctypes mirror of include/jss_hip.h (structs, constants, prototypes).
 
 Pure declarations: no torch, no device access.  ``bind(lib)`` attaches the
-prototypes to a loaded ``libjss_hip.so`` and fails loudly if a symbol the header
-declares is missing.
+prototypes to a loaded ``libjss_hip.so`` (or its host-core twin ``libjss_cpu.so``:
+identical symbols) and fails loudly if a symbol the header declares is missing.
 """
 from __future__ import annotations
 
 import ctypes as C
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_JOBS, MAX_MACHINES = 128, 64
-F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_FLAGS, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
-FLAG_LEGAL, FLAG_BLOCKED = 1, 2
+F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_NEXT, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
+TODO_MASK, FLAG_LEGAL, FLAG_BLOCKED = 255, 256, 512
 H_CLOCK, H_EPISODE, H_STEP, H_STATUS = 0, 1, 2, 3
 STATUS_NOOP = 256
 F4_ONE = -1
+I_JOBS, I_MACHINES, I_MAX_TIME_OP, I_MAX_TIME_JOBS, I_SUM_OP = 0, 1, 2, 3, 4
+I_RCP_MAX_TIME_OP, I_RCP_MAX_TIME_JOBS, I_RCP_SUM_OP, I_RCP_MACHINES, NI = 5, 6, 7, 8, 12
 ERR_ILLEGAL_ACTION, ERR_NOPE_IDLE, ERR_BAD_ACTION = 1, 2, 4
 ACTION_SKIP = -1
 POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6, "CR": 7}
 ROLLOUT_AUTORESET = 1
-OPT_KERNEL, KERNEL_AUTO, KERNEL_WAVE = 0, 0, 1
-OPT_ABLATE = 1
-OPT_LDS_PAD = 2
-OPT_PERSIST = 3
-OPT_CU_COUNT = 4
+KERNEL = {"auto": 0, "wave": 1}
+E_NULL, E_SHAPE, E_KIND, E_LDS = -1, -2, -3, -4
+MAX_SUB_BATCHES = 16
 
-SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_set_option", "jss_reset", "jss_step", "jss_advance", "jss_policy", "jss_rollout")
+SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_backend", "jss_reset", "jss_step", "jss_advance", "jss_policy",
+           "jss_rollout", "jss_rollout_steps")
 
 _p = C.c_void_p
 
 
 class JssDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("jmax", C.c_int32), ("mmax", C.c_int32), ("n_tables", C.c_int32),
-                ("ops", _p), ("jobs", _p), ("machines", _p), ("max_time_op", _p), ("max_time_jobs", _p),
-                ("sum_op", _p), ("table_of_env", _p), ("env_id_base", C.c_int64), ("env_ids", _p), ("ops16", _p)]
+                ("ops", _p), ("rem", _p), ("inst", _p), ("table_of_env", _p), ("env_ids", _p),
+                ("env_id_base", C.c_int64), ("kernel", C.c_int32), ("threads", C.c_int32)]
 
 
 class JssState(C.Structure):
@@ -45,28 +46,33 @@ class JssOut(C.Structure):
     _fields_ = [("real_obs", _p), ("action_mask", _p), ("reward", _p), ("done", _p), ("makespan", _p)]
 
 
-def library_path() -> str:
-    """In-tree libjss_hip.so; JSSENV_AMD_LIB points development builds at another build of the same ABI."""
-    return os.environ.get("JSSENV_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libjss_hip.so")
+def library_path(name: str = "libjss_hip.so") -> str:
+    """In-tree library; JSSENV_AMD_LIB points development builds at another build of the same ABI."""
+    if name == "libjss_hip.so" and os.environ.get("JSSENV_AMD_LIB"):
+        return os.environ["JSSENV_AMD_LIB"]
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
 
 
 def bind(lib):
     """Attach prototypes; raises AttributeError naming the first missing symbol."""
     for name in SYMBOLS:
         if not hasattr(lib, name):
-            raise AttributeError(f"libjss_hip.so does not export {name}")
+            raise AttributeError(f"library does not export {name}")
     D, S, O = C.POINTER(JssDesc), C.POINTER(JssState), C.POINTER(JssOut)
     lib.jss_abi_version.restype, lib.jss_abi_version.argtypes = C.c_int, []
     lib.jss_error_string.restype, lib.jss_error_string.argtypes = C.c_char_p, [C.c_int]
-    lib.jss_set_option.restype, lib.jss_set_option.argtypes = C.c_int, [C.c_int, C.c_int]
+    lib.jss_backend.restype, lib.jss_backend.argtypes = C.c_char_p, []
     lib.jss_reset.restype, lib.jss_reset.argtypes = C.c_int, [D, S, O, _p, _p]
     lib.jss_step.restype, lib.jss_step.argtypes = C.c_int, [D, S, _p, O, _p]
     lib.jss_advance.restype, lib.jss_advance.argtypes = C.c_int, [D, S, _p, _p, O, _p]
     lib.jss_policy.restype, lib.jss_policy.argtypes = C.c_int, [D, S, C.c_int, C.c_uint64, C.c_uint32, _p, _p]
     lib.jss_rollout.restype = C.c_int
     lib.jss_rollout.argtypes = [D, S, O, C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, _p]
+    lib.jss_rollout_steps.restype = C.c_int
+    lib.jss_rollout_steps.argtypes = [D, S, O, C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.POINTER(_p)]
     if lib.jss_abi_version() != ABI_VERSION:
-        raise RuntimeError(f"libjss_hip.so ABI {lib.jss_abi_version()} != expected {ABI_VERSION}")
+        raise RuntimeError(f"library ABI {lib.jss_abi_version()} != expected {ABI_VERSION}")
     return lib
 
 

@@ -38,6 +38,9 @@ def shape_class(jobs: int, machines: int) -> int:
 class BucketedJssEnv:
     def __init__(self, instances: Sequence, batch: Optional[int] = None, device=None, seed: int = 0,
                  env_id_base: int = 0, concurrent: bool = True, _backend=None):
+        from .env import make_backend
+        if _backend is None:
+            _backend = make_backend(device)     # one backend (library handle, device) shared by the buckets
         insts = [resolve_instance(i) for i in instances]
         n = len(insts)
         self.batch = B = int(batch) if batch is not None else n
@@ -67,10 +70,11 @@ class BucketedJssEnv:
         # one side stream per bucket: the buckets are independent env sets, so their launches may overlap.
         # Every call forks from / joins back to the caller's current stream, so callers see ordinary
         # stream-ordered semantics (and a graph capture of the caller's stream records the fork/join too).
-        self._torch = getattr(self._each()[0][1].backend, "torch", None) if concurrent else None
+        self._torch = getattr(_backend, "torch", None) if concurrent else None
         self._streams = None
+        self._device = getattr(_backend, "device", None)
         if self._torch is not None and len(self._each()) > 1:
-            dev = self._each()[0][1].backend.device
+            dev = self._device
             self._streams = {k: self._torch.cuda.Stream(device=dev) for k, _ in self._each()}
             # events are allocated once and re-recorded every call (no allocation/destruction while a
             # hipGraph capture of the caller's stream is in progress)
@@ -93,7 +97,7 @@ class BucketedJssEnv:
         if self._streams is None:
             return {k: fn(k, b) for k, b in self._each()}
         t = self._torch
-        main = t.cuda.current_stream()
+        main = t.cuda.current_stream(self._device)      # the env's device, which need not be the current one
         self._fork_event.record(main)
         out = {}
         for k, b in self._each():
@@ -122,6 +126,7 @@ class BucketedJssEnv:
         self._fan_out(run)
 
     def policy(self, kind="random", seed=None, explore=0.0):
+        """Per-bucket action buffers (each bucket's own preallocated tensor: nothing is allocated on the side streams)."""
         return self._fan_out(lambda k, b: b.policy(kind, seed=seed, explore=explore))
 
     def step(self, actions_per_bucket):

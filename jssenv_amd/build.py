@@ -1,4 +1,8 @@
-"""Builds jssenv_amd/libjss_hip.so (hipcc, gfx950 only)."""
+"""Builds the two native libraries of the package, in-tree:
+
+* ``libjss_hip.so``  -- the MI355X kernels + C ABI (hipcc, gfx950 only);
+* ``libjss_cpu.so``  -- the host-core twin with the identical C ABI (g++, OpenMP).
+"""
 import os
 import shutil
 import subprocess
@@ -8,6 +12,10 @@ _ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "jss_kernels.hip")
 OUT = os.path.join(_HERE, "libjss_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(_ROOT, "include")]
+CPU_SRC = os.path.join(_HERE, "csrc", "jss_cpu.cpp")
+CPU_OUT = os.path.join(_HERE, "libjss_cpu.so")
+CPU_FLAGS = ["-O3", "-std=c++17", "-fopenmp", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(_ROOT, "include")]
+_HEADER = os.path.join(_ROOT, "include", "jss_hip.h")
 
 
 def hipcc() -> str:
@@ -17,10 +25,26 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build_extension(force: bool = False, extra=()) -> str:
+def _fresh(out, deps):
+    return os.path.isfile(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)
+
+
+def build_extension(force: bool = False, extra=(), out: str = OUT) -> str:
     csrc = os.path.dirname(SRC)
-    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(_ROOT, "include", "jss_hip.h")]
-    if not force and os.path.isfile(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
-        return OUT
-    subprocess.check_call([hipcc(), *FLAGS, *extra, SRC, "-o", OUT])
-    return OUT
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))] + [_HEADER]
+    if not force and _fresh(out, deps):
+        return out
+    subprocess.check_call([hipcc(), *FLAGS, *extra, SRC, "-o", out])
+    return out
+
+
+def build_cpu_twin(force: bool = False) -> str:
+    if not force and _fresh(CPU_OUT, [CPU_SRC, _HEADER]):
+        return CPU_OUT
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("g++ not found")
+    tmp = CPU_OUT + f".tmp{os.getpid()}"
+    subprocess.check_call([cxx, *CPU_FLAGS, CPU_SRC, "-o", tmp])
+    os.replace(tmp, CPU_OUT)     # atomic: several processes (ranks, xdist workers) may build at once
+    return CPU_OUT

@@ -1,20 +1,23 @@
-// jssenv_amd/csrc/jss_kernels.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI of the
-// batched Job-Shop-Scheduling simulator.  Interface and layout: include/jss_hip.h.
+// jssenv_amd/csrc/jss_common.hpp -- parameters, wave helpers, counter RNG shared by the two
+// kernel flavours of the MI355X (gfx950 / CDNA4) batched Job-Shop-Scheduling simulator.
+// Interface and layout: include/jss_hip.h.
 //
 // Execution model
-//   * one 64-lane wavefront simulates one env; job j sits on lane j%64 (slot j/64,
-//     JPL = 1 or 2 slots), machine m on lane m.  256-thread workgroups = 4 envs in
-//     flight per workgroup, waves grid-stride over the batch.
-//   * the env's whole state lives in registers for the duration of the call:
-//     7 int32 per job (VGPRs), the machine clocks (one VGPR, lane = machine) and the
-//     legal / blocked job sets as wave-uniform 64-bit masks (SGPR pairs), so
-//     nb_legal_actions is one s_bcnt1 and "any legal" one s_cmp.
-//   * the op table (machine << 16 | duration) is staged in LDS: once per workgroup
-//     when the batch shares one instance, once per env otherwise; the look-ahead
-//     walk of _check_no_op is a per-lane chain of ds_read_b32.
-//   * cross-lane work: __ballot for every "for job in range(J)" predicate of the
-//     reference, a butterfly min for the next event time, readlane for the (<= 4)
-//     legal jobs the order-dependent pass of _check_no_op walks through.
+//   * wave flavour (jss_wave_env.hpp): one 64-lane wavefront simulates one env; job j sits on
+//     lane j%64 (slot j/64, JPL = 1 or 2 slots), machine m on lane m.  Packed flavour
+//     (jss_packed_env.hpp): 64/G envs per wavefront, G = 16 or 32 lanes per env.
+//   * the env's whole state lives in registers for the duration of the call: 8 int32 per job
+//     (the seventh-plus-one being the job's NEXT op, so that a step touches the op table only
+//     when a job moves on to a new op or a look-ahead walk goes further than two ops).
+//   * the op table (machine << 16 | duration) of a batch that shares ONE instance is staged in
+//     LDS once per workgroup (kTabLds); batches with one instance per env or an env -> instance
+//     map read the few entries they need straight from global memory (kTabGlobal): staging a
+//     2-8 KB table per env per step was 1.4-1.8x the algorithmic traffic (profiles/README.md).
+//   * addresses are wave-uniform 64-bit bases (SGPR pairs) + 32-bit lane offsets, so every
+//     access is a `global_load/store ... v_off, s[base:base+1]`.
+//   * cross-lane work: __ballot for every "for job in range(J)" predicate of the reference,
+//     DPP row reductions for the next event time, readlane / ds_bpermute for the (<= 4) legal
+//     jobs the order-dependent pass of _check_no_op walks through.
 //   * no MFMA: the path is integer indexing, there is no dense contraction.
 //
 // Semantics follow the reference JSSEnv/envs/jss_env.py (cited per function) in the
@@ -40,6 +43,8 @@ constexpr int kDurMask = 0xffff;
 // kRollout1 = kRollout with n_iter == 1 compiled loop-free (fewer live registers: the benchmarked
 // one-launch-per-env-step path)
 enum Mode { kReset = 0, kStep = 1, kAdvance = 2, kPolicy = 3, kRollout = 4, kRollout1 = 5 };
+// where the op table lives: LDS (one instance shared by the batch) or global memory
+enum Tab { kTabLds = 0, kTabGlobal = 1 };
 
 struct Params {
     JssDesc d;
@@ -54,35 +59,44 @@ struct Params {
     int32_t kind;
     int32_t n_iter;
     int32_t flags;
-    int32_t stride;       // LDS row stride of the op table (= mmax: rows are copied verbatim)
-    int32_t region_ints;  // LDS ints per staged table
-    int32_t shared_table; // 1: one table for the whole batch, staged once per workgroup
-    int32_t ablate;          // JSS_OPT_ABLATE mask (profiling aid)
-    int32_t obs_off_ints;    // packed kernel: LDS offset (ints, multiple of 4) of the observation images
-    int32_t obs_wave_floats; // packed kernel: floats per wave image (multiple of 4)
+    int32_t region_ints;     // ints of one op table (jmax * mmax)
+    int32_t table_lds_ints;  // LDS ints reserved for the shared op table (0 with kTabGlobal), multiple of 4
+    int32_t obs_wave_floats; // floats of one wave's observation image in LDS (multiple of 4)
     int32_t mv_off_ints;     // packed kernel: LDS offset (ints) of the per-lane max_horizon_machine table
+    int32_t ablate;          // JSS_PROFILING builds: JSS_PROF_ABLATE mask; 0 otherwise
 };
+
+#ifdef JSS_PROFILING
+#define JSS_ABLATED(p, bit) (((p).ablate & (bit)) != 0)
+#else
+#define JSS_ABLATED(p, bit) false
+#define JSS_ABLATE_CHECK_NO_OP 1
+#define JSS_ABLATE_PRIORITIZE 2
+#define JSS_ABLATE_OBS 4
+#define JSS_ABLATE_SELECT 8
+#define JSS_ABLATE_ADVANCE 16
+#endif
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-// a / b for small non-negative integers as float32: reciprocal (v_rcp_f32 + one Newton step) and
-// one residual correction of the quotient -- the core of the IEEE division sequence without its
-// range scaling (operands here are far from denormal/overflow).  |error| <= 1 ulp, i.e. < 1.2e-7
-// on values in [0, 1]: inside the 1e-6 budget of the float observation.
-__device__ __forceinline__ float refined_rcp(float b) {
-    float r = __builtin_amdgcn_rcpf(b);
-    return __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
-}
+// a / b for small non-negative integers as float32, given rb = fl(1 / b) (correctly rounded, from the
+// instance record): quotient estimate and one residual correction -- the core of the IEEE division
+// sequence without its range scaling (operands here are far from denormal/overflow).  |error| <= 1 ulp,
+// i.e. < 1.2e-7 on values in [0, 1]: inside the 1e-6 budget of the float observation.
 __device__ __forceinline__ float div_by(float a, float b, float rb) {
     const float q = a * rb;
     return __builtin_fmaf(__builtin_fmaf(-q, b, a), rb, q);
 }
-
+__device__ __forceinline__ float as_float(int bits) {
+    union { int i; float f; } u;
+    u.i = bits;
+    return u.f;
+}
 
 #define JSS_DPP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xF, 0xF, false)
 
-// min / max over the 16 lanes of a DPP row, result in every lane of the row
+// min / max / or over the 16 lanes of a DPP row, result in every lane of the row
 __device__ __forceinline__ int row_min(int v) {
     v = imin(v, JSS_DPP(v, 0xB1));   // quad_perm [1,0,3,2]   lane ^ 1
     v = imin(v, JSS_DPP(v, 0x4E));   // quad_perm [2,3,0,1]   lane ^ 2
@@ -97,7 +111,6 @@ __device__ __forceinline__ int row_max(int v) {
     v = imax(v, JSS_DPP(v, 0x140));
     return v;
 }
-
 __device__ __forceinline__ int row_or(int v) {
     v |= JSS_DPP(v, 0xB1);
     v |= JSS_DPP(v, 0x4E);
@@ -120,33 +133,14 @@ __device__ __forceinline__ int wave_max(int v) {
     return imax(imax(a, b), imax(c, d));
 }
 
-// Op table -> LDS as int32 (machine << 16 | duration), from the int32 table or, when the batch
-// provides it, from the 16-bit copy (machine << 10 | duration): half the HBM bytes per staged table.
-__device__ __forceinline__ void stage_table(int32_t *dst, const int32_t *ops, const uint16_t *ops16, size_t first,
-                                            int n, int start, int step) {
-    if (ops16) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(ops16 + first);  // `first` is even: tables are jmax*mmax
-        if ((first & 1) == 0) {                                                   // entries with jmax*mmax even or table 0
-            const int pairs = n >> 1;
-            for (int i = start; i < pairs; i += step) {
-                const uint32_t w = src[i];
-                const uint32_t a = w & 0xFFFFu, b = w >> 16;
-                dst[2 * i] = (int32_t)(((a >> 10) << 16) | (a & 1023u));
-                dst[2 * i + 1] = (int32_t)(((b >> 10) << 16) | (b & 1023u));
-            }
-            if ((n & 1) && start == 0) {
-                const uint32_t a = ops16[first + n - 1];
-                dst[n - 1] = (int32_t)(((a >> 10) << 16) | (a & 1023u));
-            }
-        } else {
-            for (int i = start; i < n; i += step) {
-                const uint32_t a = ops16[first + i];
-                dst[i] = (int32_t)(((a >> 10) << 16) | (a & 1023u));
-            }
-        }
+// the batch's one shared op table -> LDS, whole workgroup (dwordx4 when the table is 16-byte sized)
+__device__ __forceinline__ void stage_shared_table(int32_t *dst, const int32_t *src, int n, int tid) {
+    if ((n & 3) == 0) {
+        const int4 *s4 = reinterpret_cast<const int4 *>(src);
+        int4 *d4 = reinterpret_cast<int4 *>(dst);
+        for (int i = tid; i < (n >> 2); i += kBlock) d4[i] = s4[i];
     } else {
-        const int32_t *src = ops + first;
-        for (int i = start; i < n; i += step) dst[i] = src[i];
+        for (int i = tid; i < n; i += kBlock) dst[i] = src[i];
     }
 }
 

@@ -1,0 +1,577 @@
+// jssenv_amd/csrc/jss_cpu.cpp -- libjss_cpu.so: the host-core twin of libjss_hip.so.
+//
+// Same C ABI (include/jss_hip.h: identical symbols, structs and memory layouts; every pointer is a host
+// pointer, `stream` is ignored, calls are synchronous), written from the kernels' queue-free restatement of
+// the simulator: scalar C++ working in place on the 32-byte job records, OpenMP over envs.  It exists for
+// BASELINE config 1 ("runs without a GPU"), for `device="cpu"` users of the package, and as the multi-core
+// CPU baseline bench.py times next to the GPU (cpu_baseline kind "twin").  It shares no code with oracle/
+// (the literal restatement of the reference used as the checker) -- tests/ compares the two.
+//
+// Reference semantics (JSSEnv/envs/jss_env.py, cited per function) in the queue-free form: the reference's
+// sorted event list is {t + tm[m] : tm[m] > 0}, its M x J illegal_actions matrix is blocked[j] && need[j] == m,
+// and nb_legal_actions / machine_legal / nb_machine_legal are functions of the legal flags.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "jss_hip.h"
+
+namespace {
+
+constexpr int kBig = 0x3fffffff;
+constexpr int kDurMask = 0xffff;
+constexpr uint64_t kExploreSeedXor = 0x5851F42D4C957F2DULL;
+
+struct Call {   // one ABI call
+    JssDesc d;
+    JssState s;
+    JssOut o;
+    const int32_t *actions = nullptr;
+    int32_t *actions_out = nullptr;
+    const uint8_t *which = nullptr;
+    int32_t *hole = nullptr;
+    uint64_t seed = 0;
+    uint32_t explore_q16 = 0;
+    int kind = 0;
+    int n_iter = 0;
+    int flags = 0;
+};
+
+// One env: pointers into the batch tensors + its instance.
+struct Env {
+    int J, M, max_time_op;
+    const int32_t *inst;        // JSS_I_* record
+    const int32_t *ops, *rem;   // [jmax][mmax] tables of my instance (rem may be null)
+    int stride;
+    int32_t *hdr;               // [4]
+    int32_t *job;               // [jmax][JSS_NF]
+    int32_t *tm;                // [mmax]
+    int32_t *sol;               // [jmax][mmax]
+
+    int32_t &w(int j, int f) const { return job[j * JSS_NF + f]; }
+    int todo(int j) const { return w(j, JSS_F_TODO) & JSS_TODO_MASK; }
+    bool legal(int j) const { return w(j, JSS_F_TODO) & JSS_FLAG_LEGAL; }
+    bool blocked(int j) const { return w(j, JSS_F_TODO) & JSS_FLAG_BLOCKED; }
+    void set_legal(int j, bool v) const { w(j, JSS_F_TODO) = (w(j, JSS_F_TODO) & ~JSS_FLAG_LEGAL) | (v ? JSS_FLAG_LEGAL : 0); }
+    void set_blocked(int j, bool v) const { w(j, JSS_F_TODO) = (w(j, JSS_F_TODO) & ~JSS_FLAG_BLOCKED) | (v ? JSS_FLAG_BLOCKED : 0); }
+    int &t() const { return hdr[JSS_H_CLOCK]; }
+    int noop() const { return (hdr[JSS_H_STATUS] & JSS_STATUS_NOOP) ? 1 : 0; }
+    void set_noop(int v) const { hdr[JSS_H_STATUS] = (hdr[JSS_H_STATUS] & ~JSS_STATUS_NOOP) | (v ? JSS_STATUS_NOOP : 0); }
+    void flag(int err) const { hdr[JSS_H_STATUS] |= err; }
+};
+
+Env env_of(const Call &c, int b) {
+    const JssDesc &d = c.d;
+    const int tid = d.table_of_env ? d.table_of_env[b] : (d.n_tables == 1 ? 0 : b);
+    const size_t region = (size_t)d.jmax * d.mmax;
+    Env e;
+    e.inst = d.inst + (size_t)tid * JSS_NI;
+    e.J = e.inst[JSS_I_JOBS];
+    e.M = e.inst[JSS_I_MACHINES];
+    e.max_time_op = e.inst[JSS_I_MAX_TIME_OP];
+    e.ops = d.ops + tid * region;
+    e.rem = d.rem ? d.rem + tid * region : nullptr;
+    e.stride = d.mmax;
+    e.hdr = c.s.env + (size_t)b * 4;
+    e.job = c.s.job + (size_t)b * d.jmax * JSS_NF;
+    e.tm = c.s.machine + (size_t)b * d.mmax;
+    e.sol = c.s.solution + b * region;
+    return e;
+}
+
+int n_legal(const Env &e) {
+    int n = 0;
+    for (int j = 0; j < e.J; ++j) n += e.legal(j);
+    return n;
+}
+
+bool any_busy(const Env &e) {
+    for (int m = 0; m < e.M; ++m)
+        if (e.tm[m] > 0) return true;
+    return false;
+}
+
+// ---- reset(): jss_env.py:145-181 ---------------------------------------------------------------------------
+void reset_env(const Env &e) {
+    e.t() = 0;                                                            // :154
+    e.hdr[JSS_H_STATUS] = 0;                                              // NOPE illegal (:161), error bits cleared
+    for (int m = 0; m < e.M; ++m) e.tm[m] = 0;                            // :164
+    for (int j = 0; j < e.J; ++j) {
+        e.w(j, JSS_F_TODO) = JSS_FLAG_LEGAL;                              // todo 0 (:166), legal (:160), not blocked (:171)
+        e.w(j, JSS_F_CUR) = e.ops[j * e.stride];                          // :174-176 needed machine = op 0
+        e.w(j, JSS_F_NEXT) = 1 < e.M ? e.ops[j * e.stride + 1] : -1;
+        e.w(j, JSS_F_LEFT) = e.w(j, JSS_F_PERF) = e.w(j, JSS_F_IDLE) = e.w(j, JSS_F_IDLE_LAST) = 0;   // :165-170
+        e.w(j, JSS_F_F4) = 0;                                             // :180
+    }
+    for (int i = 0; i < e.J * e.stride; ++i) e.sol[i] = -1;               // :163
+}
+
+// ---- increase_time_step(): jss_env.py:495-637; caller guarantees a busy machine ------------------------------
+int advance(const Env &e) {
+    int d = kBig;                                                         // :517-522 next event = earliest release
+    for (int m = 0; m < e.M; ++m)
+        if (e.tm[m] > 0 && e.tm[m] < d) d = e.tm[m];
+    e.t() += d;
+    int hole = 0;
+    for (int m = 0; m < e.M; ++m) {                                       // :604-613
+        if (e.tm[m] < d) hole += d - e.tm[m];                             // :606-608 (only idle machines: tm == 0)
+        e.tm[m] = e.tm[m] > d ? e.tm[m] - d : 0;                          // :611
+    }
+    for (int j = 0; j < e.J; ++j) {                                       // :525-601
+        const int was = e.w(j, JSS_F_LEFT);
+        if (was > 0) {                                                    // :529 running
+            e.w(j, JSS_F_PERF) += d < was ? d : was;                      // :531, :544
+            e.w(j, JSS_F_LEFT) = was > d ? was - d : 0;                   // :534
+            if (was <= d) {                                               // :550 op finished
+                e.w(j, JSS_F_IDLE) += d - was;                            // :552
+                e.w(j, JSS_F_IDLE_LAST) = d - was;                        // :554
+                const int k = e.todo(j) + 1;                              // :558
+                e.w(j, JSS_F_TODO) = (e.w(j, JSS_F_TODO) & ~JSS_TODO_MASK) | k;
+                const int cur = e.w(j, JSS_F_NEXT);                       // :562-566 the job moves on (-1: complete, :581)
+                e.w(j, JSS_F_CUR) = cur;
+                e.w(j, JSS_F_NEXT) = k + 1 < e.M ? e.ops[j * e.stride + k + 1] : -1;
+                e.w(j, JSS_F_F4) = cur >= 0 ? e.tm[cur >> 16] : JSS_F4_ONE;   // :569-586 (machine clocks already advanced)
+            }
+        } else if (e.todo(j) < e.M) {                                     // :594 waiting
+            e.w(j, JSS_F_IDLE) += d;                                      // :596
+            e.w(j, JSS_F_IDLE_LAST) += d;                                 // :597
+        }
+    }
+    for (int j = 0; j < e.J; ++j) {                                       // :616-634 re-legalisation
+        const int cur = e.w(j, JSS_F_CUR);
+        if (cur >= 0 && e.tm[cur >> 16] == 0 && !e.blocked(j)) e.set_legal(j, true);
+    }
+    return hole;
+}
+
+// ---- _prioritization_non_final(): jss_env.py:183-254 --------------------------------------------------------
+void prioritize(const Env &e) {
+    bool any_final = false;
+    for (int j = 0; j < e.J; ++j) any_final |= e.legal(j) && e.todo(j) == e.M - 1;   // :217
+    if (!any_final) return;
+    // shortest legal non-final job per machine whose NEXT machine is idle (:219-239)
+    int min_nf[JSS_MAX_MACHINES];
+    for (int m = 0; m < e.M; ++m) min_nf[m] = kBig;
+    for (int j = 0; j < e.J; ++j) {
+        if (!e.legal(j) || e.todo(j) >= e.M - 1) continue;
+        if (e.tm[e.w(j, JSS_F_NEXT) >> 16] != 0) continue;                // :234
+        const int cur = e.w(j, JSS_F_CUR);
+        if ((cur & kDurMask) < min_nf[cur >> 16]) min_nf[cur >> 16] = cur & kDurMask;
+    }
+    for (int j = 0; j < e.J; ++j) {                                       // :244-254
+        if (!e.legal(j) || e.todo(j) != e.M - 1) continue;
+        const int cur = e.w(j, JSS_F_CUR);
+        if ((cur & kDurMask) > min_nf[cur >> 16]) e.set_legal(j, false);
+    }
+}
+
+// ---- _check_no_op(): jss_env.py:256-401 ----------------------------------------------------------------------
+void check_no_op(const Env &e) {
+    e.set_noop(0);                                                        // :278
+    const int t = e.t();
+    int legal_jobs[4], nl = 0;
+    for (int j = 0; j < e.J; ++j)
+        if (e.legal(j)) {
+            if (nl == 4) return;                                          // :287 more than 4 legal jobs
+            legal_jobs[nl++] = j;
+        }
+    if (nl == 0) return;
+    int d_next = kBig;                                                    // :285, :293
+    for (int m = 0; m < e.M; ++m)
+        if (e.tm[m] > 0 && e.tm[m] < d_next) d_next = e.tm[m];
+    if (d_next == kBig) return;
+    const int next_event = t + d_next;
+    // pass 1 (:305-321), in ascending job order: per legal machine the running minimum of the ends
+    int horizon[JSS_MAX_MACHINES];                                        // max_horizon_machine; kBig = machine not legal
+    bool m_legal[JSS_MAX_MACHINES];
+    int n_ml = 0;
+    for (int m = 0; m < e.M; ++m) m_legal[m] = false;
+    for (int i = 0; i < nl; ++i) {
+        const int m = e.w(legal_jobs[i], JSS_F_CUR) >> 16;
+        if (!m_legal[m]) {
+            m_legal[m] = true;
+            ++n_ml;
+        }
+    }
+    if (n_ml > 3) return;                                                 // :286
+    for (int m = 0; m < e.M; ++m) horizon[m] = t + e.max_time_op;         // :300-302
+    int max_horizon = t;                                                  // :296
+    for (int i = 0; i < nl; ++i) {
+        const int cur = e.w(legal_jobs[i], JSS_F_CUR);
+        const int end = t + (cur & kDurMask);                             // :310
+        if (end < next_event) return;                                     // :314-315
+        if (end < horizon[cur >> 16]) horizon[cur >> 16] = end;           // :318
+        if (horizon[cur >> 16] > max_horizon) max_horizon = horizon[cur >> 16];   // :321
+    }
+    // pass 2 (:324-401): every illegal job looks ahead along its ops
+    bool covered[JSS_MAX_MACHINES];
+    for (int m = 0; m < e.M; ++m) covered[m] = false;
+    for (int j = 0; j < e.J; ++j) {
+        if (e.legal(j)) continue;
+        const int todo = e.todo(j);
+        const bool caseA = e.w(j, JSS_F_LEFT) > 0 && todo + 1 < e.M;      // :327-330 running, has a next op
+        const bool caseB = !caseA && !e.blocked(j) && todo < e.M;         // :366-369 waiting for its machine
+        if (!caseA && !caseB) continue;
+        int k = caseA ? todo + 1 : todo;                                  // :332 / :370
+        int tn = caseA ? t + e.w(j, JSS_F_LEFT) : t + e.tm[e.w(j, JSS_F_CUR) >> 16];   // :334-337 / :374-377
+        while (k < e.M - 1 && max_horizon > tn) {                         // :340-342 / :380-382
+            const int op = k == todo ? e.w(j, JSS_F_CUR) : (k == todo + 1 ? e.w(j, JSS_F_NEXT) : e.ops[j * e.stride + k]);
+            const int m = op >> 16;
+            if (m_legal[m] && horizon[m] > tn) covered[m] = true;         // :346-351
+            tn += op & kDurMask;                                          // :362
+            ++k;
+        }
+    }
+    for (int m = 0; m < e.M; ++m)
+        if (m_legal[m] && !covered[m]) return;
+    e.set_noop(1);                                                        // :357-359 / :395-397
+}
+
+// ---- step(): jss_env.py:403-481; returns the reward numerator ---------------------------------------------------
+int step_env(const Env &e, int a) {
+    if (a == JSS_ACTION_SKIP) return 0;
+    if (a < 0 || a > e.J) {
+        e.flag(JSS_ERR_BAD_ACTION);
+        return 0;
+    }
+    int rn = 0;
+    if (a == e.J) {                                                       // :419 NOPE
+        for (int j = 0; j < e.J; ++j)                                     // :422-428
+            if (e.legal(j)) {
+                e.set_blocked(j, true);
+                e.set_legal(j, false);
+            }
+        for (;;) {                                                        // :429-430
+            if (!any_busy(e)) {                                           // reference: IndexError (:517)
+                e.flag(JSS_ERR_NOPE_IDLE);
+                break;
+            }
+            rn -= advance(e);
+            if (n_legal(e)) break;
+        }
+    } else {                                                              // :441 allocate job a
+        if (!e.legal(a)) {                                                // outside the mask: ignored + flagged
+            e.flag(JSS_ERR_ILLEGAL_ACTION);
+            return 0;
+        }
+        const int cur = e.w(a, JSS_F_CUR);
+        const int m = cur >> 16, d = cur & kDurMask;                      // :443-444
+        rn = d;                                                           // :445
+        e.tm[m] = d;                                                      // :446
+        e.w(a, JSS_F_LEFT) = d;                                           // :447
+        e.sol[a * e.stride + e.todo(a)] = e.t();                          // :454
+        for (int j = 0; j < e.J; ++j) {
+            const int cj = e.w(j, JSS_F_CUR);
+            if (cj >= 0 && (cj >> 16) == m) {
+                e.set_legal(j, false);                                    // :455-463
+                e.set_blocked(j, false);                                  // :464-467
+            }
+        }
+        while (!n_legal(e) && any_busy(e)) rn -= advance(e);              // :469-470
+    }
+    prioritize(e);                                                        // :432 / :471
+    check_no_op(e);                                                       // :433 / :472
+    return rn;
+}
+
+// ---- action selectors ---------------------------------------------------------------------------------------
+uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+uint32_t rng_u32(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t step) {
+    const uint32_t a = (uint32_t)seed + (uint32_t)env_id * 0x9E3779B9u + episode * 0x85EBCA6Bu + step * 0xC2B2AE35u;
+    const uint32_t b = (uint32_t)(seed >> 32) ^ ((uint32_t)(env_id >> 32) * 0x27D4EB2Fu);
+    return fmix32(fmix32(a) ^ b);
+}
+
+int select_action(const Env &e, const Call &c, uint64_t env_id) {
+    const uint32_t episode = (uint32_t)e.hdr[JSS_H_EPISODE], step = (uint32_t)e.hdr[JSS_H_STEP];
+    const int nl = n_legal(e);
+    const int n = nl + e.noop();
+    if (n == 0) return -1;
+    if (c.kind == JSS_POLICY_RANDOM) {                                    // README.md:58-60 uniform over the mask's set bits
+        int pick = (int)(((uint64_t)rng_u32(c.seed, env_id, episode, step) * (uint32_t)n) >> 32);
+        for (int j = 0; j < e.J; ++j)
+            if (e.legal(j) && pick-- == 0) return j;
+        return e.J;
+    }
+    if (nl == 0) return e.J;                                              // only NOPE is legal (dispatching.py:96-97)
+    int best = -1;
+    long long best_num = 0, best_den = 1;                                 // CR: exact fraction compare
+    int best_v = 0;
+    for (int j = 0; j < e.J; ++j) {
+        if (!e.legal(j)) continue;
+        const int todo = e.todo(j);
+        if (c.kind == JSS_POLICY_CR) {                                    // dispatching.py:365-408, (3 L - 2 t) / remaining
+            const long long num = 3LL * e.rem[j * e.stride] - 2LL * e.t(), den = e.rem[j * e.stride + todo];
+            if (best < 0 || num * best_den < best_num * den) {
+                best = j;
+                best_num = num;
+                best_den = den;
+            }
+            continue;
+        }
+        int v;
+        bool larger = false;
+        switch (c.kind) {
+        case JSS_POLICY_FIFO: v = e.w(j, JSS_F_IDLE_LAST); larger = true; break;      // :146
+        case JSS_POLICY_SPT: v = e.w(j, JSS_F_CUR) & kDurMask; break;                 // :105-106
+        case JSS_POLICY_MWR: v = e.rem[j * e.stride + todo]; larger = true; break;    // :187-189
+        case JSS_POLICY_LWR: v = e.rem[j * e.stride + todo]; break;                   // :230-232
+        case JSS_POLICY_MOR: v = e.M - todo; larger = true; break;                    // :273
+        default: v = e.M - todo; break;                                               // LOR :314
+        }
+        if (best < 0 || (larger ? v > best_v : v < best_v)) {             // strict: the lowest index wins ties
+            best = j;
+            best_v = v;
+        }
+    }
+    if (e.noop() && c.explore_q16 != 0) {                                 // dispatching.py:113
+        if ((rng_u32(c.seed ^ kExploreSeedXor, env_id, episode, step) >> 16) < c.explore_q16) best = e.J;
+    }
+    return best;
+}
+
+// ---- outputs ------------------------------------------------------------------------------------------------
+float as_float(int32_t bits) {
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+// the kernels' division: quotient estimate with the record's reciprocal, one residual correction (bit-identical)
+float div_by(float a, float b, float rb) {
+    const float q = a * rb;
+    return std::fmaf(std::fmaf(-q, b, a), rb, q);
+}
+
+void write_outputs(const Env &e, const Call &c, int b) {
+    const int jm = c.d.jmax;
+    float *obs = c.o.real_obs + (size_t)b * jm * 7;
+    uint8_t *mk = c.o.action_mask + (size_t)b * (jm + 1);
+    const float f_op = (float)e.max_time_op, f_jobs = (float)e.inst[JSS_I_MAX_TIME_JOBS], f_sum = (float)e.inst[JSS_I_SUM_OP];
+    const float f_m = (float)e.M;
+    const float r_op = as_float(e.inst[JSS_I_RCP_MAX_TIME_OP]), r_jobs = as_float(e.inst[JSS_I_RCP_MAX_TIME_JOBS]);
+    const float r_sum = as_float(e.inst[JSS_I_RCP_SUM_OP]), r_m = as_float(e.inst[JSS_I_RCP_MACHINES]);
+    for (int j = 0; j < e.J; ++j) {                                       // jss_env.py:102-111
+        float *row = obs + j * 7;
+        row[0] = e.legal(j) ? 1.f : 0.f;                                  // :130
+        row[1] = div_by((float)e.w(j, JSS_F_LEFT), f_op, r_op);           // :448, :539
+        row[2] = div_by((float)e.todo(j), f_m, r_m);                      // :559
+        row[3] = div_by((float)e.w(j, JSS_F_PERF), f_jobs, r_jobs);       // :545
+        row[4] = e.w(j, JSS_F_F4) == JSS_F4_ONE ? 1.f : div_by((float)e.w(j, JSS_F_F4), f_op, r_op);   // :569-586
+        row[5] = div_by((float)e.w(j, JSS_F_IDLE_LAST), f_sum, r_sum);    // :555, :600
+        row[6] = div_by((float)e.w(j, JSS_F_IDLE), f_sum, r_sum);         // :553, :601
+        mk[j] = e.legal(j) ? 1 : 0;
+    }
+    for (int i = e.J * 7; i < jm * 7; ++i) obs[i] = 0.f;                  // padding rows
+    mk[e.J] = (uint8_t)e.noop();
+    for (int j = e.J + 1; j <= jm; ++j) mk[j] = 0;
+}
+
+void add_counters(const Call &c, int b, int steps, int episodes, long long makespans, long long reward_num) {
+    if (!c.s.counters) return;
+    int64_t *cn = c.s.counters + (size_t)b * 4;
+    cn[0] += steps;
+    cn[1] += episodes;
+    cn[2] += makespans;
+    cn[3] += reward_num;
+}
+
+uint64_t env_id_of(const Call &c, int b) { return (uint64_t)(c.d.env_ids ? c.d.env_ids[b] : c.d.env_id_base + b); }
+
+enum Mode { kReset, kStep, kAdvance, kPolicy, kRollout };
+
+void run_env(const Call &c, int mode, int b) {
+    const Env e = env_of(c, b);
+    switch (mode) {
+    case kReset:
+        if (c.which && !c.which[b]) break;
+        {
+            const int episode = e.hdr[JSS_H_EPISODE];
+            reset_env(e);
+            e.hdr[JSS_H_EPISODE] = episode + 1;
+            e.hdr[JSS_H_STEP] = 0;
+            c.o.reward[b] = 0.f;
+            c.o.done[b] = 0;
+        }
+        break;
+    case kStep: {
+        const int a = c.actions[b];
+        if (a == JSS_ACTION_SKIP) break;                                  // untouched: reward / done / makespan stay
+        const int rn = step_env(e, a);
+        const bool done = n_legal(e) == 0;                                // :639-653
+        e.hdr[JSS_H_STEP] += 1;
+        c.o.reward[b] = (float)rn / (float)e.max_time_op;                 // :483-493
+        c.o.done[b] = done ? 1 : 0;
+        if (done) c.o.makespan[b] = e.t();                                // :650
+        add_counters(c, b, 1, done ? 1 : 0, done ? e.t() : 0, rn);
+        break;
+    }
+    case kAdvance:
+        if (c.which && !c.which[b]) break;
+        {
+            int hole = 0;
+            if (!any_busy(e)) e.flag(JSS_ERR_NOPE_IDLE);                  // reference: IndexError (:517)
+            else hole = advance(e);
+            if (c.hole) c.hole[b] = hole;
+        }
+        break;
+    case kPolicy:
+        c.actions_out[b] = select_action(e, c, env_id_of(c, b));
+        return;                                                           // no outputs rewritten
+    default: {                                                            // n_iter x (policy + step), dispatching.py:55-75
+        const uint64_t env_id = env_id_of(c, b);
+        int n_steps = 0, n_done = 0, last_rn = 0, last_makespan = -1;
+        long long sum_makespan = 0, sum_rn = 0;
+        for (int it = 0; it < c.n_iter; ++it) {
+            if (n_legal(e) == 0) {                                        // done
+                if (!(c.flags & JSS_ROLLOUT_AUTORESET)) break;            // frozen
+                const int episode = e.hdr[JSS_H_EPISODE];
+                reset_env(e);
+                e.hdr[JSS_H_EPISODE] = episode + 1;
+                e.hdr[JSS_H_STEP] = 0;
+                continue;
+            }
+            last_rn = step_env(e, select_action(e, c, env_id));
+            e.hdr[JSS_H_STEP] += 1;
+            n_steps += 1;
+            sum_rn += last_rn;
+            if (n_legal(e) == 0) {
+                n_done += 1;
+                sum_makespan += e.t();
+                last_makespan = e.t();
+            }
+        }
+        if (n_steps) c.o.reward[b] = (float)last_rn / (float)e.max_time_op;
+        c.o.done[b] = n_legal(e) == 0 ? 1 : 0;
+        if (last_makespan >= 0) c.o.makespan[b] = last_makespan;
+        add_counters(c, b, n_steps, n_done, sum_makespan, sum_rn);
+        break;
+    }
+    }
+    write_outputs(e, c, b);
+}
+
+int run(const Call &c, int mode) {
+    const int B = c.d.batch;
+#ifdef _OPENMP
+    if (c.d.threads > 0) {
+#pragma omp parallel for schedule(static) num_threads(c.d.threads)
+        for (int b = 0; b < B; ++b) run_env(c, mode, b);
+    } else {
+#pragma omp parallel for schedule(static)
+        for (int b = 0; b < B; ++b) run_env(c, mode, b);
+    }
+#else
+    for (int b = 0; b < B; ++b) run_env(c, mode, b);
+#endif
+    return 0;
+}
+
+int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_out) {
+    if (!d || !s) return JSS_E_NULL;
+    if (!d->ops || !d->inst) return JSS_E_NULL;
+    if (!s->env || !s->job || !s->machine || !s->solution) return JSS_E_NULL;
+    if (need_out && (!o || !o->real_obs || !o->action_mask || !o->reward || !o->done || !o->makespan)) return JSS_E_NULL;
+    if (d->batch < 0 || d->jmax < 1 || d->jmax > JSS_MAX_JOBS || d->mmax < 2 || d->mmax > JSS_MAX_MACHINES ||
+        d->n_tables < 1)
+        return JSS_E_SHAPE;
+    if (!d->table_of_env && d->n_tables != 1 && d->n_tables != d->batch) return JSS_E_SHAPE;
+    if (d->kernel != JSS_KERNEL_AUTO && d->kernel != JSS_KERNEL_WAVE) return JSS_E_KIND;
+    return 0;
+}
+
+int check_kind(const JssDesc *d, int kind) {
+    if (kind < 0 || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+    if ((kind == JSS_POLICY_MWR || kind == JSS_POLICY_LWR || kind == JSS_POLICY_CR) && !d->rem) return JSS_E_NULL;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jss_abi_version(void) { return JSS_ABI_VERSION; }
+
+const char *jss_backend(void) {
+#ifdef _OPENMP
+    return "cpu:openmp";
+#else
+    return "cpu:serial";
+#endif
+}
+
+const char *jss_error_string(int code) {
+    switch (code) {
+    case 0: return "ok";
+    case JSS_E_NULL: return "null pointer in JssDesc/JssState/JssOut or arguments";
+    case JSS_E_SHAPE: return "bad shape (batch/jmax/mmax/n_tables/n_sub)";
+    case JSS_E_KIND: return "unknown policy kind or kernel flavour";
+    case JSS_E_LDS: return "batch shape needs more LDS per workgroup than the device provides";
+    default: return "unknown error";
+    }
+}
+
+int jss_reset(const JssDesc *desc, const JssState *state, const JssOut *out, const uint8_t *which, void *) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    Call c;
+    c.d = *desc; c.s = *state; c.o = *out; c.which = which;
+    return run(c, kReset);
+}
+
+int jss_step(const JssDesc *desc, const JssState *state, const int32_t *actions, const JssOut *out, void *) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if (!actions) return JSS_E_NULL;
+    Call c;
+    c.d = *desc; c.s = *state; c.o = *out; c.actions = actions;
+    return run(c, kStep);
+}
+
+int jss_advance(const JssDesc *desc, const JssState *state, const uint8_t *which, int32_t *hole, const JssOut *out, void *) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    Call c;
+    c.d = *desc; c.s = *state; c.o = *out; c.which = which; c.hole = hole;
+    return run(c, kAdvance);
+}
+
+int jss_policy(const JssDesc *desc, const JssState *state, int kind, uint64_t seed, uint32_t explore_q16, int32_t *actions,
+               void *) {
+    int rc = check_args(desc, state, nullptr, false);
+    if (rc) return rc;
+    if (!actions) return JSS_E_NULL;
+    if ((rc = check_kind(desc, kind))) return rc;
+    Call c;
+    c.d = *desc; c.s = *state; c.o = JssOut(); c.actions_out = actions; c.kind = kind; c.seed = seed; c.explore_q16 = explore_q16;
+    return run(c, kPolicy);
+}
+
+int jss_rollout(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed, uint32_t explore_q16,
+                int32_t n_iter, int32_t flags, void *) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if ((rc = check_kind(desc, kind))) return rc;
+    if (n_iter < 0) return JSS_E_SHAPE;
+    Call c;
+    c.d = *desc; c.s = *state; c.o = *out; c.kind = kind; c.seed = seed; c.explore_q16 = explore_q16;
+    c.n_iter = n_iter; c.flags = flags;
+    return run(c, kRollout);
+}
+
+// envs are independent and the call is synchronous: n_steps one-step rollouts of every env ARE one n_steps-iteration
+// rollout per env; sub-batches and streams have nothing to overlap here
+int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
+                      uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub, void *const *streams) {
+    if (n_steps < 0 || n_sub < 1 || n_sub > 16) return desc && state ? JSS_E_SHAPE : JSS_E_NULL;
+    if (!streams) return JSS_E_NULL;
+    return jss_rollout(desc, state, out, kind, seed, explore_q16, n_steps, flags, nullptr);
+}
+
+}  // extern "C"

@@ -18,88 +18,121 @@ using namespace jss;
 // ---------------------------------------------------------------------------------------
 int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_out) {
     if (!d || !s) return JSS_E_NULL;
-    if (!d->ops || !d->jobs || !d->machines || !d->max_time_op || !d->max_time_jobs || !d->sum_op) return JSS_E_NULL;
+    if (!d->ops || !d->inst) return JSS_E_NULL;
     if (!s->env || !s->job || !s->machine || !s->solution) return JSS_E_NULL;
     if (need_out && (!o || !o->real_obs || !o->action_mask || !o->reward || !o->done || !o->makespan)) return JSS_E_NULL;
     if (d->batch < 0 || d->jmax < 1 || d->jmax > JSS_MAX_JOBS || d->mmax < 2 || d->mmax > JSS_MAX_MACHINES ||
         d->n_tables < 1)
         return JSS_E_SHAPE;
     if (!d->table_of_env && d->n_tables != 1 && d->n_tables != d->batch) return JSS_E_SHAPE;
+    if (d->kernel != JSS_KERNEL_AUTO && d->kernel != JSS_KERNEL_WAVE) return JSS_E_KIND;
     return 0;
 }
 
-int g_kernel_choice = JSS_KERNEL_AUTO;
+int check_kind(const JssDesc *d, int kind) {
+    if (kind < 0 || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+    if ((kind == JSS_POLICY_MWR || kind == JSS_POLICY_LWR || kind == JSS_POLICY_CR) && !d->rem) return JSS_E_NULL;
+    return 0;
+}
+
+#ifdef JSS_PROFILING
 int g_ablate = 0;
 int g_lds_pad = 0;
-int g_persist = 0;   // waves per SIMD of the persistent kernel; 0 = off (default: measured slower, profiles/README.md)
-int g_cu_count = 0;  // 0 = ask the runtime
-
-int compute_units() {
-    if (g_cu_count > 0) return g_cu_count;
-    static int cached = 0;
-    if (cached == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cached = n;
-        else
-            cached = 256;
-    }
-    return cached;
-}
+#endif
 
 // Kernel flavour for a batch shape: the packed kernel needs every env's jobs AND machines to fit
 // a 16- or 32-lane group.
 int packed_group(const JssDesc &d) {
-    if (g_kernel_choice == JSS_KERNEL_WAVE) return 0;
+    if (d.kernel == JSS_KERNEL_WAVE) return 0;
     if (d.jmax <= 16 && d.mmax <= 16) return 16;
     if (d.jmax <= 32 && d.mmax <= 32) return 32;
     return 0;
 }
 
+using KernelFn = void (*)(Params);
+
 template <int MODE>
-int launch(Params &p, void *stream) {
-    if (p.d.batch == 0) return 0;
-    p.stride = p.d.mmax;
-    p.region_ints = p.d.jmax * p.stride;
-    p.shared_table = p.d.n_tables == 1 ? 1 : 0;
-    p.ablate = g_ablate;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+KernelFn pick(int G, int jpl, bool shared) {
+    if (G == 16) return shared ? jss_packed_kernel<16, MODE, kTabLds> : jss_packed_kernel<16, MODE, kTabGlobal>;
+    if (G == 32) return shared ? jss_packed_kernel<32, MODE, kTabLds> : jss_packed_kernel<32, MODE, kTabGlobal>;
+    if (jpl == 1) return shared ? jss_kernel<1, MODE, kTabLds> : jss_kernel<1, MODE, kTabGlobal>;
+    return shared ? jss_kernel<2, MODE, kTabLds> : jss_kernel<2, MODE, kTabGlobal>;
+}
+
+struct LaunchPlan {
+    KernelFn fn;
+    int envs_per_block;
+    size_t shmem;
+};
+
+constexpr size_t kMaxDynamicLds = 64 * 1024;   // available to a workgroup without raising the function attribute
+
+// Fills the launch-derived fields of `p` (LDS layout) from the whole batch's description.
+template <int MODE>
+int plan(Params &p, LaunchPlan &lp) {
+    const bool shared = p.d.n_tables == 1;
+    p.region_ints = p.d.jmax * p.d.mmax;
+    p.table_lds_ints = shared ? ((p.region_ints + 3) & ~3) : 0;
     const int G = packed_group(p.d);
     if (G) {
-        const int envs_per_block = (kWave / G) * kWavesPerBlock;
-        const int n_regions = p.shared_table ? 1 : envs_per_block;
-        p.obs_off_ints = (n_regions * p.region_ints + 3) & ~3;
+        lp.envs_per_block = (kWave / G) * kWavesPerBlock;
         p.obs_wave_floats = ((kWave / G) * p.d.jmax * 7 + 3) & ~3;
-        p.mv_off_ints = p.obs_off_ints + kWavesPerBlock * p.obs_wave_floats;
-        const size_t shmem = sizeof(int32_t) * ((size_t)p.mv_off_ints + kBlock) + g_lds_pad;
-        const int blocks = (p.d.batch + envs_per_block - 1) / envs_per_block;
-        // persistent variant: shared instance, step-per-launch modes, more env sets than resident waves
-        if ((MODE == kStep || MODE == kRollout1) && p.shared_table && g_persist > 0) {
-            const int pblocks = compute_units() * g_persist;              // one wave per SIMD per workgroup
-            if (blocks > pblocks) {
-                constexpr int PM = (MODE == kStep) ? kStep : kRollout1;   // only these two are instantiated
-                if (G == 16)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed_persistent<16, PM>), dim3(pblocks), dim3(kBlock), shmem, st, p);
-                else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed_persistent<32, PM>), dim3(pblocks), dim3(kBlock), shmem, st, p);
-                return (int)hipGetLastError();
-            }
-        }
-        if (G == 16)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed_kernel<16, MODE>), dim3(blocks), dim3(kBlock), shmem, st, p);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_packed_kernel<32, MODE>), dim3(blocks), dim3(kBlock), shmem, st, p);
-        return (int)hipGetLastError();
+        p.mv_off_ints = p.table_lds_ints + kWavesPerBlock * p.obs_wave_floats;
+        lp.shmem = sizeof(int32_t) * ((size_t)p.mv_off_ints + kBlock);
+    } else {
+        lp.envs_per_block = kWavesPerBlock;
+        p.obs_wave_floats = (p.d.jmax * 7 + 3) & ~3;
+        p.mv_off_ints = 0;
+        lp.shmem = sizeof(int32_t) * ((size_t)p.table_lds_ints + kWavesPerBlock * p.obs_wave_floats);
     }
-    const int n_regions = p.shared_table ? 1 : kWavesPerBlock;
-    const size_t shmem = sizeof(int32_t) * (size_t)n_regions * p.region_ints + sizeof(float) * kWavesPerBlock * p.d.jmax * 7;
-    const int blocks = (p.d.batch + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (p.d.jmax <= kWave)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_kernel<1, MODE>), dim3(blocks), dim3(kBlock), shmem, st, p);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(jss_kernel<2, MODE>), dim3(blocks), dim3(kBlock), shmem, st, p);
+#ifdef JSS_PROFILING
+    p.ablate = g_ablate;
+    lp.shmem += g_lds_pad;
+#endif
+    if (lp.shmem > kMaxDynamicLds) return JSS_E_LDS;
+    lp.fn = pick<MODE>(G, p.d.jmax <= kWave ? 1 : 2, shared);
+    return 0;
+}
+
+int fire(const Params &p, const LaunchPlan &lp, void *stream) {
+    if (p.d.batch == 0) return 0;
+    const int blocks = (p.d.batch + lp.envs_per_block - 1) / lp.envs_per_block;
+    hipLaunchKernelGGL(lp.fn, dim3(blocks), dim3(kBlock), lp.shmem, reinterpret_cast<hipStream_t>(stream), p);
     return (int)hipGetLastError();
+}
+
+template <int MODE>
+int launch(Params &p, void *stream) {
+    LaunchPlan lp;
+    const int rc = plan<MODE>(p, lp);
+    return rc ? rc : fire(p, lp, stream);
+}
+
+// The description of envs [start, start + count) of the batch `p` describes: every per-env pointer moves,
+// and so do the instance tables when the batch has one table per env (tid = local env index).
+Params sub_batch(const Params &p, int start, int count) {
+    Params q = p;
+    const size_t s0 = (size_t)start, jm = (size_t)p.d.jmax, mm = (size_t)p.d.mmax;
+    q.d.batch = count;
+    if (p.d.table_of_env) q.d.table_of_env = p.d.table_of_env + s0;
+    else if (p.d.n_tables != 1) {
+        q.d.ops = p.d.ops + s0 * jm * mm;
+        if (p.d.rem) q.d.rem = p.d.rem + s0 * jm * mm;
+        q.d.inst = p.d.inst + s0 * JSS_NI;
+    }
+    if (p.d.env_ids) q.d.env_ids = p.d.env_ids + s0;
+    q.d.env_id_base = p.d.env_id_base + start;
+    q.s.env = p.s.env + s0 * 4;
+    q.s.job = p.s.job + s0 * jm * JSS_NF;
+    q.s.machine = p.s.machine + s0 * mm;
+    q.s.solution = p.s.solution + s0 * jm * mm;
+    if (p.s.counters) q.s.counters = p.s.counters + s0 * 4;
+    q.o.real_obs = p.o.real_obs + s0 * jm * 7;
+    q.o.action_mask = p.o.action_mask + s0 * (jm + 1);
+    q.o.reward = p.o.reward + s0;
+    q.o.done = p.o.done + s0;
+    q.o.makespan = p.o.makespan + s0;
+    return q;
 }
 
 }  // namespace
@@ -108,36 +141,29 @@ extern "C" {
 
 int jss_abi_version(void) { return JSS_ABI_VERSION; }
 
-int jss_set_option(int option, int value) {
-    if (option == JSS_OPT_KERNEL && value >= JSS_KERNEL_AUTO && value <= JSS_KERNEL_WAVE) {
-        g_kernel_choice = value;
-        return 0;
-    }
-    if (option == JSS_OPT_LDS_PAD && value >= 0 && value <= 150000) {
+const char *jss_backend(void) { return "hip:gfx950"; }
+
+#ifdef JSS_PROFILING
+int jss_profiling_set(int option, int value) {
+    if (option == JSS_PROF_LDS_PAD && value >= 0 && value <= 150000) {
         g_lds_pad = value;
         return 0;
     }
-    if (option == JSS_OPT_PERSIST && value >= 0 && value <= 8) {
-        g_persist = value;
-        return 0;
-    }
-    if (option == JSS_OPT_CU_COUNT && value >= 0) {
-        g_cu_count = value;
-        return 0;
-    }
-    if (option == JSS_OPT_ABLATE) {
+    if (option == JSS_PROF_ABLATE) {
         g_ablate = value;
         return 0;
     }
     return JSS_E_KIND;
 }
+#endif
 
 const char *jss_error_string(int code) {
     switch (code) {
     case 0: return "ok";
     case JSS_E_NULL: return "null pointer in JssDesc/JssState/JssOut or arguments";
-    case JSS_E_SHAPE: return "bad shape (batch/jmax/mmax/n_tables)";
-    case JSS_E_KIND: return "unknown policy kind";
+    case JSS_E_SHAPE: return "bad shape (batch/jmax/mmax/n_tables/n_sub)";
+    case JSS_E_KIND: return "unknown policy kind or kernel flavour";
+    case JSS_E_LDS: return "batch shape needs more LDS per workgroup than the device provides";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -173,7 +199,7 @@ int jss_policy(const JssDesc *desc, const JssState *state, int kind, uint64_t se
     int rc = check_args(desc, state, nullptr, false);
     if (rc) return rc;
     if (!actions) return JSS_E_NULL;
-    if (kind < 0 || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+    if ((rc = check_kind(desc, kind))) return rc;
     Params p = {};
     p.d = *desc; p.s = *state; p.actions_out = actions; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
     return launch<kPolicy>(p, stream);
@@ -183,12 +209,39 @@ int jss_rollout(const JssDesc *desc, const JssState *state, const JssOut *out, i
                 uint32_t explore_q16, int32_t n_iter, int32_t flags, void *stream) {
     int rc = check_args(desc, state, out, true);
     if (rc) return rc;
-    if (kind < 0 || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+    if ((rc = check_kind(desc, kind))) return rc;
     if (n_iter < 0) return JSS_E_SHAPE;
     Params p = {};
     p.d = *desc; p.s = *state; p.o = *out; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
     p.n_iter = n_iter; p.flags = flags;
     return n_iter == 1 ? launch<kRollout1>(p, stream) : launch<kRollout>(p, stream);
+}
+
+int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
+                      uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub, void *const *streams) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if ((rc = check_kind(desc, kind))) return rc;
+    if (n_steps < 0 || n_sub < 1 || n_sub > 16) return JSS_E_SHAPE;
+    if (!streams) return JSS_E_NULL;
+    Params p = {};
+    p.d = *desc; p.s = *state; p.o = *out; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
+    p.n_iter = 1; p.flags = flags;
+    LaunchPlan lp;
+    if ((rc = plan<kRollout1>(p, lp))) return rc;
+    // contiguous sub-batches with boundaries at multiples of 64 envs (whole workgroups, 16-byte aligned rows)
+    const int chunk = (((desc->batch + n_sub - 1) / n_sub) + 63) & ~63;
+    Params sub[16];
+    int n = 0;
+    for (int i = 0; i < n_sub; ++i) {
+        const int start = i * chunk;
+        if (start >= desc->batch) break;
+        sub[n++] = sub_batch(p, start, desc->batch - start < chunk ? desc->batch - start : chunk);
+    }
+    for (int s = 0; s < n_steps; ++s)
+        for (int i = 0; i < n; ++i)
+            if ((rc = fire(sub[i], lp, streams[i]))) return rc;
+    return 0;
 }
 
 }  // extern "C"

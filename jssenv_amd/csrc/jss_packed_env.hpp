@@ -19,21 +19,31 @@
 
 namespace jss {
 
+template <class T>
+__device__ __forceinline__ T ld_off(const void *base, unsigned byte_off) {   // uniform base + 32-bit lane offset
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void st_off(void *base, unsigned byte_off, T v) {
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
 template <int G>
 struct PCtx {                 // per-lane view of "my env"
     int lane, gl, gbase;      // gl = lane within the group, gbase = first lane of the group
-    int b;                    // env index (clamped to batch-1 for dead groups)
-    bool alive;               // b < batch
+    unsigned rel;             // my env's index within the wave's env set (clamped like b)
+    int first_env;            // wave-uniform: first env of the wave's set
+    bool alive;               // my env exists (first_env + lane / G < batch)
     bool jvalid, mvalid;      // gl < J, gl < M
-    int J, M, max_time_op, max_time_jobs, sum_op;
-    const int32_t *ops;       // LDS op table of my env, row stride `stride`
-    int stride;
+    int tid;                  // instance of my env
+    int J, M, max_time_op;
+    const int32_t *row;       // op table row of my job (LDS with kTabLds, global with kTabGlobal)
 };
 
 template <int G>
 struct PEnv {
     int t;                    // group-uniform
-    int todo, cur, left, perf, idle, idle_last, f4;  // job gl
+    int todo, cur, nxt, left, perf, idle, idle_last, f4;  // job gl
     int tm;                   // machine gl
     bool legal, blocked;      // job gl
     int noop, err;            // group-uniform
@@ -82,13 +92,14 @@ __device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G> &c, const Para
         e.noop = 0;                                                      // :161
         e.err = 0;
         e.todo = 0;                                                      // :166
-        e.cur = c.jvalid ? c.ops[c.gl * c.stride] : -1;                  // :174-176
+        e.cur = c.jvalid ? c.row[0] : -1;                                // :174-176
+        e.nxt = (c.jvalid && 1 < c.M) ? c.row[1] : -1;
         e.left = e.perf = e.idle = e.idle_last = 0;                      // :165-170
         e.f4 = 0;                                                        // :180
         e.legal = c.jvalid;                                              // :160
         e.blocked = false;                                               // :171-172
         if (c.alive) {                                                   // solution = -1 (:163)
-            int32_t *sol = p.s.solution + (size_t)c.b * p.d.jmax * p.d.mmax;
+            int32_t *sol = p.s.solution + ((size_t)c.first_env + c.rel) * p.d.jmax * p.d.mmax;
             const int n = c.J * p.d.mmax;
             for (int i = c.gl; i < n; i += G) sol[i] = -1;
         }
@@ -98,13 +109,6 @@ __device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G> &c, const Para
 // ---------------------------------------------------------------------------------------
 // increase_time_step(): jss_env.py:495-637 for the groups with `act`; returns hole_planning.
 // ---------------------------------------------------------------------------------------
-// op after my job's current one (-1 when the current op is the job's last): read from LDS ahead of time so
-// its latency hides behind the event-time reduction instead of sitting in increase_time_step's chain
-template <int G>
-__device__ __forceinline__ int p_prefetch_next_op(const PEnv<G> &e, const PCtx<G> &c) {
-    return (c.jvalid && e.todo + 1 < c.M) ? c.ops[c.gl * c.stride + e.todo + 1] : -1;
-}
-
 // time to the next event of my env = earliest machine release (:517-522; the reference's queue is
 // {t + tm[m] : tm[m] > 0}); kBig when no machine is busy (empty queue)
 template <int G>
@@ -113,7 +117,7 @@ __device__ __forceinline__ int p_next_event(const PEnv<G> &e) {
 }
 
 template <int G>
-__device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act, int d, int next_op) {
+__device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act, int d) {
     const int idle_machines = __popc(grp_ballot<G>(c.mvalid && e.tm < d, c.gbase));
     const int hole = d * idle_machines;                                  // :606-608 (tm < d only when tm == 0)
     bool fin = false;
@@ -135,7 +139,10 @@ __device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act,
             e.idle_last += d;                                            // :597
         }
         e.tm = imax(0, e.tm - d);                                        // :611
-        if (fin) e.cur = next_op;                                        // :562-566 / :581 (prefetched by the caller)
+        if (fin) {                                                       // :562-566 / :581: the job moves on to its next op,
+            e.cur = e.nxt;                                               // which the record carries; the one after it is the
+            e.nxt = (e.todo + 1 < c.M) ? c.row[e.todo + 1] : -1;         // step's only op table read (not needed before the
+        }                                                                // job's next finish, a prioritisation or a long walk)
     }
     // time left on the machine my job needs (after the update): feature-4 numerator
     // max(0, tm_old[need] - d) (:569-578) and the "machine is free" test of :616 in one read
@@ -158,7 +165,7 @@ __device__ __forceinline__ void p_prioritize(PEnv<G> &e, const PCtx<G> &c, bool 
     int tm_next = 1;
     {
         const bool cand = on && e.legal && e.todo < c.M - 1;             // :219
-        const int next_m = cand ? (c.ops[c.gl * c.stride + e.todo + 1] >> 16) : 0;  // :227
+        const int next_m = cand ? (e.nxt >> 16) : 0;                     // :227
         tm_next = grp_read<G>(e.tm, next_m, c.gbase);
         nf = cand && tm_next == 0;                                       // :234 next machine idle
     }
@@ -184,7 +191,9 @@ __device__ __forceinline__ void p_prioritize(PEnv<G> &e, const PCtx<G> &c, bool 
 // (min over the legal jobs with a lower or equal index on its machine), a machine lane its
 // machine's final minimum `mv`.  One round per legal job broadcasts that job's (machine, end).
 // Pass 2 looks max_horizon_machine up in a per-group LDS table (`mvtab`, one int per lane) because
-// the walk is divergent, and collects the covered machines as a bit mask (M <= G <= 32).
+// the walk is divergent, and collects the covered machines as a bit mask (M <= G <= 32).  The walk's
+// first ops are the ones the job record carries (current op, next op); only a walk that goes further
+// reads the op table (about one lane in ten, tools/walk_depth.py).
 // ---------------------------------------------------------------------------------------
 template <int G>
 __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool on, int32_t *mvtab) {
@@ -246,15 +255,38 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool
     int k = caseA ? e.todo + 1 : e.todo;                                              // :332 / :370
     int tn = caseA ? e.t + e.left : e.t + tm_need;                                    // :334-337 / :374-377
     int u = 0;                                                                        // machine_next as a bit mask
-    if (gate && (caseA || caseB)) {
-        const int32_t *tab = mvtab + c.gbase;
-        while (k < c.M - 1 && mh > tn) {                                              // :340-342 / :380-382
-            const int op = c.ops[c.gl * c.stride + k];
-            const int m = op >> 16;
-            if (tab[m] > tn) u |= 1 << m;                                             // :346-351
-            tn += op & kDurMask;                                                      // :362
+    const int last = c.M - 1;
+    const int32_t *tab = mvtab + c.gbase;
+    // the loop of :340-363 / :380-401, its first iterations on the ops the record carries
+    bool go = gate && (caseA || caseB) && k < last && mh > tn;
+    if (go && caseB) {                                                                // op k == todo: the current op
+        const int m = e.cur >> 16;
+        if (tab[m] > tn) u |= 1 << m;                                                 // :346-351
+        tn += e.cur & kDurMask;                                                       // :362
+        ++k;
+        go = k < last && mh > tn;
+    }
+    if (go) {                                                                         // op k == todo + 1: the next op
+        const int m = e.nxt >> 16;
+        if (tab[m] > tn) u |= 1 << m;
+        tn += e.nxt & kDurMask;
+        ++k;
+        go = k < last && mh > tn;
+    }
+    if (go) {                                                                         // further: the op table, two entries per trip
+        do {
+            const int op0 = c.row[k], op1 = c.row[k + 1];                             // k + 1 <= M - 1: inside the row
+            int m = op0 >> 16;
+            if (tab[m] > tn) u |= 1 << m;
+            tn += op0 & kDurMask;
             ++k;
-        }
+            if (k < last && mh > tn) {
+                m = op1 >> 16;
+                if (tab[m] > tn) u |= 1 << m;
+                tn += op1 & kDurMask;
+                ++k;
+            }
+        } while (k < last && mh > tn);
     }
     int covered = row_or(u);                                                          // union over the group
     if (G == 32) covered |= __builtin_amdgcn_ds_swizzle(covered, 0x401F);
@@ -282,7 +314,7 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params
         if (c.gl == m) e.tm = d;                                         // :446
         if (mine) {
             e.left = d;                                                  // :447
-            p.s.solution[((size_t)c.b * p.d.jmax + a) * p.d.mmax + e.todo] = e.t;  // :454
+            p.s.solution[(((size_t)c.first_env + c.rel) * p.d.jmax + a) * p.d.mmax + e.todo] = e.t;  // :454
         }
         if (e.cur >= 0 && (e.cur >> 16) == m) {
             e.legal = false;                                             // :455-463
@@ -297,18 +329,17 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params
     for (;;) {                                                           // :429-430 / :469-470
         const bool none_legal = !grp_any<G>(e.legal, c.gbase);
         if (__ballot(stepping && none_legal) == 0) break;                // nobody waits for an event: skip the min
-        const int next_op = p_prefetch_next_op(e, c);
         const int d = p_next_event(e);
         const bool busy = d < kBig;
         bool act = stepping && none_legal;
         if (act && !busy && is_nope) e.err |= JSS_ERR_NOPE_IDLE;         // reference: IndexError (:517)
         act = act && busy;
-        if (__ballot(act) == 0 || (p.ablate & JSS_ABLATE_ADVANCE)) break;
-        const int hole = p_advance(e, c, act, d, next_op);
+        if (__ballot(act) == 0 || JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) break;
+        const int hole = p_advance(e, c, act, d);
         if (act) rn -= hole;
     }
-    if (!(p.ablate & JSS_ABLATE_PRIORITIZE)) p_prioritize(e, c, stepping);      // :432 / :471
-    if (!(p.ablate & JSS_ABLATE_CHECK_NO_OP)) p_check_no_op(e, c, stepping, mvtab);  // :433 / :472
+    if (!JSS_ABLATED(p, JSS_ABLATE_PRIORITIZE)) p_prioritize(e, c, stepping);        // :432 / :471
+    if (!JSS_ABLATED(p, JSS_ABLATE_CHECK_NO_OP)) p_check_no_op(e, c, stepping, mvtab);  // :433 / :472
     return rn;
 }
 
@@ -316,52 +347,46 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params
 // action selectors (group-uniform result; -1 when nothing is legal)
 // ---------------------------------------------------------------------------------------
 template <int G>
-__device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G> &c, int kind, uint64_t seed, uint32_t explore_q16,
-                                        uint64_t env_id, uint32_t episode, uint32_t step) {
+__device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G> &c, const Params &p, uint64_t env_id,
+                                        uint32_t episode, uint32_t step) {
+    const int kind = p.kind;
     const uint32_t lm = grp_ballot<G>(e.legal, c.gbase);
     const int nl = __popc(lm);
     const int n = nl + (e.noop ? 1 : 0);
     int a;
     if (kind == JSS_POLICY_RANDOM) {
-        const uint32_t r = rng_u32(seed, env_id, episode, step);
+        const uint32_t r = rng_u32(p.seed, env_id, episode, step);
         const int pick = (int)__umulhi(r, (uint32_t)n);
         const int below = __popc(lm & ((1u << c.gl) - 1u));
         const uint32_t hit = grp_ballot<G>(e.legal && below == pick, c.gbase);
         a = hit ? __ffs(hit) - 1 : c.J;                                  // pick >= nl: NOPE (it is legal then)
     } else {
+        // remaining-work table row of my job: rem[k] = durations of ops k..M-1 (MWR / LWR / CR)
+        const int32_t *rem = p.d.rem + (size_t)c.tid * p.region_ints + c.gl * p.d.mmax;
         if (kind == JSS_POLICY_CR) {
-            int total = 0, remaining = 0;
-            if (e.legal)
-                for (int k = 0; k < c.M; ++k) {
-                    const int d = c.ops[c.gl * c.stride + k] & kDurMask;
-                    total += d;
-                    if (k >= e.todo) remaining += d;
-                }
+            const int total = e.legal ? rem[0] : 0;                      // dispatching.py:373 job length
+            const int remaining = e.legal ? rem[e.todo] : 1;             // :391
             CrKey key;
             key.num = e.legal ? 3 * total - 2 * e.t : 0x3fffffff;
-            key.den = e.legal ? remaining : 1;
+            key.den = remaining;
             key.idx = e.legal ? c.gl : kCrNone;
             key = cr_argmin<G>(key);
             a = key.idx < kCrNone ? key.idx : c.J;                       // no job legal: NOPE
         } else {
             const bool larger = (kind == JSS_POLICY_FIFO || kind == JSS_POLICY_MWR || kind == JSS_POLICY_MOR);
             int v;
-            if (kind == JSS_POLICY_FIFO) v = e.idle_last;
-            else if (kind == JSS_POLICY_SPT) v = e.cur & kDurMask;
-            else if (kind == JSS_POLICY_MOR || kind == JSS_POLICY_LOR) v = c.M - e.todo;
-            else {
-                v = 0;
-                if (e.legal)
-                    for (int k = e.todo; k < c.M; ++k) v += c.ops[c.gl * c.stride + k] & kDurMask;
-            }
+            if (kind == JSS_POLICY_FIFO) v = e.idle_last;                // dispatching.py:146
+            else if (kind == JSS_POLICY_SPT) v = e.cur & kDurMask;       // :105-106
+            else if (kind == JSS_POLICY_MOR || kind == JSS_POLICY_LOR) v = c.M - e.todo;  // :273 / :314
+            else v = e.legal ? rem[e.todo] : 0;                          // MWR / LWR :187-189 / :230-232
             const int key = e.legal ? (larger ? v : -v) : -kBig;
             const int best = grp_max<G>(key);
             const uint32_t hit = grp_ballot<G>(e.legal && key == best, c.gbase);
             a = hit ? __ffs(hit) - 1 : c.J;                              // no job legal: NOPE
         }
-        if (e.noop && explore_q16 != 0) {
-            const uint32_t r = rng_u32(seed ^ kExploreSeedXor, env_id, episode, step);
-            if ((r >> 16) < explore_q16) a = c.J;
+        if (e.noop && p.explore_q16 != 0) {
+            const uint32_t r = rng_u32(p.seed ^ kExploreSeedXor, env_id, episode, step);
+            if ((r >> 16) < p.explore_q16) a = c.J;
         }
     }
     return n == 0 ? -1 : a;
@@ -369,7 +394,8 @@ __device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G> &c, int 
 
 // ---------------------------------------------------------------------------------------
 // HBM <-> registers.  One 32-byte record per job (two dwordx4 per lane), one int4 header per env.
-// None of the addresses depends on another load, so everything is in flight at once.
+// Every address is the wave's uniform base + a 32-bit lane offset and none depends on another load,
+// so everything is in flight at once.
 // ---------------------------------------------------------------------------------------
 struct PHeader {
     int episode, step;
@@ -382,16 +408,18 @@ struct PRaw {  // loads issued before the op table is staged; unpacked after the
 };
 
 template <int G>
-__device__ __forceinline__ PRaw<G> p_issue_loads(int b, int gl, const Params &p) {
+__device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G> &c, const Params &p) {
     PRaw<G> r;
-    const int jm = p.d.jmax;
-    const int jc = gl < jm ? gl : 0;
-    const int mc = gl < p.d.mmax ? gl : 0;
-    const int4 *js = reinterpret_cast<const int4 *>(p.s.job) + ((size_t)b * jm + jc) * 2;
-    r.h = reinterpret_cast<const int4 *>(p.s.env)[b];
-    r.lo = js[0];
-    r.hi = js[1];
-    r.tm = p.s.machine[(size_t)b * p.d.mmax + mc];
+    const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
+    const unsigned jc = (unsigned)c.gl < jm ? c.gl : 0;
+    const unsigned mc = (unsigned)c.gl < mm ? c.gl : 0;
+    const size_t fe = (size_t)c.first_env;
+    r.h = ld_off<int4>(p.s.env + fe * 4, c.rel * 16u);
+    const int32_t *jb = p.s.job + fe * jm * JSS_NF;
+    const unsigned jo = (c.rel * jm + jc) * 32u;
+    r.lo = ld_off<int4>(jb, jo);
+    r.hi = ld_off<int4>(jb, jo + 16u);
+    r.tm = ld_off<int>(p.s.machine + fe * mm, (c.rel * mm + mc) * 4u);
     return r;
 }
 
@@ -402,15 +430,16 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G> &c, const 
     e.noop = (r.h.w & JSS_STATUS_NOOP) ? 1 : 0;
     e.tm = c.mvalid ? r.tm : 0;
     const bool v = c.jvalid;
-    e.todo = v ? r.lo.x : 0;
+    e.todo = v ? (r.lo.x & JSS_TODO_MASK) : 0;
     e.cur = v ? r.lo.y : -1;
     e.left = v ? r.lo.z : 0;
     e.perf = v ? r.lo.w : 0;
     e.idle = v ? r.hi.x : 0;
     e.idle_last = v ? r.hi.y : 0;
     e.f4 = v ? r.hi.z : 0;
-    e.legal = v && (r.hi.w & JSS_FLAG_LEGAL);
-    e.blocked = v && (r.hi.w & JSS_FLAG_BLOCKED);
+    e.nxt = v ? r.hi.w : -1;
+    e.legal = v && (r.lo.x & JSS_FLAG_LEGAL);
+    e.blocked = v && (r.lo.x & JSS_FLAG_BLOCKED);
     PHeader hd;
     hd.episode = r.h.y;
     hd.step = r.h.z;
@@ -420,33 +449,42 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G> &c, const 
 template <int G>
 __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G> &c, const Params &p, const PHeader &hd) {
     if (!c.alive) return;
-    const int jm = p.d.jmax;
-    uint8_t *mk = p.o.action_mask + (size_t)c.b * (jm + 1);
-    if (c.gl == 0) {
-        reinterpret_cast<int4 *>(p.s.env)[c.b] =
-            make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
-        mk[c.J] = (uint8_t)e.noop;
-    }
-    if (c.mvalid) p.s.machine[(size_t)c.b * p.d.mmax + c.gl] = e.tm;
+    const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
+    const size_t fe = (size_t)c.first_env;
+    if (c.gl == 0)
+        st_off<int4>(p.s.env + fe * 4, c.rel * 16u,
+                     make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0)));
+    if (c.mvalid) st_off<int>(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
     if (c.jvalid) {
-        int4 *js = reinterpret_cast<int4 *>(p.s.job) + ((size_t)c.b * jm + c.gl) * 2;
-        js[0] = make_int4(e.todo, e.cur, e.left, e.perf);
-        js[1] = make_int4(e.idle, e.idle_last, e.f4, (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0));
-        mk[c.gl] = e.legal ? 1 : 0;
+        int32_t *jb = p.s.job + fe * jm * JSS_NF;
+        const unsigned jo = (c.rel * jm + c.gl) * 32u;
+        st_off<int4>(jb, jo, make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0), e.cur,
+                                       e.left, e.perf));
+        st_off<int4>(jb, jo + 16u, make_int4(e.idle, e.idle_last, e.f4, e.nxt));
     }
+    // action mask row of jmax + 1 bytes: legal jobs, the NOPE flag at index J, zeros behind it
+    uint8_t *mk = p.o.action_mask + fe * (jm + 1);
+    const unsigned mo = c.rel * (jm + 1);
+    if ((unsigned)c.gl <= jm)
+        st_off<uint8_t>(mk, mo + c.gl, (uint8_t)(c.jvalid ? (e.legal ? 1 : 0) : (c.gl == c.J ? e.noop : 0)));
+    if (jm == (unsigned)G && c.gl == 0) st_off<uint8_t>(mk, mo + jm, (uint8_t)(c.J == G ? e.noop : 0));
 }
 
 // (J,7) float32 observation (jss_env.py:102-111).  Each lane writes its job's row into an LDS
 // image of the wave's E consecutive envs ([E][jmax][7], padding rows zero), which then goes out as
 // one linear copy -- dwordx4 per lane when the wave's block is whole and 16-byte sized.
-template <int G>
+template <int G, int TAB>
 __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, const Params &p, float *scratch,
-                                            int first_env, bool wave_whole) {
+                                            bool wave_whole) {
     constexpr int E = kWave / G;
     const int row_floats = p.d.jmax * 7;
-    const float f_op = (float)c.max_time_op, f_jobs = (float)c.max_time_jobs, f_sum = (float)c.sum_op, f_m = (float)c.M;
-    const float r_op = refined_rcp(f_op), r_jobs = refined_rcp(f_jobs), r_sum = refined_rcp(f_sum), r_m = refined_rcp(f_m);
-    float *mine = scratch + (c.gbase / G) * row_floats;
+    // the normalisers and their reciprocals (instance record words 2..8)
+    const int32_t *ir = p.d.inst + (TAB == kTabLds ? 0 : (size_t)c.tid * JSS_NI);
+    const float f_op = (float)c.max_time_op, f_jobs = (float)ir[JSS_I_MAX_TIME_JOBS], f_sum = (float)ir[JSS_I_SUM_OP];
+    const float f_m = (float)c.M;
+    const float r_op = as_float(ir[JSS_I_RCP_MAX_TIME_OP]), r_jobs = as_float(ir[JSS_I_RCP_MAX_TIME_JOBS]);
+    const float r_sum = as_float(ir[JSS_I_RCP_SUM_OP]), r_m = as_float(ir[JSS_I_RCP_MACHINES]);
+    float *mine = scratch + (c.gbase / G) * row_floats;   // image slot = physical group (dead groups share c.rel with a live one)
     if (c.gl < p.d.jmax) {
         float *row = mine + c.gl * 7;
         row[0] = e.legal ? 1.0f : 0.0f;                                                  // :130
@@ -459,13 +497,12 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, 
     }
     wave_lds_sync();
     const int n = E * row_floats;
+    float *dst = p.o.real_obs + (size_t)c.first_env * row_floats;
     if (wave_whole && (n & 3) == 0) {
-        const float4 *src = reinterpret_cast<const float4 *>(scratch);
-        float4 *dst = reinterpret_cast<float4 *>(p.o.real_obs + (size_t)first_env * row_floats);
-        for (int i = c.lane; i < (n >> 2); i += kWave) dst[i] = src[i];
+        for (int i = c.lane; i < (n >> 2); i += kWave)
+            st_off<float4>(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
     } else if (c.alive) {
-        float *dst = p.o.real_obs + (size_t)c.b * row_floats;
-        for (int i = c.gl; i < row_floats; i += G) dst[i] = mine[i];
+        for (int i = c.gl; i < row_floats; i += G) st_off<float>(dst, (c.rel * row_floats + i) * 4u, mine[i]);
     }
     wave_lds_sync();
 }
@@ -476,6 +513,7 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, 
 template <int G, int MODE>
 __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c, const Params &p, int a_in, bool selected,
                                        int32_t *mvtab) {
+    const size_t fe = (size_t)c.first_env;
     if (MODE == kReset) {
         const bool on = c.alive && selected;          // untouched groups are written back unchanged
         p_reset(e, c, p, on);
@@ -483,8 +521,8 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c
             hd.episode += 1;
             hd.step = 0;
             if (c.gl == 0) {
-                p.o.reward[c.b] = 0.f;
-                p.o.done[c.b] = 0;
+                st_off<float>(p.o.reward + fe, c.rel * 4u, 0.f);
+                st_off<uint8_t>(p.o.done + fe, c.rel, 0);
             }
         }
     } else if (MODE == kStep) {
@@ -492,29 +530,27 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c
         const bool called = a_in != JSS_ACTION_SKIP;
         const bool done = !grp_any<G>(e.legal, c.gbase);
         if (called) hd.step += 1;
-        if (c.alive && c.gl == 0) {
-            p.o.reward[c.b] = (float)rn / (float)c.max_time_op;          // :483-493
-            p.o.done[c.b] = done ? 1 : 0;                                // :639-653
-            if (called && done) p.o.makespan[c.b] = e.t;                 // :650
-            if (p.s.counters && called) {
-                add_counters(p.s.counters + (size_t)c.b * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
-            }
+        if (c.alive && c.gl == 0 && called) {         // a skipped env keeps its reward / done / makespan
+            st_off<float>(p.o.reward + fe, c.rel * 4u, (float)rn / (float)c.max_time_op);   // :483-493
+            st_off<uint8_t>(p.o.done + fe, c.rel, done ? 1 : 0);                            // :639-653
+            if (done) st_off<int>(p.o.makespan + fe, c.rel * 4u, e.t);                      // :650
+            if (p.s.counters) add_counters(p.s.counters + (fe + c.rel) * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
         }
     } else if (MODE == kAdvance) {
         const bool on = c.alive && selected;
-        const int next_op = p_prefetch_next_op(e, c);
         const int d = p_next_event(e);
         const bool busy = d < kBig;
         if (on && !busy) e.err |= JSS_ERR_NOPE_IDLE;                     // reference: IndexError (:517)
-        const int hole = p_advance(e, c, on && busy, d, next_op);
-        if (on && c.gl == 0 && p.hole) p.hole[c.b] = busy ? hole : 0;
+        const int hole = p_advance(e, c, on && busy, d);
+        if (on && c.gl == 0 && p.hole) st_off<int>(p.hole + fe, c.rel * 4u, busy ? hole : 0);
     } else if (MODE == kPolicy) {
-        const int a = p_select(e, c, p.kind, p.seed, p.explore_q16,
-                               (uint64_t)(p.d.env_ids ? p.d.env_ids[c.b] : p.d.env_id_base + c.b), (uint32_t)hd.episode,
-                               (uint32_t)hd.step);
-        if (c.alive && c.gl == 0) p.actions_out[c.b] = a;
+        const uint64_t env_id = (uint64_t)(p.d.env_ids ? ld_off<int64_t>(p.d.env_ids + fe, c.rel * 8u)
+                                                       : p.d.env_id_base + (int64_t)(fe + c.rel));
+        const int a = p_select(e, c, p, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
+        if (c.alive && c.gl == 0) st_off<int>(p.actions_out + fe, c.rel * 4u, a);
     } else {  // kRollout / kRollout1
-        const uint64_t env_id = (uint64_t)(p.d.env_ids ? p.d.env_ids[c.b] : p.d.env_id_base + c.b);
+        const uint64_t env_id = (uint64_t)(p.d.env_ids ? ld_off<int64_t>(p.d.env_ids + fe, c.rel * 8u)
+                                                       : p.d.env_id_base + (int64_t)(fe + c.rel));
         int n_steps = 0, n_done = 0, last_rn = 0, last_makespan = -1, sum_makespan = 0, sum_rn = 0;
         const bool autoreset = (p.flags & JSS_ROLLOUT_AUTORESET) != 0;
         const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;
@@ -528,9 +564,8 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c
                 hd.episode += 1;
                 hd.step = 0;
             }
-            int a = (p.ablate & JSS_ABLATE_SELECT)
-                        ? __ffs(grp_ballot<G>(e.legal, c.gbase)) - 1
-                        : p_select(e, c, p.kind, p.seed, p.explore_q16, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
+            int a = JSS_ABLATED(p, JSS_ABLATE_SELECT) ? __ffs(grp_ballot<G>(e.legal, c.gbase)) - 1
+                                                      : p_select(e, c, p, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
             if (!do_step) a = JSS_ACTION_SKIP;
             const int rn = p_step(e, c, p, a, mvtab);
             const bool done1 = !grp_any<G>(e.legal, c.gbase);            // collective: outside the divergent branch
@@ -548,143 +583,72 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c
         }
         const bool done = !grp_any<G>(e.legal, c.gbase);
         if (c.alive && c.gl == 0) {
-            if (n_steps) p.o.reward[c.b] = (float)last_rn / (float)c.max_time_op;
-            p.o.done[c.b] = done ? 1 : 0;
-            if (last_makespan >= 0) p.o.makespan[c.b] = last_makespan;
-            if (p.s.counters) {
-                add_counters(p.s.counters + (size_t)c.b * 4, n_steps, n_done, sum_makespan, sum_rn);
-            }
+            if (n_steps) st_off<float>(p.o.reward + fe, c.rel * 4u, (float)last_rn / (float)c.max_time_op);
+            st_off<uint8_t>(p.o.done + fe, c.rel, done ? 1 : 0);
+            if (last_makespan >= 0) st_off<int>(p.o.makespan + fe, c.rel * 4u, last_makespan);
+            if (p.s.counters) add_counters(p.s.counters + (fe + c.rel) * 4, n_steps, n_done, sum_makespan, sum_rn);
         }
     }
-}
-
-// instance constants of table `tid` into the per-lane context
-template <int G>
-__device__ __forceinline__ void p_load_constants(PCtx<G> &c, const Params &p, int tid) {
-    c.J = p.d.jobs[tid];
-    c.M = p.d.machines[tid];
-    c.max_time_op = p.d.max_time_op[tid];
-    c.max_time_jobs = p.d.max_time_jobs[tid];
-    c.sum_op = p.d.sum_op[tid];
-    c.jvalid = c.gl < c.J;
-    c.mvalid = c.gl < c.M;
-    c.stride = p.stride;
 }
 
 // ---------------------------------------------------------------------------------------
 // the packed kernel, one env set (E = 64/G envs) per wave
 // ---------------------------------------------------------------------------------------
 // launch bounds: the largest occupancy each mode reaches without spilling (8 waves per SIMD = 64 VGPRs)
-template <int G, int MODE>
+template <int G, int MODE, int TAB>
 __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : (MODE == kStep ? 7 : 8)) void jss_packed_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     constexpr int E = kWave / G;                      // envs per wave
     constexpr int EB = E * kWavesPerBlock;            // envs per workgroup
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const int grp_in_block = threadIdx.x / G;
-    // obs image of this wave: E * jmax * 7 floats, 16-byte aligned (p.obs_off_ints is a multiple of 4)
-    float *scratch = reinterpret_cast<float *>(lds + p.obs_off_ints) + wave * p.obs_wave_floats;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // obs image of this wave: E * jmax * 7 floats, 16-byte aligned (table_lds_ints is a multiple of 4)
+    float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;
     int32_t *mvtab = lds + p.mv_off_ints + wave * kWave;                 // one int per lane, see p_check_no_op
 
     PCtx<G> c;
     c.lane = lane;
     c.gl = lane & (G - 1);
     c.gbase = lane & ~(G - 1);
-    const int b_raw = blockIdx.x * EB + grp_in_block;
-    const int first_env = blockIdx.x * EB + wave * E;
-    const bool wave_whole = first_env + E <= p.d.batch;
-    c.alive = b_raw < p.d.batch;
-    c.b = c.alive ? b_raw : p.d.batch - 1;
+    c.first_env = blockIdx.x * EB + wave * E;                            // wave-uniform
+    const bool wave_dead = c.first_env >= p.d.batch;                     // only in the last workgroup
+    const int e_in_wave = lane / G;
+    c.alive = c.first_env + e_in_wave < p.d.batch;
+    c.rel = (unsigned)(c.alive ? e_in_wave : (wave_dead ? 0 : p.d.batch - 1 - c.first_env));
+    const bool wave_whole = c.first_env + E <= p.d.batch;
+    const size_t fe = (size_t)c.first_env;
     // 1. state loads first: they depend on nothing but the env index
-    const PRaw<G> raw = p_issue_loads<G>(c.b, c.gl, p);
+    PRaw<G> raw;
     int a_in = JSS_ACTION_SKIP;
-    if (MODE == kStep) a_in = p.actions[c.b];
     bool selected = true;
-    if ((MODE == kReset || MODE == kAdvance) && p.which) selected = p.which[c.b] != 0;
-    // 2. instance constants + op table -> LDS
-    const int tid = p.shared_table ? 0 : (p.d.table_of_env ? p.d.table_of_env[c.b] : c.b);
-    p_load_constants(c, p, tid);
-    int32_t *table = lds + (p.shared_table ? 0 : grp_in_block * p.region_ints);
-    c.ops = table;
-    if (p.shared_table) {
-        const int n0 = p.d.jobs[0] * p.d.mmax;
-        stage_table(lds, p.d.ops, p.d.ops16, 0, n0, (int)threadIdx.x, kBlock);
-    } else {
-        const int n = c.J * p.d.mmax;
-        stage_table(table, p.d.ops, p.d.ops16, (size_t)tid * p.d.jmax * p.d.mmax, n, c.gl, G);
+    c.tid = 0;
+    if (!wave_dead) {
+        raw = p_issue_loads<G>(c, p);
+        if (MODE == kStep) a_in = ld_off<int>(p.actions + fe, c.rel * 4u);
+        if ((MODE == kReset || MODE == kAdvance) && p.which) selected = ld_off<uint8_t>(p.which + fe, c.rel) != 0;
+        if (TAB == kTabGlobal)
+            c.tid = p.d.table_of_env ? ld_off<int>(p.d.table_of_env + fe, c.rel * 4u) : (int)(fe + c.rel);
     }
-    __syncthreads();
+    // 2. instance constants; the shared op table -> LDS
+    if (TAB == kTabLds) {
+        stage_shared_table(lds, p.d.ops, p.d.inst[JSS_I_JOBS] * p.d.mmax, (int)threadIdx.x);
+        __syncthreads();
+    }
+    if (wave_dead) return;
+    const int32_t *ir = p.d.inst + (TAB == kTabLds ? 0 : (size_t)c.tid * JSS_NI);
+    c.J = ir[JSS_I_JOBS];
+    c.M = ir[JSS_I_MACHINES];
+    c.max_time_op = ir[JSS_I_MAX_TIME_OP];
+    c.jvalid = c.gl < c.J;
+    c.mvalid = c.gl < c.M;
+    c.row = (TAB == kTabLds ? lds : p.d.ops + (size_t)c.tid * p.region_ints) + (c.gl < p.d.jmax ? c.gl : 0) * p.d.mmax;
 
     PEnv<G> e;
     PHeader hd = p_unpack(e, c, raw);
     p_body<G, MODE>(e, hd, c, p, a_in, selected, mvtab);
     if (MODE == kPolicy) return;
     p_store(e, c, p, hd);
-    if (!(p.ablate & JSS_ABLATE_OBS)) p_store_obs(e, c, p, scratch, first_env, wave_whole);
-}
-
-// ---------------------------------------------------------------------------------------
-// persistent variant for shared-instance batches (kStep / kRollout1): a fixed number of waves per
-// SIMD, each looping over env sets.  The next set's state loads are issued BEFORE the current set is
-// computed and stored, so HBM traffic and VALU work overlap inside every wave instead of relying on
-// waves being out of phase (with one set per wave, the two rounds of waves of a 65 536-env launch run
-// load -> compute -> store in near lock step: profiles/README.md).
-// ---------------------------------------------------------------------------------------
-template <int G, int MODE>
-__global__ __launch_bounds__(kBlock, 4) void jss_packed_persistent(Params p) {
-    HIP_DYNAMIC_SHARED(int32_t, lds)
-    constexpr int E = kWave / G;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float *scratch = reinterpret_cast<float *>(lds + p.obs_off_ints) + wave * p.obs_wave_floats;
-    int32_t *mvtab = lds + p.mv_off_ints + wave * kWave;
-
-    PCtx<G> c;
-    c.lane = lane;
-    c.gl = lane & (G - 1);
-    c.gbase = lane & ~(G - 1);
-    const int e_in_wave = lane / G;
-    const int n_sets = (p.d.batch + E - 1) / E;
-    const int n_waves = gridDim.x * kWavesPerBlock;
-    int set = blockIdx.x * kWavesPerBlock + wave;                        // wave-uniform
-    const int last = p.d.batch - 1;
-    // first set's loads, then the shared op table
-    int b_next = imin((set < n_sets ? set : 0) * E + e_in_wave, last);
-    PRaw<G> raw = p_issue_loads<G>(b_next, c.gl, p);
-    int a_in = MODE == kStep ? p.actions[b_next] : JSS_ACTION_SKIP;
-    p_load_constants(c, p, 0);
-    c.ops = lds;
-    stage_table(lds, p.d.ops, p.d.ops16, 0, p.d.jobs[0] * p.d.mmax, (int)threadIdx.x, kBlock);
-    __syncthreads();
-    if (set >= n_sets) return;
-
-    for (;;) {
-        const int first_env = set * E;
-        const int b_raw = first_env + e_in_wave;
-        c.alive = b_raw < p.d.batch;
-        c.b = c.alive ? b_raw : last;
-        const bool wave_whole = first_env + E <= p.d.batch;
-        // prefetch: the next set's state is in flight while this one is computed and stored
-        const int next = set + n_waves;
-        const bool has_next = next < n_sets;                             // wave-uniform
-        PRaw<G> raw_next = raw;
-        int a_next = JSS_ACTION_SKIP;
-        if (has_next) {
-            b_next = imin(next * E + e_in_wave, last);
-            raw_next = p_issue_loads<G>(b_next, c.gl, p);
-            if (MODE == kStep) a_next = p.actions[b_next];
-        }
-        PEnv<G> e;
-        PHeader hd = p_unpack(e, c, raw);
-        p_body<G, MODE>(e, hd, c, p, a_in, true, mvtab);
-        p_store(e, c, p, hd);
-        if (!(p.ablate & JSS_ABLATE_OBS)) p_store_obs(e, c, p, scratch, first_env, wave_whole);
-        if (!has_next) break;
-        raw = raw_next;
-        a_in = a_next;
-        set = next;
-    }
+    if (!JSS_ABLATED(p, JSS_ABLATE_OBS)) p_store_obs<G, TAB>(e, c, p, scratch, wave_whole);
 }
 
 }  // namespace jss

@@ -1,6 +1,10 @@
 #pragma once
 // Wave-per-env kernel: one 64-lane wavefront simulates one env (J <= 128, M <= 64).
+// Job j on lane j % 64, slot j / 64 (JPL = 1 or 2 slots); machine m on lane m.  The legal / blocked
+// job sets are wave-uniform 64-bit masks (SGPR pairs): nb_legal_actions is one s_bcnt1, "any legal"
+// one s_cmp, and the data-dependent while-loops of step() are scalar branches.
 #include "jss_common.hpp"
+#include "jss_packed_env.hpp"   // ld_off / st_off
 
 namespace jss {
 
@@ -8,8 +12,9 @@ namespace jss {
 struct Ctx {
     int b;
     int J, M;
-    int max_time_op, max_time_jobs, sum_op;
-    const int32_t *ops;  // LDS, row stride `stride`
+    int max_time_op;
+    int tid;
+    const int32_t *tab;  // op table of my env (LDS with kTabLds, global with kTabGlobal), row stride `stride`
     int stride;
     int lane;
 };
@@ -17,9 +22,8 @@ struct Ctx {
 template <int JPL>
 struct Env {
     int t;                                                               // current_time_step
-    int todo[JPL], cur[JPL], left[JPL], perf[JPL], idle[JPL], idle_last[JPL], f4[JPL];
+    int todo[JPL], cur[JPL], nxt[JPL], left[JPL], perf[JPL], idle[JPL], idle_last[JPL], f4[JPL];
     uint64_t legal[JPL], blocked[JPL];                                   // job sets, wave-uniform
-    uint64_t valid[JPL];                                                 // lanes holding a real job
     int tm;                                                              // lane m: time_until_available_machine[m]
     int noop;                                                            // legal_actions[J]
     int err;
@@ -60,20 +64,20 @@ __device__ __forceinline__ void reset_env(Env<JPL> &e, const Ctx &c, const Param
     e.err = 0;
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
-        int j = s * kWave + c.lane;
-        bool v = j < c.J;
-        e.valid[s] = __ballot(v);
+        const int j = s * kWave + c.lane;
+        const bool v = j < c.J;
         e.todo[s] = 0;                                                   // :166
-        e.cur[s] = v ? c.ops[j * c.stride] : -1;                         // :174-176 needed machine = op 0
+        e.cur[s] = v ? c.tab[j * c.stride] : -1;                         // :174-176 needed machine = op 0
+        e.nxt[s] = (v && 1 < c.M) ? c.tab[j * c.stride + 1] : -1;
         e.left[s] = e.perf[s] = e.idle[s] = e.idle_last[s] = 0;          // :165-170
         e.f4[s] = 0;                                                     // :180 state zeros
-        e.legal[s] = e.valid[s];                                         // :160
+        e.legal[s] = __ballot(v);                                        // :160
         e.blocked[s] = 0;                                                // :171-172
     }
     // solution = -1 (:163); coalesced rows of the padded [jmax][mmax] block
     int32_t *sol = p.s.solution + (size_t)c.b * p.d.jmax * p.d.mmax;
-    int n = c.J * p.d.mmax;
-    for (int i = c.lane; i < n; i += kWave) sol[i] = -1;
+    const int n = c.J * p.d.mmax;
+    for (int i = c.lane; i < n; i += kWave) st_off<int>(sol, (unsigned)i * 4u, -1);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -89,7 +93,7 @@ __device__ __forceinline__ int advance(Env<JPL> &e, const Ctx &c) {
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {                                      // job loop :525-601
         const int was = e.left[s];
-        const bool v = (e.valid[s] >> c.lane) & 1;
+        const bool v = s * kWave + c.lane < c.J;
         fin[s] = false;
         if (was > 0) {                                                   // :529 running
             const int nl = imax(0, was - d);                             // :534
@@ -115,16 +119,17 @@ __device__ __forceinline__ int advance(Env<JPL> &e, const Ctx &c) {
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
-        int ncur = e.cur[s];
-        if (fin[s]) ncur = (e.todo[s] < c.M) ? c.ops[j * c.stride + e.todo[s]] : -1;  // :562-566 / :581
-        e.cur[s] = ncur;
+        if (fin[s]) {                                                    // :562-566 / :581: the job moves on to the op its
+            e.cur[s] = e.nxt[s];                                         // record carries; the op after that is the only
+            e.nxt[s] = (e.todo[s] + 1 < c.M) ? c.tab[j * c.stride + e.todo[s] + 1] : -1;   // op table read of the step
+        }
+        const int ncur = e.cur[s];
         // feature 4 numerator: max(0, tm_old[need] - d) (:569-578) == tm_new[need]
         const int tm_need = __shfl(e.tm, (ncur >> 16) & 63);
         if (fin[s]) e.f4[s] = ncur >= 0 ? tm_need : JSS_F4_ONE;          // :586 "1.0" when the job is complete
         // re-legalisation :616-634: need[j] on a free machine, not legal, not blocked.
         // (a job that just completed has cur = -1 and is never legal, :589-591)
-        const bool v = (e.valid[s] >> c.lane) & 1;
-        const bool can = v && ncur >= 0 && ((free_m >> ((ncur >> 16) & 63)) & 1);
+        const bool can = j < c.J && ncur >= 0 && ((free_m >> ((ncur >> 16) & 63)) & 1);
         e.legal[s] |= __ballot(can) & ~e.blocked[s];
     }
     return hole;
@@ -147,11 +152,10 @@ __device__ __forceinline__ void prioritize(Env<JPL> &e, const Ctx &c) {
     bool nf[JPL];
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
-        const int j = s * kWave + c.lane;
         const bool lg = (e.legal[s] >> c.lane) & 1;
         nf[s] = false;
         if (lg && e.todo[s] < c.M - 1) {                                 // :219-239 non-final, next machine idle
-            const int next_m = c.ops[j * c.stride + e.todo[s] + 1] >> 16;  // :227
+            const int next_m = e.nxt[s] >> 16;                           // :227
             nf[s] = (free_m >> next_m) & 1;                              // :234
         }
     }
@@ -175,6 +179,17 @@ __device__ __forceinline__ void prioritize(Env<JPL> &e, const Ctx &c) {
 // ---------------------------------------------------------------------------------------
 // _check_no_op(): jss_env.py:256-401
 // ---------------------------------------------------------------------------------------
+struct Horizon {   // pass-1 result: the <= 3 legal machines, their max_horizon_machine, max_horizon
+    int mm0, mm1, mm2, mv0, mv1, mv2, mh;
+};
+__device__ __forceinline__ int walk_op(const Horizon &hz, int op, int tn, int &u) {   // :346-351, :362
+    const int m = op >> 16;
+    if (m == hz.mm0 && hz.mv0 > tn) u |= 1;
+    if (m == hz.mm1 && hz.mv1 > tn) u |= 2;
+    if (m == hz.mm2 && hz.mv2 > tn) u |= 4;
+    return tn + (op & kDurMask);
+}
+
 template <int JPL>
 __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
     e.noop = 0;                                                          // :278
@@ -184,8 +199,8 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
     if (busy == 0) return;                                               // :285 len(next_time_step) > 0
     // PASS 1 (:305-321): sequential in ascending job index over the <= 4 legal jobs; max_horizon
     // sees the running prefix minimum of max_horizon_machine, so the order matters.
-    int mm0 = -1, mm1 = -1, mm2 = -1;        // the <= 3 legal machines ...
-    int mv0 = 0, mv1 = 0, mv2 = 0;           // ... and their max_horizon_machine
+    Horizon hz;
+    hz.mm0 = hz.mm1 = hz.mm2 = -1;           // the <= 3 legal machines ...
     int n_ml = 0;                            // nb_machine_legal
     int cf[4];                               // packed current op of the i-th legal job (ascending job index)
     {
@@ -212,16 +227,16 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
     for (int i = 0; i < 4; ++i) {
         if (i < nl) {
             const int m = cf[i] >> 16;
-            if (m != mm0 && m != mm1 && m != mm2) {
-                if (n_ml == 0) mm0 = m; else if (n_ml == 1) mm1 = m; else if (n_ml == 2) mm2 = m;
+            if (m != hz.mm0 && m != hz.mm1 && m != hz.mm2) {
+                if (n_ml == 0) hz.mm0 = m; else if (n_ml == 1) hz.mm1 = m; else if (n_ml == 2) hz.mm2 = m;
                 ++n_ml;
             }
         }
     }
     if (n_ml > 3) return;                                                // :286
     const int nxt = e.t + wave_min(e.tm > 0 ? e.tm : kBig);              // :293 next_time_step[0]
-    int mh = e.t;                                                        // :296
-    mv0 = mv1 = mv2 = e.t + c.max_time_op;                               // :300-302
+    hz.mh = e.t;                                                         // :296
+    hz.mv0 = hz.mv1 = hz.mv2 = e.t + c.max_time_op;                      // :300-302
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i < nl) {
@@ -229,18 +244,20 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
             const int end = e.t + (cf[i] & kDurMask);                    // :310
             if (end < nxt) return;                                       // :314-315
             int h;
-            if (m == mm0) { mv0 = imin(mv0, end); h = mv0; }             // :318
-            else if (m == mm1) { mv1 = imin(mv1, end); h = mv1; }
-            else { mv2 = imin(mv2, end); h = mv2; }
-            mh = imax(mh, h);                                            // :321
+            if (m == hz.mm0) { hz.mv0 = imin(hz.mv0, end); h = hz.mv0; } // :318
+            else if (m == hz.mm1) { hz.mv1 = imin(hz.mv1, end); h = hz.mv1; }
+            else { hz.mv2 = imin(hz.mv2, end); h = hz.mv2; }
+            hz.mh = imax(hz.mh, h);                                      // :321
         }
     }
-    // PASS 2 (:324-401): every illegal job walks its future ops; order-free, so one lane per job.
+    // PASS 2 (:324-401): every illegal job walks its future ops; order-free, so one lane per job.  The first
+    // ops of the walk are the ones the job record carries (current, next); only a longer walk reads the op table.
     int u = 0;  // bit i: legal machine i "would be better used by waiting"
+    const int last = c.M - 1;
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
-        const bool v = (e.valid[s] >> c.lane) & 1;
+        const bool v = j < c.J;
         const bool lg = (e.legal[s] >> c.lane) & 1;
         const bool bl = (e.blocked[s] >> c.lane) & 1;
         const bool caseA = v && !lg && e.left[s] > 0 && e.todo[s] + 1 < c.M;      // :327-330
@@ -248,16 +265,28 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
         const int tm_need = __shfl(e.tm, (e.cur[s] >> 16) & 63);                   // :376
         int k = caseA ? e.todo[s] + 1 : e.todo[s];                                // :332 / :370
         int tn = caseA ? e.t + e.left[s] : e.t + tm_need;                         // :334-337 / :374-377
-        if (caseA || caseB) {
-            while (k < c.M - 1 && mh > tn) {                                       // :340-342 / :380-382
-                const int op = c.ops[j * c.stride + k];
-                const int m = op >> 16;
-                if (m == mm0 && mv0 > tn) u |= 1;                                  // :346-351 (mm* are the legal machines)
-                if (m == mm1 && mv1 > tn) u |= 2;
-                if (m == mm2 && mv2 > tn) u |= 4;
-                tn += op & kDurMask;                                               // :362
+        bool go = (caseA || caseB) && k < last && hz.mh > tn;                     // :340-342 / :380-382
+        if (go && caseB) {                                                        // op k == todo: the current op
+            tn = walk_op(hz, e.cur[s], tn, u);
+            ++k;
+            go = k < last && hz.mh > tn;
+        }
+        if (go) {                                                                 // op k == todo + 1: the next op
+            tn = walk_op(hz, e.nxt[s], tn, u);
+            ++k;
+            go = k < last && hz.mh > tn;
+        }
+        if (go) {                                                                 // further: the op table, two entries per trip
+            const int32_t *row = c.tab + j * c.stride;
+            do {
+                const int op0 = row[k], op1 = row[k + 1];                         // k + 1 <= M - 1: inside the row
+                tn = walk_op(hz, op0, tn, u);
                 ++k;
-            }
+                if (k < last && hz.mh > tn) {
+                    tn = walk_op(hz, op1, tn, u);
+                    ++k;
+                }
+            } while (k < last && hz.mh > tn);
         }
     }
     const int covered = (__ballot(u & 1) != 0) + (__ballot(u & 2) != 0) + (__ballot(u & 4) != 0);
@@ -310,15 +339,14 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
         if (c.lane == 0) p.s.solution[((size_t)c.b * p.d.jmax + a) * p.d.mmax + k] = e.t;  // :454
 #pragma unroll
         for (int s = 0; s < JPL; ++s) {
-            const bool v = (e.valid[s] >> c.lane) & 1;
-            const uint64_t same = __ballot(v && e.cur[s] >= 0 && (e.cur[s] >> 16) == m);
+            const uint64_t same = __ballot(e.cur[s] >= 0 && (e.cur[s] >> 16) == m);   // padding lanes hold cur = -1
             e.legal[s] &= ~same;                                         // :455-463
             e.blocked[s] &= ~same;                                       // :464-467
         }
-        while (!any_legal(e) && __ballot(e.tm > 0) != 0 && !(p.ablate & JSS_ABLATE_ADVANCE)) rn -= advance(e, c);  // :469-470
+        while (!any_legal(e) && __ballot(e.tm > 0) != 0 && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) rn -= advance(e, c);  // :469-470
     }
-    if (!(p.ablate & JSS_ABLATE_PRIORITIZE)) prioritize(e, c);           // :432 / :471
-    if (!(p.ablate & JSS_ABLATE_CHECK_NO_OP)) check_no_op(e, c);         // :433 / :472
+    if (!JSS_ABLATED(p, JSS_ABLATE_PRIORITIZE)) prioritize(e, c);        // :432 / :471
+    if (!JSS_ABLATED(p, JSS_ABLATE_CHECK_NO_OP)) check_no_op(e, c);      // :433 / :472
     return rn;
 }
 
@@ -332,14 +360,15 @@ __device__ __forceinline__ int nth_set_bit(uint64_t mask, int n, int lane) {
 }
 
 template <int JPL>
-__device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, int kind, uint64_t seed, uint32_t explore_q16,
-                                             uint64_t env_id, uint32_t episode, uint32_t step) {
+__device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, const Params &p, uint64_t env_id,
+                                             uint32_t episode, uint32_t step) {
+    const int kind = p.kind;
     const int nl = nb_legal(e);
     const int n = nl + (e.noop ? 1 : 0);
     if (n == 0) return -1;
     if (kind == JSS_POLICY_RANDOM) {
         // README.md:58-60: uniform over the set bits of the mask, NOPE included
-        const uint32_t r = rng_u32(seed, env_id, episode, step);
+        const uint32_t r = rng_u32(p.seed, env_id, episode, step);
         int pick = (int)__umulhi(r, (uint32_t)n);
         int a = c.J;
         bool found = false;
@@ -357,6 +386,8 @@ __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, in
     }
     if (nl == 0) return c.J;  // only NOPE is legal (dispatching.py:96-97)
     int a = -1;
+    // remaining-work table of my env: rem[j][k] = durations of ops k..M-1 of job j (MWR / LWR / CR)
+    const int32_t *rem = p.d.rem + (size_t)c.tid * p.region_ints;
     if (kind == JSS_POLICY_CR) {                                         // dispatching.py:365-408
         CrKey best;
         best.num = 0x3fffffff;
@@ -366,16 +397,9 @@ __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, in
         for (int s = 0; s < JPL; ++s) {
             const int j = s * kWave + c.lane;
             const bool lg = (e.legal[s] >> c.lane) & 1;
-            int total = 0, remaining = 0;
-            if (lg)
-                for (int k = 0; k < c.M; ++k) {
-                    const int d = c.ops[j * c.stride + k] & kDurMask;
-                    total += d;
-                    if (k >= e.todo[s]) remaining += d;
-                }
             CrKey key;
-            key.num = lg ? 3 * total - 2 * e.t : 0x3fffffff;
-            key.den = lg ? remaining : 1;
+            key.num = lg ? 3 * rem[j * c.stride] - 2 * e.t : 0x3fffffff; // :373 job length
+            key.den = lg ? rem[j * c.stride + e.todo[s]] : 1;            // :391 remaining work
             key.idx = lg ? j : kCrNone;
             if (cr_better(key, best)) best = key;
         }
@@ -392,11 +416,7 @@ __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, in
             if (kind == JSS_POLICY_FIFO) v = e.idle_last[s];                 // dispatching.py:146
             else if (kind == JSS_POLICY_SPT) v = e.cur[s] & kDurMask;        // :105-106
             else if (kind == JSS_POLICY_MOR || kind == JSS_POLICY_LOR) v = c.M - e.todo[s];  // :273 / :314
-            else {                                                           // MWR / LWR :187-189 / :230-232
-                v = 0;
-                if (lg)
-                    for (int k = e.todo[s]; k < c.M; ++k) v += c.ops[j * c.stride + k] & kDurMask;
-            }
+            else v = lg ? rem[j * c.stride + e.todo[s]] : 0;                 // MWR / LWR :187-189 / :230-232
             key[s] = lg ? (larger ? v : -v) : -kBig;
         }
         int best = key[0];
@@ -409,22 +429,23 @@ __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, in
             if (a < 0 && hit) a = s * kWave + __ffsll((unsigned long long)hit) - 1;
         }
     }
-    if (e.noop && explore_q16 != 0) {                                    // dispatching.py:113: 10 % NOPE when NOPE is legal
-        const uint32_t r = rng_u32(seed ^ kExploreSeedXor, env_id, episode, step);
-        if ((r >> 16) < explore_q16) a = c.J;
+    if (e.noop && p.explore_q16 != 0) {                                  // dispatching.py:113: 10 % NOPE when NOPE is legal
+        const uint32_t r = rng_u32(p.seed ^ kExploreSeedXor, env_id, episode, step);
+        if ((r >> 16) < p.explore_q16) a = c.J;
     }
     return a;
 }
 
 // ---------------------------------------------------------------------------------------
 // HBM <-> registers.  One 32-byte record per job (two dwordx4 per lane), one int4 header per env.
+// The env index is wave-uniform, so every base is an SGPR pair and the lane offset 32 bits.
 // ---------------------------------------------------------------------------------------
 struct Header {
-    int clock, episode, step, status;
+    int episode, step;
 };
 
 template <int JPL>
-struct RawEnv {  // loads issued before the op table is staged; unpacked after the barrier
+struct RawEnv {  // loads issued first; unpacked once the instance record is known
     int4 h;
     int4 lo[JPL], hi[JPL];
     int tm;
@@ -434,15 +455,15 @@ template <int JPL>
 __device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params &p) {
     RawEnv<JPL> r;
     const int jm = p.d.jmax;
-    r.h = reinterpret_cast<const int4 *>(p.s.env)[b];
-    const int4 *js = reinterpret_cast<const int4 *>(p.s.job) + (size_t)b * jm * 2;
-    r.tm = p.s.machine[(size_t)b * p.d.mmax + (lane < p.d.mmax ? lane : 0)];
+    r.h = *reinterpret_cast<const int4 *>(p.s.env + (size_t)b * 4);
+    const int32_t *jb = p.s.job + (size_t)b * jm * JSS_NF;
+    r.tm = ld_off<int>(p.s.machine + (size_t)b * p.d.mmax, (unsigned)(lane < p.d.mmax ? lane : 0) * 4u);
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + lane;
-        const int jc = j < jm ? j : 0;
-        r.lo[s] = js[jc * 2];
-        r.hi[s] = js[jc * 2 + 1];
+        const unsigned jo = (unsigned)(j < jm ? j : 0) * 32u;
+        r.lo[s] = ld_off<int4>(jb, jo);
+        r.hi[s] = ld_off<int4>(jb, jo + 16u);
     }
     return r;
 }
@@ -450,29 +471,28 @@ __device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params
 template <int JPL>
 __device__ __forceinline__ Header unpack_env(Env<JPL> &e, const Ctx &c, const RawEnv<JPL> &r) {
     Header hd;
-    hd.clock = __builtin_amdgcn_readfirstlane(r.h.x);
+    const int status = __builtin_amdgcn_readfirstlane(r.h.w);
     hd.episode = __builtin_amdgcn_readfirstlane(r.h.y);
     hd.step = __builtin_amdgcn_readfirstlane(r.h.z);
-    hd.status = __builtin_amdgcn_readfirstlane(r.h.w);
-    e.t = hd.clock;
-    e.err = hd.status & 0xFF;
-    e.noop = (hd.status & JSS_STATUS_NOOP) ? 1 : 0;
+    e.t = __builtin_amdgcn_readfirstlane(r.h.x);
+    e.err = status & 0xFF;
+    e.noop = (status & JSS_STATUS_NOOP) ? 1 : 0;
     e.tm = c.lane < c.M ? r.tm : 0;
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         const bool v = j < c.J;
         const int4 lo = r.lo[s], hi = r.hi[s];
-        e.valid[s] = __ballot(v);
-        e.todo[s] = v ? lo.x : 0;
+        e.todo[s] = v ? (lo.x & JSS_TODO_MASK) : 0;
         e.cur[s] = v ? lo.y : -1;
         e.left[s] = v ? lo.z : 0;
         e.perf[s] = v ? lo.w : 0;
         e.idle[s] = v ? hi.x : 0;
         e.idle_last[s] = v ? hi.y : 0;
         e.f4[s] = v ? hi.z : 0;
-        e.legal[s] = __ballot(v && (hi.w & JSS_FLAG_LEGAL));
-        e.blocked[s] = __ballot(v && (hi.w & JSS_FLAG_BLOCKED));
+        e.nxt[s] = v ? hi.w : -1;
+        e.legal[s] = __ballot(v && (lo.x & JSS_FLAG_LEGAL));
+        e.blocked[s] = __ballot(v && (lo.x & JSS_FLAG_BLOCKED));
     }
     return hd;
 }
@@ -480,23 +500,25 @@ __device__ __forceinline__ Header unpack_env(Env<JPL> &e, const Ctx &c, const Ra
 template <int JPL>
 __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p, const Header &hd) {
     const int jm = p.d.jmax;
-    int4 *js = reinterpret_cast<int4 *>(p.s.job) + (size_t)c.b * jm * 2;
+    int32_t *jb = p.s.job + (size_t)c.b * jm * JSS_NF;
     uint8_t *mk = p.o.action_mask + (size_t)c.b * (jm + 1);
     if (c.lane == 0) {
-        reinterpret_cast<int4 *>(p.s.env)[c.b] =
+        *reinterpret_cast<int4 *>(p.s.env + (size_t)c.b * 4) =
             make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
-        mk[c.J] = (uint8_t)e.noop;
+        mk[jm] = (uint8_t)(c.J == jm ? e.noop : 0);                      // last byte of the row (lanes cover 0..jmax-1)
     }
-    if (c.lane < c.M) p.s.machine[(size_t)c.b * p.d.mmax + c.lane] = e.tm;
+    if (c.lane < c.M) st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
+        const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = (int)((e.blocked[s] >> c.lane) & 1);
         if (j < c.J) {
-            const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = (int)((e.blocked[s] >> c.lane) & 1);
-            js[j * 2] = make_int4(e.todo[s], e.cur[s], e.left[s], e.perf[s]);
-            js[j * 2 + 1] = make_int4(e.idle[s], e.idle_last[s], e.f4[s], lg | (bl << 1));
-            mk[j] = (uint8_t)lg;
+            st_off<int4>(jb, (unsigned)j * 32u, make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0),
+                                                          e.cur[s], e.left[s], e.perf[s]));
+            st_off<int4>(jb, (unsigned)j * 32u + 16u, make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]));
         }
+        // action mask: legal jobs, the NOPE flag at index J, zeros behind it
+        if (j < jm) st_off<uint8_t>(mk, (unsigned)j, (uint8_t)(j < c.J ? lg : (j == c.J ? e.noop : 0)));
     }
 }
 
@@ -505,8 +527,11 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
 // op finishes).  Transposed through LDS so the HBM write is jmax*7 contiguous floats.
 template <int JPL>
 __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const Params &p, float *scratch) {
-    const float f_op = (float)c.max_time_op, f_jobs = (float)c.max_time_jobs, f_sum = (float)c.sum_op, f_m = (float)c.M;
-    const float r_op = refined_rcp(f_op), r_jobs = refined_rcp(f_jobs), r_sum = refined_rcp(f_sum), r_m = refined_rcp(f_m);
+    const int32_t *ir = p.d.inst + (size_t)c.tid * JSS_NI;
+    const float f_op = (float)c.max_time_op, f_jobs = (float)ir[JSS_I_MAX_TIME_JOBS], f_sum = (float)ir[JSS_I_SUM_OP];
+    const float f_m = (float)c.M;
+    const float r_op = as_float(ir[JSS_I_RCP_MAX_TIME_OP]), r_jobs = as_float(ir[JSS_I_RCP_MAX_TIME_JOBS]);
+    const float r_sum = as_float(ir[JSS_I_RCP_SUM_OP]), r_m = as_float(ir[JSS_I_RCP_MACHINES]);
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
@@ -525,21 +550,34 @@ __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const
     wave_lds_sync();
     float *dst = p.o.real_obs + (size_t)c.b * p.d.jmax * 7;
     const int n = p.d.jmax * 7;
-    for (int i = c.lane; i < n; i += kWave) dst[i] = scratch[i];
+    if ((n & 3) == 0 && (((size_t)c.b * n) & 3) == 0) {
+        for (int i = c.lane; i < (n >> 2); i += kWave)
+            st_off<float4>(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+    } else {
+        for (int i = c.lane; i < n; i += kWave) st_off<float>(dst, (unsigned)i * 4u, scratch[i]);
+    }
     wave_lds_sync();
 }
 
 // ---------------------------------------------------------------------------------------
 // the kernel: one mode per instantiation
 // ---------------------------------------------------------------------------------------
-template <int JPL, int MODE>
-__global__ __launch_bounds__(kBlock, (MODE == kRollout && JPL == 2) ? 6 : 8) void jss_kernel(Params p) {
+// Occupancy bound: 8 waves per SIMD keeps 8 192 envs (BASELINE config 4's share of one GPU) in ONE round of resident
+// waves; the price is an SGPR budget of 80, which the step/rollout modes overrun by 30-60 values that live in spare
+// VGPR lanes (v_writelane / v_readlane, no scratch).  JSS_WAVE_MIN_BLOCKS = 7 lifts the budget to 102 (A/B builds).
+// Two jobs per lane (J > 64) runs at 7 (6 for the multi-iteration rollout): at 8 it would spill VGPRs to scratch.
+#ifndef JSS_WAVE_MIN_BLOCKS
+#define JSS_WAVE_MIN_BLOCKS 8
+#endif
+template <int JPL, int MODE, int TAB>
+__global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE == kRollout1)
+                                         ? (JPL == 2 ? (MODE == kRollout ? 6 : 7) : JSS_WAVE_MIN_BLOCKS)
+                                         : 8) void jss_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n_regions = p.shared_table ? 1 : kWavesPerBlock;
-    int32_t *table = lds + (p.shared_table ? 0 : wave * p.region_ints);
-    float *scratch = reinterpret_cast<float *>(lds + n_regions * p.region_ints) + wave * (p.d.jmax * 7);
+    // obs image of this wave, 16-byte aligned (table_lds_ints and obs_wave_floats are multiples of 4)
+    float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;
 
     const int b_raw = blockIdx.x * kWavesPerBlock + wave;                 // one env per wave
     const bool alive = b_raw < p.d.batch;
@@ -550,26 +588,23 @@ __global__ __launch_bounds__(kBlock, (MODE == kRollout && JPL == 2) ? 6 : 8) voi
     if (MODE == kStep) a_in = __builtin_amdgcn_readfirstlane(p.actions[b]);
     bool selected = true;
     if ((MODE == kReset || MODE == kAdvance) && p.which) selected = __builtin_amdgcn_readfirstlane((int)p.which[b]) != 0;
-    // 2. instance constants + op table -> LDS
-    const int tid = __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : (p.d.n_tables == 1 ? 0 : b));
+    // 2. instance record; the shared op table -> LDS
     Ctx c;
     c.b = b;
     c.lane = lane;
-    c.J = __builtin_amdgcn_readfirstlane(p.d.jobs[tid]);
-    c.M = __builtin_amdgcn_readfirstlane(p.d.machines[tid]);
-    c.max_time_op = __builtin_amdgcn_readfirstlane(p.d.max_time_op[tid]);
-    c.max_time_jobs = __builtin_amdgcn_readfirstlane(p.d.max_time_jobs[tid]);
-    c.sum_op = __builtin_amdgcn_readfirstlane(p.d.sum_op[tid]);
-    c.ops = table;
-    c.stride = p.stride;
-    if (p.shared_table) {
-        const int n0 = p.d.jobs[0] * p.d.mmax;
-        stage_table(lds, p.d.ops, p.d.ops16, 0, n0, (int)threadIdx.x, kBlock);
+    c.tid = TAB == kTabLds ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : b);
+    const int32_t *ir = p.d.inst + (size_t)c.tid * JSS_NI;
+    c.J = __builtin_amdgcn_readfirstlane(ir[JSS_I_JOBS]);
+    c.M = __builtin_amdgcn_readfirstlane(ir[JSS_I_MACHINES]);
+    c.max_time_op = __builtin_amdgcn_readfirstlane(ir[JSS_I_MAX_TIME_OP]);
+    c.stride = p.d.mmax;
+    if (TAB == kTabLds) {
+        stage_shared_table(lds, p.d.ops, c.J * p.d.mmax, (int)threadIdx.x);
+        __syncthreads();
+        c.tab = lds;
     } else {
-        const int n = c.J * p.d.mmax;
-        stage_table(table, p.d.ops, p.d.ops16, (size_t)tid * p.d.jmax * p.d.mmax, n, lane, kWave);
+        c.tab = p.d.ops + (size_t)c.tid * p.region_ints;
     }
-    __syncthreads();
     if (!alive) return;
 
     Env<JPL> e;
@@ -588,13 +623,11 @@ __global__ __launch_bounds__(kBlock, (MODE == kRollout && JPL == 2) ? 6 : 8) voi
         const bool called = a_in != JSS_ACTION_SKIP;
         const bool done = !any_legal(e);
         if (called) hd.step += 1;
-        if (lane == 0) {
-            p.o.reward[b] = (float)rn / (float)c.max_time_op;            // :483-493 (0 for skipped / ignored actions)
+        if (lane == 0 && called) {                                       // a skipped env keeps its reward / done / makespan
+            p.o.reward[b] = (float)rn / (float)c.max_time_op;            // :483-493 (0 for ignored actions)
             p.o.done[b] = done ? 1 : 0;                                  // :639-653
-            if (called && done) p.o.makespan[b] = e.t;                   // last_time_step :650
-            if (p.s.counters && called) {
-                add_counters(p.s.counters + (size_t)b * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
-            }
+            if (done) p.o.makespan[b] = e.t;                             // last_time_step :650
+            if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
         }
     } else if (MODE == kAdvance) {
         if (!selected) return;
@@ -603,7 +636,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kRollout && JPL == 2) ? 6 : 8) voi
         else hole = advance(e, c);
         if (lane == 0 && p.hole) p.hole[b] = hole;
     } else if (MODE == kPolicy) {
-        const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, (uint64_t)(p.d.env_ids ? p.d.env_ids[b] : p.d.env_id_base + b),
+        const int a = select_action(e, c, p, (uint64_t)(p.d.env_ids ? p.d.env_ids[b] : p.d.env_id_base + b),
                                     (uint32_t)hd.episode, (uint32_t)hd.step);
         if (lane == 0) p.actions_out[b] = a;
         return;
@@ -620,8 +653,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kRollout && JPL == 2) ? 6 : 8) voi
                 hd.step = 0;
                 continue;
             }
-            const int a = select_action(e, c, p.kind, p.seed, p.explore_q16, env_id, (uint32_t)hd.episode,
-                                        (uint32_t)hd.step);
+            const int a = select_action(e, c, p, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
             last_rn = step_env(e, c, p, a);
             hd.step += 1;
             n_steps += 1;
@@ -636,13 +668,11 @@ __global__ __launch_bounds__(kBlock, (MODE == kRollout && JPL == 2) ? 6 : 8) voi
             if (n_steps) p.o.reward[b] = (float)last_rn / (float)c.max_time_op;
             p.o.done[b] = any_legal(e) ? 0 : 1;
             if (last_makespan >= 0) p.o.makespan[b] = last_makespan;
-            if (p.s.counters) {
-                add_counters(p.s.counters + (size_t)b * 4, n_steps, n_done, sum_makespan, sum_rn);
-            }
+            if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, n_steps, n_done, sum_makespan, sum_rn);
         }
     }
     store_env(e, c, p, hd);
-    if (!(p.ablate & JSS_ABLATE_OBS)) store_obs(e, c, p, scratch);
+    if (!JSS_ABLATED(p, JSS_ABLATE_OBS)) store_obs(e, c, p, scratch);
 }
 
 }  // namespace jss

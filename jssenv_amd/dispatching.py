@@ -162,6 +162,17 @@ class CriticalRatio(DispatchingRule):                                     # disp
             self._due_dates[job] = total * self.due_date_factor
         return self._due_dates[job]
 
+    def _best_job(self, env, legal_actions) -> int:
+        # the device selector compares (3 * job_length - 2 * now) / remaining, i.e. a due-date factor of exactly 1.5;
+        # any other factor takes the host loop
+        if self.due_date_factor != 1.5:
+            saved, self.kind = self.kind, None
+            try:
+                return super()._best_job(env, legal_actions)
+            finally:
+                self.kind = saved
+        return super()._best_job(env, legal_actions)
+
     def _value(self, env, job):
         remaining = _remaining_work(env, job)
         time_remaining = self._calculate_due_date(env, job) - env.current_time_step

@@ -8,8 +8,15 @@ single-env view with the reference's exact surface
 False, {})``, ``get_legal_actions()``, ``increase_time_step()`` and the public
 attributes its tests and dispatching rules read).
 
-There is no CPU path: constructing an env without a GPU (or without the built
-extension) raises.  torch is used for device memory and streams only.
+Two backends implement the same C ABI:
+
+* ``HipBackend`` (default): torch.cuda tensors + ``libjss_hip.so``.  Constructing it
+  without a GPU or without the built extension raises -- there is NO silent fallback.
+* ``CpuBackend`` (``device="cpu"``, explicit only): NumPy arrays + ``libjss_cpu.so``,
+  the from-scratch C++/OpenMP twin with identical symbols (BASELINE config 1, "runs
+  without a GPU"; also bench.py's ``cpu_baseline`` kind "twin").
+
+torch is used for device memory and streams only.
 """
 from __future__ import annotations
 
@@ -22,25 +29,35 @@ import numpy as np
 from . import _abi
 from .instances import Instance, PackedBatch, pack_batch, resolve_instance
 
-_NP = {"int32": np.int32, "int64": np.int64, "uint8": np.uint8, "float32": np.float32}
-
 
 class HipBackend:
     """Device memory = torch.cuda tensors; kernels = libjss_hip.so on torch's current stream."""
 
     name = "hip"
+    default_kernel = "auto"
 
     def __init__(self, device=None):
         import torch
         if not torch.cuda.is_available():
-            raise RuntimeError("jssenv_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU path")
+            raise RuntimeError("jssenv_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no silent "
+                               "CPU fallback -- pass device='cpu' to run on the host-core twin (libjss_cpu.so) on purpose")
         path = _abi.library_path()
         if not os.path.isfile(path):
             raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
         self.torch = torch
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise ValueError(f"HipBackend needs a cuda device, got {self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = _abi.bind(C.CDLL(path))
+        if not self.lib.jss_backend().startswith(b"hip"):
+            raise RuntimeError(f"{path} is not the HIP library ({self.lib.jss_backend()!r})")
+        self._side = []          # side streams for rollout_steps (sub-batch pipelining)
+        self._fork = None
+        self._join = []
 
+    # -- memory ----------------------------------------------------------------------------
     def zeros(self, shape, dtype):
         return self.torch.zeros(shape, dtype=getattr(self.torch, dtype), device=self.device)
 
@@ -53,24 +70,137 @@ class HipBackend:
     def numpy(self, x):
         return x.detach().cpu().numpy()
 
+    def as_device(self, x, dtype):
+        t = self.torch.as_tensor(x, device=self.device)
+        return t.to(getattr(self.torch, dtype)).contiguous()
+
+    def copy_into(self, dst, src):
+        if isinstance(src, np.ndarray):
+            src = self.torch.from_numpy(np.ascontiguousarray(src))
+        dst.copy_(src)
+
+    def select_into(self, out, cond, a, b):
+        """out[...] = where(cond, a (scalar), b) without allocating."""
+        out.copy_(b)
+        out.masked_fill_(cond, a)
+
+    # -- execution -------------------------------------------------------------------------
     def stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
     def sync(self):
         self.torch.cuda.current_stream(self.device).synchronize()
 
+    def on_device(self):
+        """Context making this backend's device current (kernel launches go to its streams)."""
+        t = self.torch
+        if t.cuda.current_device() == self.device.index:
+            return _NULL_CTX
+        return t.cuda.device(self.device)
+
+    def with_streams(self, n, fn):
+        """Call fn(streams) where streams is a (void* * n) array: the current stream plus n-1 side streams that
+        are forked from it before the call and joined back into it afterwards (stream-ordered for the caller,
+        capturable in a hipGraph)."""
+        t = self.torch
+        main = t.cuda.current_stream(self.device)
+        while len(self._side) < n - 1:
+            self._side.append(t.cuda.Stream(device=self.device))
+            self._join.append(t.cuda.Event())
+        if self._fork is None:
+            self._fork = t.cuda.Event()
+        side = self._side[:n - 1]
+        if side:
+            self._fork.record(main)
+            for st in side:
+                st.wait_event(self._fork)
+        arr = (C.c_void_p * n)(main.cuda_stream, *[st.cuda_stream for st in side])
+        rc = fn(arr)
+        for i, st in enumerate(side):
+            self._join[i].record(st)
+            main.wait_event(self._join[i])
+        return rc
+
+    def close(self):
+        self._side, self._join, self._fork = [], [], None
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
+class CpuBackend:
+    """Host memory = NumPy arrays; stepping = libjss_cpu.so (C++17 + OpenMP over envs, same C ABI, written from the
+    kernels' queue-free state).  Explicit choice only (``device='cpu'``); never a fallback of the HIP path."""
+
+    name = "cpu"
+    default_kernel = "auto"
+    device = "cpu"
+
+    def __init__(self, threads: int = 0):
+        from .build import build_cpu_twin
+        path = build_cpu_twin()
+        self.lib = _abi.bind(C.CDLL(path))
+        if not self.lib.jss_backend().startswith(b"cpu"):
+            raise RuntimeError(f"{path} is not the CPU twin ({self.lib.jss_backend()!r})")
+        self.threads = int(threads)
+        self._keep = None
+
+    def zeros(self, shape, dtype):
+        return np.zeros(shape, dtype=getattr(np, dtype))
+
+    def from_numpy(self, a):
+        return np.ascontiguousarray(a).copy()
+
+    def ptr(self, x):
+        if x is None:
+            return 0
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data
+
+    def numpy(self, x):
+        return np.array(x, copy=True)
+
     def as_device(self, x, dtype):
-        t = self.torch.as_tensor(x, device=self.device)
-        return t.to(getattr(self.torch, dtype)).contiguous()
+        a = np.ascontiguousarray(np.asarray(x).astype(getattr(np, dtype), copy=False))
+        self._keep = a
+        return a
 
-    def shift_right(self, x, n):
-        return x >> n
+    def copy_into(self, dst, src):
+        dst[...] = src
 
-    def where(self, cond, a, b):
-        return self.torch.where(cond, self.torch.as_tensor(a, dtype=b.dtype, device=self.device), b)
+    def select_into(self, out, cond, a, b):
+        np.copyto(out, b)
+        out[cond] = a
 
-    def copy_into(self, dst, src_numpy):
-        dst.copy_(self.torch.from_numpy(np.ascontiguousarray(src_numpy)).to(self.device))
+    def stream(self):
+        return 0
+
+    def sync(self):
+        pass
+
+    def on_device(self):
+        return _NULL_CTX
+
+    def with_streams(self, n, fn):
+        return fn((C.c_void_p * n)())
+
+    def close(self):
+        pass
+
+
+def make_backend(device=None):
+    """``None`` / ``'cuda[:i]'`` -> HipBackend (raises without a GPU); ``'cpu'`` -> CpuBackend."""
+    if device is not None and str(device).startswith("cpu"):
+        return CpuBackend()
+    return HipBackend(device)
 
 
 class BatchedJssEnv:
@@ -80,23 +210,30 @@ class BatchedJssEnv:
                sequence of them.  With a sequence, env i runs instance ``i % len(instances)``
                unless ``table_of_env`` says otherwise.
     batch      number of envs (defaults to len(instances)).
+    kernel     "auto" (packed kernel when every env fits a 16/32-lane group) or "wave"
+               (one wavefront per env); a per-env-object choice carried in JssDesc.
     """
 
     def __init__(self, instances, batch: Optional[int] = None, device=None, env_id_base: int = 0,
-                 table_of_env: Optional[Sequence[int]] = None, seed: int = 0, _backend=None):
-        self.backend = be = _backend if _backend is not None else HipBackend(device)
-        if isinstance(instances, (str, os.PathLike, Instance)):
-            instances = [instances]
-        self.instances = [resolve_instance(i) for i in instances]
-        n = len(self.instances)
-        if n == 0:
-            raise ValueError("need at least one instance")
+                 table_of_env: Optional[Sequence[int]] = None, seed: int = 0, kernel: Optional[str] = None,
+                 _backend=None):
+        self.backend = be = _backend if _backend is not None else make_backend(device)
+        if isinstance(instances, PackedBatch):
+            pk = instances
+            self.instances = None
+        else:
+            if isinstance(instances, (str, os.PathLike, Instance)):
+                instances = [instances]
+            self.instances = [resolve_instance(i) for i in instances]
+            if len(self.instances) == 0:
+                raise ValueError("need at least one instance")
+            pk = pack_batch(self.instances)
+        n = int(pk.ops.shape[0])
         self.batch = B = int(batch) if batch is not None else n
         if B < 1:
             raise ValueError("batch must be >= 1")
         self.seed = int(seed)
         self.env_id_base = int(env_id_base)
-        pk: PackedBatch = pack_batch(self.instances)
         self.packed = pk
         self.jmax, self.mmax, self.n_tables = pk.jmax, pk.mmax, n
         if table_of_env is None and n != 1 and n != B:
@@ -108,39 +245,39 @@ class BatchedJssEnv:
             raise ValueError("table_of_env must hold B indices into instances")
         self.jobs_per_env = pk.jobs[self.table_of_env_host]
         self.machines_per_env = pk.machines[self.table_of_env_host]
+        self.kernel = kernel if kernel is not None else getattr(be, "default_kernel", "auto")
+        if self.kernel not in _abi.KERNEL:
+            raise ValueError(f"kernel must be one of {list(_abi.KERNEL)}")
 
-        # instance tables
-        self._ops = be.from_numpy(pk.ops)
-        self._jobs = be.from_numpy(pk.jobs)
-        self._machines = be.from_numpy(pk.machines)
-        self._max_time_op = be.from_numpy(pk.max_time_op)
-        self._max_time_jobs = be.from_numpy(pk.max_time_jobs)
-        self._sum_op = be.from_numpy(pk.sum_op)
-        self._table_of_env = None if table_of_env is None else be.from_numpy(self.table_of_env_host)
-        # compact 16-bit copy of the op tables (machine << 10 | duration) when every duration fits 10 bits:
-        # halves the bytes a kernel stages per table, which matters when every env has its own instance
-        self._ops16 = None
-        if n > 1 and int(pk.max_time_op.max()) <= 1023:
-            ops16 = (((pk.ops >> 16) << 10) | (pk.ops & 0xFFFF)).astype(np.uint16)
-            self._ops16 = be.from_numpy(ops16.view(np.int16))
-        # state (include/jss_hip.h JssState)
-        J, M = self.jmax, self.mmax
-        self.env_header = be.zeros((B, 4), "int32")          # clock, episode, step_in_episode, status
-        self.job_state = be.zeros((B, J, _abi.NF), "int32")  # one 32-byte record per job
-        self.machine_state = be.zeros((B, M), "int32")
-        self.solution = be.zeros((B, J, M), "int32")
-        self.counters = be.zeros((B, 4), "int64")
-        # outputs (JssOut)
-        self.real_obs = be.zeros((B, J, 7), "float32")
-        self.action_mask = be.zeros((B, J + 1), "uint8")
-        self.reward = be.zeros((B,), "float32")
-        self.done = be.zeros((B,), "uint8")
-        self.makespan = be.zeros((B,), "int32")
+        with be.on_device():
+            # instance tables
+            self._ops = be.from_numpy(pk.ops)
+            self._rem = be.from_numpy(pk.rem)
+            self._inst = be.from_numpy(pk.inst)
+            self._table_of_env = None if table_of_env is None else be.from_numpy(self.table_of_env_host)
+            self._env_ids = None
+            # state (include/jss_hip.h JssState)
+            J, M = self.jmax, self.mmax
+            self.env_header = be.zeros((B, 4), "int32")          # clock, episode, step_in_episode, status
+            self.job_state = be.zeros((B, J, _abi.NF), "int32")  # one 32-byte record per job
+            self.machine_state = be.zeros((B, M), "int32")
+            self.solution = be.zeros((B, J, M), "int32")
+            self.counters = be.zeros((B, 4), "int64")
+            # outputs (JssOut)
+            self.real_obs = be.zeros((B, J, 7), "float32")
+            self.action_mask = be.zeros((B, J + 1), "uint8")
+            self.reward = be.zeros((B,), "float32")
+            self.done = be.zeros((B,), "uint8")
+            self.makespan = be.zeros((B,), "int32")
+            # per-call outputs, allocated once (no allocation inside the stepping calls)
+            self._actions_out = be.zeros((B,), "int32")
+            self._hole = be.zeros((B,), "int32")
+            self._act_buf = be.zeros((B,), "int32")
+            self._was_done = be.zeros((B,), "uint8")
 
         p = be.ptr
-        self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._jobs), p(self._machines), p(self._max_time_op),
-                                  p(self._max_time_jobs), p(self._sum_op), p(self._table_of_env), self.env_id_base, None,
-                                  p(self._ops16))
+        self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._rem), p(self._inst), p(self._table_of_env), None,
+                                  self.env_id_base, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)))
         self._state = _abi.JssState(p(self.env_header), p(self.job_state), p(self.machine_state), p(self.solution),
                                     p(self.counters))
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
@@ -173,7 +310,8 @@ class BatchedJssEnv:
         ids = np.ascontiguousarray(np.asarray(ids, dtype=np.int64))
         if ids.shape != (self.batch,):
             raise ValueError("env ids must have shape (B,)")
-        self._env_ids = self.backend.from_numpy(ids)
+        with self.backend.on_device():
+            self._env_ids = self.backend.from_numpy(ids)
         self._desc.env_ids = self.backend.ptr(self._env_ids)
 
     # -- raw ABI handles (bench.py launches through these) -------------------------------
@@ -194,13 +332,17 @@ class BatchedJssEnv:
             raise ValueError("mask must have shape (B,)")
         return w
 
+    def _refs(self):
+        return C.byref(self._desc), C.byref(self._state), C.byref(self._out)
+
     # -- API -----------------------------------------------------------------------------
     def reset(self, which=None):
         """reset() of jss_env.py:145-181 for every env (or those with which[i] != 0). Returns the obs dict."""
         be = self.backend
-        w = self._mask_arg(which)
-        _abi.check(be.lib, be.lib.jss_reset(C.byref(self._desc), C.byref(self._state), C.byref(self._out), be.ptr(w),
-                                            be.stream()), "jss_reset")
+        d, s, o = self._refs()
+        with be.on_device():
+            w = self._mask_arg(which)
+            _abi.check(be.lib, be.lib.jss_reset(d, s, o, be.ptr(w), be.stream()), "jss_reset")
         self._is_reset = True
         return self._obs()
 
@@ -214,37 +356,41 @@ class BatchedJssEnv:
         if not self._is_reset:
             raise RuntimeError("call reset() before step()")
         be = self.backend
-        a = be.as_device(actions, "int32")
-        if tuple(a.shape) != (self.batch,):
-            raise ValueError("actions must have shape (B,)")
-        if autoreset:
-            was_done = self.done.clone() if hasattr(self.done, "clone") else self.done.copy()
-            a = be.where(was_done != 0, -1, a)
-        _abi.check(be.lib, be.lib.jss_step(C.byref(self._desc), C.byref(self._state), be.ptr(a), C.byref(self._out),
-                                           be.stream()), "jss_step")
-        if autoreset:
-            _abi.check(be.lib, be.lib.jss_reset(C.byref(self._desc), C.byref(self._state), C.byref(self._out),
-                                                be.ptr(was_done), be.stream()), "jss_reset")
+        d, s, o = self._refs()
+        with be.on_device():
+            a = be.as_device(actions, "int32")
+            if tuple(a.shape) != (self.batch,):
+                raise ValueError("actions must have shape (B,)")
+            if autoreset:
+                be.copy_into(self._was_done, self.done)
+                be.select_into(self._act_buf, self._was_done != 0, -1, a)
+                a = self._act_buf
+            _abi.check(be.lib, be.lib.jss_step(d, s, be.ptr(a), o, be.stream()), "jss_step")
+            if autoreset:
+                _abi.check(be.lib, be.lib.jss_reset(d, s, o, be.ptr(self._was_done), be.stream()), "jss_reset")
         return self._obs(), self.reward, self.done, False, {}
 
     def increase_time_step(self, which=None):
-        """increase_time_step() of jss_env.py:495-637 per env; returns hole_planning (B,) int32."""
+        """increase_time_step() of jss_env.py:495-637 per env; returns hole_planning (B,) int32 (the env's own
+        buffer, overwritten by the next call)."""
         be = self.backend
-        w = self._mask_arg(which)
-        hole = be.zeros((self.batch,), "int32")
-        _abi.check(be.lib, be.lib.jss_advance(C.byref(self._desc), C.byref(self._state), be.ptr(w), be.ptr(hole),
-                                              C.byref(self._out), be.stream()), "jss_advance")
-        return hole
+        d, s, o = self._refs()
+        with be.on_device():
+            w = self._mask_arg(which)
+            _abi.check(be.lib, be.lib.jss_advance(d, s, be.ptr(w), be.ptr(self._hole), o, be.stream()), "jss_advance")
+        return self._hole
 
     def policy(self, kind: Union[str, int] = "random", seed: Optional[int] = None, explore: float = 0.0):
-        """Per-env action from the on-device selectors (random masked, FIFO, SPT, MWR, LWR, MOR, LOR)."""
+        """Per-env action from the on-device selectors (random masked, FIFO, SPT, MWR, LWR, MOR, LOR, CR).
+        Returns the env's own (B,) int32 action buffer (overwritten by the next policy() call)."""
         be = self.backend
         k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
-        out = be.zeros((self.batch,), "int32")
-        _abi.check(be.lib, be.lib.jss_policy(C.byref(self._desc), C.byref(self._state), k,
-                                             self.seed if seed is None else int(seed), int(round(explore * 65536)),
-                                             be.ptr(out), be.stream()), "jss_policy")
-        return out
+        d, s, _ = self._refs()
+        with be.on_device():
+            _abi.check(be.lib, be.lib.jss_policy(d, s, k, self.seed if seed is None else int(seed),
+                                                 int(round(explore * 65536)), be.ptr(self._actions_out), be.stream()),
+                       "jss_policy")
+        return self._actions_out
 
     def rollout(self, kind: Union[str, int] = "random", n_iter: int = 1, seed: Optional[int] = None,
                 autoreset: bool = True, explore: float = 0.0):
@@ -254,9 +400,32 @@ class BatchedJssEnv:
         be = self.backend
         k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
         flags = _abi.ROLLOUT_AUTORESET if autoreset else 0
-        _abi.check(be.lib, be.lib.jss_rollout(C.byref(self._desc), C.byref(self._state), C.byref(self._out), k,
-                                              self.seed if seed is None else int(seed), int(round(explore * 65536)),
-                                              int(n_iter), flags, be.stream()), "jss_rollout")
+        d, s, o = self._refs()
+        with be.on_device():
+            _abi.check(be.lib, be.lib.jss_rollout(d, s, o, k, self.seed if seed is None else int(seed),
+                                                  int(round(explore * 65536)), int(n_iter), flags, be.stream()),
+                       "jss_rollout")
+        return self._obs(), self.reward, self.done, False, {}
+
+    def rollout_steps(self, kind: Union[str, int] = "random", steps: int = 1, n_sub: int = 2, seed: Optional[int] = None,
+                      autoreset: bool = True, explore: float = 0.0):
+        """``steps`` consecutive one-step rollouts of the whole batch, issued as ``n_sub`` independent contiguous
+        sub-batches on ``n_sub`` streams (the current one + side streams forked from / joined back into it): step s of a
+        sub-batch depends only on its own step s-1, so the drain of one sub-batch's launch overlaps the fill of
+        another's.  Results are identical to ``steps`` calls of ``rollout(n_iter=1)``; outputs hold the last step."""
+        if not self._is_reset:
+            raise RuntimeError("call reset() before rollout_steps()")
+        if not 1 <= int(n_sub) <= _abi.MAX_SUB_BATCHES:
+            raise ValueError(f"n_sub must be in [1, {_abi.MAX_SUB_BATCHES}]")
+        be = self.backend
+        k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
+        flags = _abi.ROLLOUT_AUTORESET if autoreset else 0
+        d, s, o = self._refs()
+        sd = self.seed if seed is None else int(seed)
+        with be.on_device():
+            rc = be.with_streams(int(n_sub), lambda streams: be.lib.jss_rollout_steps(
+                d, s, o, k, sd, int(round(explore * 65536)), int(steps), flags, int(n_sub), streams))
+        _abi.check(be.lib, rc, "jss_rollout_steps")
         return self._obs(), self.reward, self.done, False, {}
 
     def synchronize(self):
@@ -281,13 +450,17 @@ class BatchedJssEnv:
     def err(self):
         return self.env_header[:, _abi.H_STATUS] & 0xFF
 
+    def clear_errors(self):
+        """Clear the sticky per-env error bits (the NOPE flag in the same word is kept)."""
+        self.env_header[:, _abi.H_STATUS] &= ~0xFF
+
     @property
     def todo_time_step_job(self):
-        return self.job_state[:, :, _abi.F_TODO]
+        return self.job_state[:, :, _abi.F_TODO] & _abi.TODO_MASK
 
     @property
     def needed_machine_jobs(self):
-        return self.backend.shift_right(self.job_state[:, :, _abi.F_CUR], 16)
+        return self.job_state[:, :, _abi.F_CUR] >> 16
 
     @property
     def time_until_finish_current_op_jobs(self):
@@ -315,7 +488,7 @@ class BatchedJssEnv:
 
     @property
     def action_illegal_no_op(self):
-        return self.backend.shift_right(self.job_state[:, :, _abi.F_FLAGS], 1) & 1
+        return (self.job_state[:, :, _abi.F_TODO] >> 9) & 1
 
     def counter_totals(self):
         """Device tensor [4]: env steps, finished episodes, sum of makespans, sum of reward numerators."""
@@ -337,33 +510,59 @@ class BatchedJssEnv:
         """Host copy of everything needed to resume: state + last outputs + the batch description."""
         n = self.backend.numpy
         d = {k: n(getattr(self, k)) for k in self._STATE_TENSORS}
-        d["meta"] = {"batch": self.batch, "jmax": self.jmax, "mmax": self.mmax, "seed": self.seed,
-                     "env_id_base": self.env_id_base, "instances": [i.name for i in self.instances],
-                     "table_of_env": self.table_of_env_host.copy(), "ops": self.packed.ops.copy()}
+        d["meta"] = {"abi": _abi.ABI_VERSION, "batch": self.batch, "jmax": self.jmax, "mmax": self.mmax, "seed": self.seed,
+                     "env_id_base": self.env_id_base, "table_of_env": self.table_of_env_host.copy(),
+                     "ops": self.packed.ops.copy()}
         return d
 
     def load_state_dict(self, d):
         m = d["meta"]
-        if (m["batch"], m["jmax"], m["mmax"]) != (self.batch, self.jmax, self.mmax) or \
+        if int(m.get("abi", 0)) != _abi.ABI_VERSION:
+            raise ValueError(f"checkpoint was written with state layout v{m.get('abi')}, this build is v{_abi.ABI_VERSION}")
+        if (int(m["batch"]), int(m["jmax"]), int(m["mmax"])) != (self.batch, self.jmax, self.mmax) or \
                 not np.array_equal(m["ops"], self.packed.ops) or not np.array_equal(m["table_of_env"], self.table_of_env_host):
             raise ValueError("checkpoint belongs to a different batch (shape or instances differ)")
-        for k in self._STATE_TENSORS:
-            self.backend.copy_into(getattr(self, k), d[k])
+        with self.backend.on_device():
+            for k in self._STATE_TENSORS:
+                self.backend.copy_into(getattr(self, k), np.asarray(d[k]))
         self.seed, self._is_reset = int(m["seed"]), True
 
+    def save_checkpoint(self, path):
+        """state_dict() to one .npz file (NumPy arrays only, no pickling)."""
+        d = self.state_dict()
+        meta = d.pop("meta")
+        flat = {f"state_{k}": v for k, v in d.items()}
+        for k, v in meta.items():
+            flat[f"meta_{k}"] = np.asarray(v)
+        with open(path, "wb") as fh:
+            np.savez(fh, **flat)
+
+    def load_checkpoint(self, path):
+        with np.load(path, allow_pickle=False) as z:
+            d = {k[len("state_"):]: z[k] for k in z.files if k.startswith("state_")}
+            d["meta"] = {k[len("meta_"):]: (z[k] if z[k].ndim else z[k].item()) for k in z.files if k.startswith("meta_")}
+        self.load_state_dict(d)
+
     def host_state(self, i: int = 0):
-        """Everything about env i as NumPy, sliced to its true (J, M)."""
+        """Everything about env i as NumPy, sliced to its true (J, M).  ``job_state`` rows follow the JSS_F_* word
+        order with the packed word 0 decoded: row 0 = todo_time_step_job, row 7 = flags (1 legal, 2 blocked);
+        ``next_op`` is the record's cached next op."""
         n = self.backend.numpy
         J, M = int(self.jobs_per_env[i]), int(self.machines_per_env[i])
-        js = n(self.job_state[i])[:J].astype(np.int64).T          # (NF, J): rows = JSS_F_* words
+        raw = n(self.job_state[i])[:J].astype(np.int64).T         # (NF, J): rows = JSS_F_* words
+        js = raw.copy()
+        js[_abi.F_TODO] = raw[_abi.F_TODO] & _abi.TODO_MASK
+        js[7] = (raw[_abi.F_TODO] >> 8) & 3
         hdr = n(self.env_header[i])
         return {
             "jobs": J, "machines": M,
             "clock": int(hdr[_abi.H_CLOCK]),
             "job_state": js,
+            "next_op": raw[_abi.F_NEXT],
             "tm": n(self.machine_state[i])[:M].astype(np.int64),
             "mask": n(self.action_mask[i])[:J + 1].astype(bool),
-            "blocked": (js[_abi.F_FLAGS] & _abi.FLAG_BLOCKED) != 0,
+            "mask_padding": n(self.action_mask[i])[J + 1:],
+            "blocked": (js[7] & 2) != 0,
             "solution": n(self.solution[i])[:J, :M].astype(np.int64),
             "obs": n(self.real_obs[i])[:J].astype(np.float32),
             "obs_padding": n(self.real_obs[i])[J:],
@@ -384,7 +583,8 @@ class JssEnv:
     jss_env.py:35-38), same methods and return shapes, same public attributes (NumPy, pulled
     from the device on access).  Differences, all outside what the reference defines:
     a job action outside the mask raises ``ValueError`` (the reference corrupts its counters
-    silently); the observation is float32.
+    silently); the observation is float32.  ``device='cpu'`` runs the same env on the
+    host-core twin (no GPU needed).
     """
 
     metadata = {"render_modes": ["human"]}
@@ -404,7 +604,6 @@ class JssEnv:
         self.last_solution = None                                          # :52
         self._b = BatchedJssEnv([inst], batch=1, device=device, _backend=_backend)
         self._cache = None
-        self._err_seen = 0
         try:  # spaces only when gymnasium is importable (jss_env.py:97, :112-119)
             import gymnasium as gym
             self.action_space = gym.spaces.Discrete(self.jobs + 1)
@@ -412,7 +611,7 @@ class JssEnv:
                 "action_mask": gym.spaces.Box(0, 1, shape=(self.jobs + 1,)),
                 "real_obs": gym.spaces.Box(low=0.0, high=1.0, shape=(self.jobs, 7), dtype=float),
             })
-        except Exception:  # pragma: no cover - gymnasium is optional
+        except ImportError:  # gymnasium is optional
             self.action_space = self.observation_space = None
 
     # -- host mirror of the device state ---------------------------------------------------
@@ -476,8 +675,21 @@ class JssEnv:
         """jss_env.py:145-181 -- returns the observation dict only (no info tuple)."""
         self._b.reset()
         self._cache = None
-        self._err_seen = 0
         return self._obs()
+
+    def _raise_for(self, err, action=None):
+        """Turn the kernel's per-env error bits into the reference's exceptions.  The bits are sticky on the
+        device, so they are cleared here: every offending call raises, not only the first of an episode."""
+        if not err:
+            return
+        self._b.clear_errors()
+        self._cache = None
+        if err & _abi.ERR_BAD_ACTION:
+            raise IndexError(f"action {action} out of range for {self.jobs} jobs")
+        if err & _abi.ERR_NOPE_IDLE:
+            raise IndexError("pop from empty list")  # what the reference raises at jss_env.py:517
+        if err & _abi.ERR_ILLEGAL_ACTION:
+            raise ValueError(f"job {action} is not a legal action")
 
     def step(self, action):
         """jss_env.py:403-481."""
@@ -485,14 +697,7 @@ class JssEnv:
         self._b.step(np.asarray([action], dtype=np.int32))
         self._cache = None
         h = self._h()
-        new_err = h["err"] & ~self._err_seen
-        self._err_seen = h["err"]
-        if new_err & _abi.ERR_BAD_ACTION:
-            raise IndexError(f"action {action} out of range for {self.jobs} jobs")
-        if new_err & _abi.ERR_NOPE_IDLE:
-            raise IndexError("pop from empty list")  # what the reference raises at jss_env.py:517
-        if new_err & _abi.ERR_ILLEGAL_ACTION:
-            raise ValueError(f"job {action} is not a legal action")
+        self._raise_for(h["err"], action)
         if h["done"]:                                                       # :649-652
             self.last_time_step = h["clock"]
             self.last_solution = h["solution"]
@@ -500,13 +705,10 @@ class JssEnv:
 
     def increase_time_step(self):
         """jss_env.py:495-637 -- public in the reference and called directly by its tests."""
-        hole = self._b.increase_time_step()
+        hole = int(self._b.backend.numpy(self._b.increase_time_step())[0])
         self._cache = None
-        new_err = self._h()["err"] & ~self._err_seen
-        self._err_seen = self._h()["err"]
-        if new_err & _abi.ERR_NOPE_IDLE:
-            raise IndexError("pop from empty list")
-        return int(self._b.backend.numpy(hole)[0])
+        self._raise_for(self._h()["err"])
+        return hole
 
     def render(self, mode: str = "human"):
         """Gantt chart of ``solution`` (jss_env.py:655-693); needs pandas + plotly on the host."""

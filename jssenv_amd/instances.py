@@ -24,6 +24,7 @@ MAX_JOBS = 128       # two jobs per lane of a 64-wide wavefront
 MAX_MACHINES = 64    # machine m lives on lane m
 MAX_DURATION = 0xFFFF
 OP_MACHINE_SHIFT = 16
+INST_RECORD_INTS = 12   # JSS_NI
 
 _DATA_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "instances.npz")
 
@@ -174,6 +175,53 @@ def synthetic_batch(n: int, jobs: int, machines: int, first: int = 0) -> List[In
     return [taillard_instance(jobs, machines, 1 + 2 * (first + i), 2 + 2 * (first + i)) for i in range(n)]
 
 
+def _lcg_unif(x: np.ndarray, low, high) -> np.ndarray:
+    """One Taillard LCG draw per element of the state vector ``x`` (advanced in place)."""
+    k = x // _LCG_B
+    x[:] = _LCG_A * (x % _LCG_B) - k * _LCG_C
+    x[x < 0] += _LCG_M
+    return low + ((x / _LCG_M) * (high - low + 1)).astype(np.int64)
+
+
+def synthetic_arrays(n: int, jobs: int, machines: int, first: int = 0):
+    """The instances of ``synthetic_batch(n, jobs, machines, first)`` as two (n, J, M) int32 arrays
+    (machine, duration), generated for all n instances at once (every instance has its own LCG streams, so the
+    J*M draws vectorise over the instance axis).  65 536 instances of 15x15 take about a second."""
+    idx = first + np.arange(n, dtype=np.int64)
+    xt, xm = 1 + 2 * idx, 2 + 2 * idx
+    if n and (xm.max() >= _LCG_M):
+        raise ValueError("seed must be in [1, 2^31-2]")
+    duration = np.zeros((n, jobs, machines), dtype=np.int32)
+    for j in range(jobs):
+        for k in range(machines):
+            duration[:, j, k] = _lcg_unif(xt, 1, 99)
+    machine = np.tile(np.arange(machines, dtype=np.int32), (n, jobs, 1))
+    rows = np.arange(n)
+    for j in range(jobs):
+        for k in range(machines):
+            s = _lcg_unif(xm, k, machines - 1)
+            a, b = machine[rows, j, k].copy(), machine[rows, j, s].copy()
+            machine[rows, j, k], machine[rows, j, s] = b, a
+    return machine, duration
+
+
+def synthetic_packed(n: int, jobs: int, machines: int, first: int = 0) -> "PackedBatch":
+    """``pack_batch(synthetic_batch(...))`` without building n Instance objects (bench-sized batches)."""
+    machine, duration = synthetic_arrays(n, jobs, machines, first)
+    ops = ((machine << OP_MACHINE_SHIFT) | duration).astype(np.int32)
+    rem = np.cumsum(duration[:, :, ::-1], axis=2)[:, :, ::-1].astype(np.int32)
+    jl = duration.sum(axis=2)
+    mto, mtj, sop = duration.max(axis=(1, 2)), jl.max(axis=1), jl.sum(axis=1)
+    rec = np.zeros((n, INST_RECORD_INTS), dtype=np.int32)
+    rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 4] = jobs, machines, mto, mtj, sop
+    vals = np.stack([mto, mtj, sop, np.full(n, machines)], axis=1).astype(np.float32)
+    rec[:, 5:9] = (np.float32(1.0) / vals).view(np.int32)
+    as32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+    return PackedBatch(ops=np.ascontiguousarray(ops), rem=np.ascontiguousarray(rem), inst=rec,
+                       jobs=np.full(n, jobs, dtype=np.int32), machines=np.full(n, machines, dtype=np.int32),
+                       max_time_op=as32(mto), max_time_jobs=as32(mtj), sum_op=as32(sop), jmax=jobs, mmax=machines)
+
+
 # --------------------------------------------------------------------------
 # Shipped benchmark set (ta01-ta80, dmu16-dmu20), stored as packed arrays.
 # --------------------------------------------------------------------------
@@ -221,9 +269,11 @@ def resolve_instance(spec) -> Instance:
 
 @dataclass
 class PackedBatch:
-    """Host-side description of a batch of instances, ready to upload."""
+    """Host-side description of a batch of instances, ready to upload (include/jss_hip.h JssDesc)."""
 
     ops: np.ndarray            # (n_tables, Jmax, Mmax) int32, machine<<16|duration
+    rem: np.ndarray            # (n_tables, Jmax, Mmax) int32, rem[j][k] = sum of the durations of ops k..M-1 of job j
+    inst: np.ndarray           # (n_tables, NI) int32 instance records (JSS_I_*: J, M, normalisers, float32 reciprocals)
     jobs: np.ndarray           # (n_tables,) int32
     machines: np.ndarray       # (n_tables,) int32
     max_time_op: np.ndarray    # (n_tables,) int32
@@ -233,16 +283,30 @@ class PackedBatch:
     mmax: int
 
 
+def instance_record(inst: Instance) -> np.ndarray:
+    """The JSS_I_* record of one instance: J, M, the observation's normalisers (jss_env.py:86-89) and their
+    correctly rounded float32 reciprocals (the kernels divide as q = a * r, one residual correction)."""
+    rec = np.zeros(INST_RECORD_INTS, dtype=np.int32)
+    vals = (inst.max_time_op, inst.max_time_jobs, inst.sum_op, inst.machines)
+    rec[0:5] = (inst.jobs, inst.machines, inst.max_time_op, inst.max_time_jobs, inst.sum_op)
+    rec[5:9] = (np.float32(1.0) / np.asarray(vals, dtype=np.float32)).view(np.int32)
+    return rec
+
+
 def pack_batch(instances: Sequence[Instance], jmax: int | None = None, mmax: int | None = None) -> PackedBatch:
     jmax = max(i.jobs for i in instances) if jmax is None else jmax
     mmax = max(i.machines for i in instances) if mmax is None else mmax
     n = len(instances)
     ops = np.zeros((n, jmax, mmax), dtype=np.int32)
+    rem = np.zeros((n, jmax, mmax), dtype=np.int32)
+    rec = np.zeros((n, INST_RECORD_INTS), dtype=np.int32)
     for i, inst in enumerate(instances):
         ops[i] = inst.packed(jmax, mmax)
+        rem[i, :inst.jobs, :inst.machines] = np.cumsum(inst.duration[:, ::-1], axis=1)[:, ::-1]
+        rec[i] = instance_record(inst)
     as32 = lambda it: np.asarray(list(it), dtype=np.int32)  # noqa: E731
     return PackedBatch(
-        ops=ops,
+        ops=ops, rem=rem, inst=rec,
         jobs=as32(i.jobs for i in instances),
         machines=as32(i.machines for i in instances),
         max_time_op=as32(i.max_time_op for i in instances),
@@ -251,3 +315,38 @@ def pack_batch(instances: Sequence[Instance], jmax: int | None = None, mmax: int
         jmax=jmax,
         mmax=mmax,
     )
+
+
+# --------------------------------------------------------------------------
+# Packed on-disk batch format: one .npz holding the upload-ready tables.
+# --------------------------------------------------------------------------
+_BATCH_FORMAT = 1
+
+
+def save_batch(path, batch: "PackedBatch") -> None:
+    """Write a PackedBatch as one .npz (arrays only, no pickling): the op tables as uploaded, the instance
+    records, and enough per-table scalars to rebuild everything else."""
+    with open(path, "wb") as fh:
+        np.savez(fh, format=np.int32(_BATCH_FORMAT), ops=batch.ops, inst=batch.inst)
+
+
+def load_batch(path) -> "PackedBatch":
+    """Read a file written by save_batch; derived tables (remaining work, reciprocals) are recomputed and the
+    stored instance records are checked against them."""
+    with np.load(path, allow_pickle=False) as z:
+        if int(z["format"]) != _BATCH_FORMAT:
+            raise ValueError(f"unknown packed batch format {int(z['format'])}")
+        ops, inst = np.ascontiguousarray(z["ops"], dtype=np.int32), np.ascontiguousarray(z["inst"], dtype=np.int32)
+    if ops.ndim != 3 or inst.shape != (ops.shape[0], INST_RECORD_INTS):
+        raise ValueError("malformed packed batch")
+    n, jmax, mmax = ops.shape
+    insts = []
+    for i in range(n):
+        J, M = int(inst[i, 0]), int(inst[i, 1])
+        if not (1 <= J <= jmax and 2 <= M <= mmax):
+            raise ValueError(f"table {i}: bad shape {J}x{M}")
+        insts.append(Instance(f"table{i}", ops[i, :J, :M] >> OP_MACHINE_SHIFT, ops[i, :J, :M] & MAX_DURATION))
+    pk = pack_batch(insts, jmax, mmax)
+    if not (np.array_equal(pk.ops, ops) and np.array_equal(pk.inst, inst)):
+        raise ValueError("packed batch is inconsistent (padding or instance records do not match the op tables)")
+    return pk

@@ -26,9 +26,11 @@ def build(force=False):
 
 class EmuBackend:
     name = "emu"
+    device = "emu"
 
-    def __init__(self):
+    def __init__(self, default_kernel="auto"):
         self.lib = _abi.bind(C.CDLL(build()))
+        self.default_kernel = default_kernel
         self._keep = []
 
     def zeros(self, shape, dtype):
@@ -52,16 +54,24 @@ class EmuBackend:
     def sync(self):
         pass
 
+    def on_device(self):
+        from jssenv_amd.env import _NULL_CTX
+        return _NULL_CTX
+
+    def with_streams(self, n, fn):
+        return fn((C.c_void_p * n)())
+
     def as_device(self, x, dtype):
         a = np.ascontiguousarray(np.asarray(x).astype(getattr(np, dtype)))
         self._keep = [a]
         return a
 
-    def shift_right(self, x, n):
-        return x >> n
+    def select_into(self, out, cond, a, b):
+        np.copyto(out, b)
+        out[cond] = a
 
-    def where(self, cond, a, b):
-        return np.where(cond, np.asarray(a, dtype=b.dtype), b).astype(b.dtype)
+    def copy_into(self, dst, src):
+        dst[...] = src
 
-    def copy_into(self, dst, src_numpy):
-        dst[...] = src_numpy
+    def close(self):
+        pass

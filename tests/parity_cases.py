@@ -52,6 +52,13 @@ def assert_matches_oracle(h, orc, where, fresh_col0=True, check_outputs=True):
     err = np.abs(got_obs - want_obs).max()
     assert err <= OBS_TOL, f"{where}: real_obs max |diff| {err}"
     assert not h["obs_padding"].any(), f"{where}: padding rows of real_obs must be zero"
+    assert not h["mask_padding"].any(), f"{where}: action_mask bytes behind the NOPE flag must be zero"
+    # the record's cached next op is op table entry [j][todo + 1] (-1 when there is none)
+    for j in range(J):
+        want_next = -1
+        if todo[j] + 1 < orc.machines:
+            want_next = (int(orc.instance_matrix[j, todo[j] + 1, 0]) << 16) | int(orc.instance_matrix[j, todo[j] + 1, 1])
+        assert h["next_op"][j] == want_next, f"{where}: next op of job {j}"
     assert h["noop_flag"] == bool(orc.legal_actions[-1]), f"{where}: NOPE flag in the header"
     if check_outputs:
         assert h["done"] == (orc.nb_legal_actions == 0), f"{where}: done"
@@ -68,6 +75,7 @@ def replay_golden_through_facade(backend, golden_name, inst, max_rows=None, chec
     orc.reset()
     n = len(g["action"]) if max_rows is None else min(max_rows, len(g["action"]))
     obs_rows = {int(s): k for k, s in enumerate(g["obs_step"])}
+    num_before = 0
     for i in range(n):
         a = int(g["action"][i])
         where = f"{golden_name} row {i} action {a}"
@@ -81,6 +89,10 @@ def replay_golden_through_facade(backend, golden_name, inst, max_rows=None, chec
             _, r1, d1, t1, info = env.step(a)
             _, r2, d2, _, _ = orc.step(a)
             assert reward_close(r1, g["reward"][i]) and reward_close(r1, r2), f"{where}: reward {r1} vs {g['reward'][i]}"
+            if "reward_num" in g:   # the exact integer numerator: accumulated on the device next to the float reward
+                num = int(env._b.backend.numpy(env._b.counters)[0, 3])
+                assert num - num_before == int(g["reward_num"][i]), f"{where}: reward numerator {num - num_before} vs {g['reward_num'][i]}"
+                num_before = num
             assert d1 == bool(g["done"][i]) == d2, f"{where}: done"
             assert t1 is False and info == {}
         # golden rows (the reference's own values) ...
@@ -240,6 +252,13 @@ def case_error_semantics(backend):
     for i in range(5):
         assert_matches_oracle(env.host_state(i), orcs[i], f"err case env {i}")
     assert env.host_state(0)["done"] is True and env.host_state(2)["step_in_episode"] == 0
+    # JSS_ACTION_SKIP leaves reward / done / makespan of that env as they were
+    r4 = env.host_state(4)["reward"]
+    assert r4 > 0
+    env.step(np.array([-1, -1, -1, -1, -1], dtype=np.int32))
+    assert env.host_state(4)["reward"] == r4 and env.host_state(0)["done"] is True and env.host_state(4)["step_in_episode"] == 1
+    for i in range(5):
+        assert_matches_oracle(env.host_state(i), orcs[i], f"after an all-skip step, env {i}")
     # repeat a running job: outside the mask -> ignored + flagged, state untouched
     before = env.host_state(1)
     env.step(np.array([-1, 3, -1, -1, -1], dtype=np.int32))
@@ -266,11 +285,12 @@ def case_facade_errors(backend):
         pass
     env.reset()
     env.step(0)
-    try:
-        env.step(0)
-        raise AssertionError("illegal job must raise")
-    except ValueError:
-        pass
+    for attempt in range(2):        # the error bits are sticky on the device; the facade must raise every time
+        try:
+            env.step(0)
+            raise AssertionError("illegal job must raise")
+        except ValueError:
+            pass
     try:
         env.step(env.jobs + 3)
         raise AssertionError("out-of-range action must raise")
@@ -481,23 +501,6 @@ def case_vector_facade(backend):
     assert (finished >= 1).all() and (envs.makespan > 1000).all()
 
 
-def case_persistent_kernel(backend, batch=41, n_steps=40):
-    """The persistent packed kernel (env sets looped per wave with prefetch of the next set) must be
-    indistinguishable from the one-set-per-wave kernel: force it with a 1-CU, 1-wave-per-SIMD 'device' so
-    that a small batch already needs several sets per wave, including a partial tail set."""
-    lib = backend.lib
-    assert lib.jss_set_option(_abi.OPT_CU_COUNT, 1) == 0 and lib.jss_set_option(_abi.OPT_PERSIST, 1) == 0
-    try:
-        # jss_step path (kStep) with oracle lock step, forced NOPEs and skipped envs
-        case_batch_lockstep(backend, ["ta01"], batch=batch, n_steps=n_steps, kind="random", nope_every=6, check_every=8)
-        # jss_rollout(n_iter=1) path (kRollout1) with auto-restart, G = 32 flavour too
-        case_rollout(backend, ["ta01"], batch=batch, n_iter=0, chunks=(1,) * n_steps)
-        case_rollout(backend, ["ta21"], batch=19, n_iter=0, chunks=(1,) * (n_steps // 2), kind="SPT")
-    finally:
-        lib.jss_set_option(_abi.OPT_CU_COUNT, 0)
-        lib.jss_set_option(_abi.OPT_PERSIST, 0)
-
-
 def case_instance_resampling(backend):
     """assign_instances(): envs switch instance (and shape) between episodes; untouched envs keep running."""
     insts = [I.builtin_instance(n) for n in ("ta01", "ta11", "ta02")]
@@ -527,9 +530,50 @@ def case_instance_resampling(backend):
         h = env.host_state(i)
         assert h["jobs"] == o.jobs and h["episode"] == o.episode
         assert_matches_oracle(h, o, f"resampled env {i} ({o.instance.name})")
+    # larger -> smaller instance (20 jobs -> 15): the mask bytes behind the new NOPE index must be cleared
+    step_all(30)                                   # env 4 (ta11) has NOPE history / legal bits beyond index 15 by now
+    env.assign_instances([4], [0])
+    orcs[4] = OracleEnv(insts[0], strict=True)
+    orcs[4].reset()
+    orcs[4].episode = 3
+    row = env.backend.numpy(env.action_mask)[4]
+    assert row[:15].all() and not row[15:].any(), row
+    step_all(10)
+    for i, o in enumerate(orcs):
+        assert_matches_oracle(env.host_state(i), o, f"after larger->smaller reassignment, env {i}")
     single = BatchedJssEnv(insts[0], batch=2, _backend=backend)
     try:
         single.assign_instances([0], [0])
         raise AssertionError("a shared-instance batch has no env -> instance map to change")
+    except ValueError:
+        pass
+
+
+def case_rollout_steps(backend, batch=150, steps=6, n_sub=3, seed=31):
+    """jss_rollout_steps (n_sub sub-batches on n_sub streams) is the same computation as `steps` calls of
+    jss_rollout(n_iter=1): every tensor bit-identical, for the three env -> instance mappings."""
+    rng = np.random.default_rng(seed)
+    small = [random_instance(rng, 5, 4, max_dur=9) for _ in range(batch)]
+    variants = [dict(instances="ta01"),                                         # one shared table (LDS)
+                dict(instances=[I.builtin_instance(n) for n in ("ta01", "ta02", "ta03")]),   # env -> instance map
+                dict(instances=small)]                                          # one table per env
+    for kw in variants:
+        a = BatchedJssEnv(batch=batch, seed=seed, env_id_base=9, _backend=backend, **kw)
+        b = BatchedJssEnv(batch=batch, seed=seed, env_id_base=9, _backend=backend, **kw)
+        a.reset()
+        b.reset()
+        a.rollout("random", n_iter=7)
+        b.rollout("random", n_iter=7)
+        a.rollout_steps("random", steps=steps, n_sub=n_sub)
+        for _ in range(steps):
+            b.rollout("random", n_iter=1)
+        a.synchronize()
+        for name in BatchedJssEnv._STATE_TENSORS:
+            x, y = a.backend.numpy(getattr(a, name)), b.backend.numpy(getattr(b, name))
+            assert np.array_equal(x, y), f"rollout_steps differs from rollout x {steps} in {name}"
+        assert a.stats()["steps"] > 0
+    try:
+        a.rollout_steps("random", steps=1, n_sub=17)
+        raise AssertionError("n_sub > 16 must be rejected")
     except ValueError:
         pass

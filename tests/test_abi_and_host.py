@@ -22,6 +22,7 @@ def hip_lib():
 
 def test_header_symbols_exported(hip_lib):
     hdr = open(os.path.join(ROOT, "include", "jss_hip.h")).read()
+    hdr = re.sub(r"#ifdef JSS_PROFILING.*?#endif", "", hdr, flags=re.S)      # instrumented builds only, not shipped
     declared = set(re.findall(r"^(?:int|const char \*)\s*\*?(jss_\w+)\(", hdr, flags=re.M))
     assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
     for name in declared:
@@ -29,19 +30,26 @@ def test_header_symbols_exported(hip_lib):
     _abi.bind(hip_lib)
     assert hip_lib.jss_abi_version() == _abi.ABI_VERSION
     assert b"null" in hip_lib.jss_error_string(-1)
+    assert hip_lib.jss_backend() == b"hip:gfx950"
+    assert not hasattr(hip_lib, "jss_profiling_set") and not hasattr(hip_lib, "jss_set_option")   # no back-doors shipped
 
 
 def test_header_constants_match_python_mirror():
     hdr = open(os.path.join(ROOT, "include", "jss_hip.h")).read()
     defs = {k: int(v) for k, v in re.findall(r"#define (JSS_\w+) \(?(-?\d+)\)?", hdr)}
     assert defs["JSS_NF"] == _abi.NF and defs["JSS_F_CUR"] == _abi.F_CUR and defs["JSS_F_F4"] == _abi.F_F4
-    assert defs["JSS_F_FLAGS"] == _abi.F_FLAGS and defs["JSS_H_STATUS"] == _abi.H_STATUS and defs["JSS_STATUS_NOOP"] == _abi.STATUS_NOOP
+    assert defs["JSS_F_NEXT"] == _abi.F_NEXT and defs["JSS_H_STATUS"] == _abi.H_STATUS and defs["JSS_STATUS_NOOP"] == _abi.STATUS_NOOP
+    assert (defs["JSS_TODO_MASK"], defs["JSS_FLAG_LEGAL"], defs["JSS_FLAG_BLOCKED"]) == (_abi.TODO_MASK, _abi.FLAG_LEGAL, _abi.FLAG_BLOCKED)
+    assert defs["JSS_NI"] == _abi.NI == I.INST_RECORD_INTS and defs["JSS_I_RCP_MACHINES"] == _abi.I_RCP_MACHINES
+    for name, kid in _abi.KERNEL.items():
+        assert defs["JSS_KERNEL_" + name.upper()] == kid
+    assert (defs["JSS_E_NULL"], defs["JSS_E_SHAPE"], defs["JSS_E_KIND"], defs["JSS_E_LDS"]) == (_abi.E_NULL, _abi.E_SHAPE, _abi.E_KIND, _abi.E_LDS)
     assert defs["JSS_ABI_VERSION"] == _abi.ABI_VERSION
     assert defs["JSS_MAX_JOBS"] == _abi.MAX_JOBS == I.MAX_JOBS and defs["JSS_MAX_MACHINES"] == I.MAX_MACHINES
     assert defs["JSS_ERR_NOPE_IDLE"] == _abi.ERR_NOPE_IDLE and defs["JSS_ERR_ILLEGAL_ACTION"] == _abi.ERR_ILLEGAL_ACTION
     for name, kid in _abi.POLICY.items():
         assert defs["JSS_POLICY_" + name.upper()] == kid
-    assert ctypes.sizeof(_abi.JssDesc) == 16 + 7 * 8 + 8 + 8 + 8 and ctypes.sizeof(_abi.JssState) == 40 and ctypes.sizeof(_abi.JssOut) == 40
+    assert ctypes.sizeof(_abi.JssDesc) == 16 + 5 * 8 + 8 + 8 and ctypes.sizeof(_abi.JssState) == 40 and ctypes.sizeof(_abi.JssOut) == 40
 
 
 def test_argument_errors_without_gpu(hip_lib):
@@ -49,16 +57,18 @@ def test_argument_errors_without_gpu(hip_lib):
     d, s, o = _abi.JssDesc(), _abi.JssState(), _abi.JssOut()
     assert hip_lib.jss_reset(ctypes.byref(d), ctypes.byref(s), ctypes.byref(o), None, None) == -1   # JSS_E_NULL
     assert hip_lib.jss_policy(None, None, 0, 0, 0, None, None) == -1
+    assert hip_lib.jss_rollout_steps(ctypes.byref(d), ctypes.byref(s), ctypes.byref(o), 0, 0, 0, 1, 0, 2, None) == -1
 
 
-def test_no_cpu_fallback():
+def test_no_silent_cpu_fallback():
+    """Without a GPU the default (HIP) path raises; the host-core twin is reachable only by asking for it."""
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     from jssenv_amd import BatchedJssEnv, make
-    with pytest.raises(RuntimeError, match="no CPU path"):
+    with pytest.raises(RuntimeError, match="no silent CPU fallback"):
         BatchedJssEnv("ta01", batch=4)
-    with pytest.raises(RuntimeError, match="no CPU path"):
+    with pytest.raises(RuntimeError, match="no silent CPU fallback"):
         make("jss-v1", env_config={"instance_path": "ta01"})
 
 
@@ -81,6 +91,10 @@ def test_instances_roundtrip_and_taillard():
     assert I.builtin_instance("ta80").jobs == 100 and I.builtin_instance("dmu16").max_time_op == 200
     pk = I.pack_batch([ta01, I.builtin_instance("ta80")])
     assert pk.ops.shape == (2, 100, 20) and pk.ops[0, 15:].max() == 0 and pk.jobs.tolist() == [15, 100]
+    assert pk.inst[0, :5].tolist() == [15, 15, 99, ta01.max_time_jobs, ta01.sum_op]
+    assert pk.inst[0, 5:9].view(np.float32).tolist() == [np.float32(1) / np.float32(v) for v in (99, ta01.max_time_jobs, ta01.sum_op, 15)]
+    assert (pk.rem[0, :15, 0] == ta01.jobs_length).all() and (pk.rem[0, :15, 14] == ta01.duration[:, 14]).all()
+    assert pk.rem[0, 15:].max() == 0 and pk.rem[0, 3, 5] == ta01.duration[3, 5:].sum()
     for row in ta01.machine:
         assert sorted(row.tolist()) == list(range(15))
     syn = I.synthetic_batch(3, 50, 20)

@@ -1,0 +1,117 @@
+"""libjss_cpu.so -- the from-scratch C++/OpenMP twin with the HIP library's C ABI -- against the oracle and the
+golden vectors, through the same host layer and the same parity cases as the GPU path (tests/parity_cases.py
+is backend-agnostic).  Runs everywhere (no GPU); sizes are the GPU suite's."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import parity_cases as P
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    from jssenv_amd.env import CpuBackend
+    be = CpuBackend()
+    assert be.lib.jss_backend().startswith(b"cpu")
+    return be
+
+
+def test_identical_symbols(cpu):
+    import ctypes
+    from jssenv_amd import _abi
+    from jssenv_amd.build import build_extension
+    hip = ctypes.CDLL(build_extension())
+    for name in _abi.SYMBOLS:
+        assert hasattr(hip, name) and hasattr(cpu.lib, name), name
+    assert cpu.lib.jss_abi_version() == hip.jss_abi_version() == _abi.ABI_VERSION
+
+
+@pytest.mark.parametrize("inst", G.PUBLISHED)
+def test_published_schedules(cpu, inst):
+    P.case_published(cpu, inst)
+
+
+@pytest.mark.parametrize("inst", G.RANDOM)
+def test_random_golden(cpu, inst):
+    P.case_random_golden(cpu, inst)
+
+
+def test_batch_ragged_random_policy(cpu):
+    names = ["ta01", "ta11", "ta21", "ta31", "ta41", "ta51", "ta61", "ta71", "dmu16"]
+    P.case_batch_lockstep(cpu, names, batch=18, n_steps=300, kind="random", nope_every=9, check_every=7)
+
+
+@pytest.mark.parametrize("kind", ["FIFO", "SPT", "MWR", "LWR", "MOR", "LOR", "CR"])
+def test_batch_rules(cpu, kind):
+    P.case_batch_lockstep(cpu, ["ta01", "ta21", "ta72"], batch=3, n_steps=2500, kind=kind, check_every=50)
+
+
+def test_rollout(cpu):
+    P.case_rollout(cpu, ["ta01"], batch=32, n_iter=0, chunks=(300, 1, 1, 555))
+    P.case_rollout(cpu, ["ta02", "ta72", "ta45", "dmu17"], batch=8, n_iter=0, chunks=(512, 700), kind="random")
+    P.case_rollout(cpu, ["ta02", "ta72"], batch=4, n_iter=0, chunks=(400,), kind="SPT", autoreset=False)
+
+
+def test_rule_makespans(cpu):
+    P.case_rule_makespans(cpu, insts=("ta01", "ta41", "ta80"))
+
+
+def test_error_semantics(cpu):
+    P.case_error_semantics(cpu)
+    P.case_facade_errors(cpu)
+
+
+def test_state_invariants(cpu):
+    P.case_state_invariants(cpu, episodes=2)
+
+
+def test_dispatching_module(cpu):
+    P.case_dispatching_seeded(cpu)
+    P.case_dispatching_deterministic(cpu, insts=("ta01",))
+
+
+def test_edge_shapes(cpu):
+    P.case_edge_shapes(cpu, steps=200, batch_per_shape=3)
+
+
+def test_vector_env_and_resampling(cpu):
+    P.case_vector_env_features(cpu)
+    P.case_vector_facade(cpu)
+    P.case_instance_resampling(cpu)
+
+
+def test_bucketed_and_rollout_steps(cpu):
+    P.case_bucketed_equals_padded(cpu, n_envs=48, n_iter=400)
+    P.case_rollout_steps(cpu, batch=150, steps=30, n_sub=3)
+
+
+def test_config1_ta01_fifo_on_cpu(cpu):
+    """BASELINE config 1: ta01 single env on CPU, FIFO dispatching rule to completion -- through the reference's own
+    call shape (make + rule(env) + step), no GPU anywhere.  225 steps, makespan 1486 (golden G3)."""
+    from jssenv_amd import dispatching as D, make
+    env = make("jss-v1", env_config={"instance_path": "ta01"}, device="cpu")
+    assert env._b.backend.name == "cpu"
+    real = np.random.random
+    np.random.random = lambda *a, **k: 1.0        # the golden run disabled the rules' 10 % NOPE exploration this way
+    try:
+        env.reset()
+        rule, steps, done = D.get_rule("FIFO"), 0, False
+        while not done:
+            _, _, done, _, _ = env.step(rule(env))
+            steps += 1
+    finally:
+        np.random.random = real
+    assert (steps, env.current_time_step, env.last_time_step) == (225, 1486, 1486)
+
+
+def test_thread_count_does_not_change_results():
+    from jssenv_amd import BatchedJssEnv
+    from jssenv_amd.env import CpuBackend
+    outs = []
+    for threads in (1, 3):
+        env = BatchedJssEnv(["ta01", "ta31"], batch=40, seed=5, _backend=CpuBackend(threads=threads))
+        env.reset()
+        env.rollout("random", n_iter=500)
+        outs.append((env.job_state.copy(), env.counters.copy(), env.real_obs.copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)

@@ -13,13 +13,11 @@ pytestmark = pytest.mark.gpu
 def hip(request):
     """auto: packed kernel (64/G envs per wavefront) where the batch shape fits, wave-per-env
     otherwise; wave: force one wavefront per env everywhere."""
-    from jssenv_amd import _abi
     from jssenv_amd.env import HipBackend
     be = HipBackend("cuda:0")
-    assert be.name == "hip"
-    assert be.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_WAVE if request.param == "wave" else _abi.KERNEL_AUTO) == 0
-    yield be
-    be.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_AUTO)
+    assert be.name == "hip" and be.lib.jss_backend() == b"hip:gfx950"
+    be.default_kernel = request.param                   # the flavour travels per call in JssDesc.kernel
+    return be
 
 
 @pytest.mark.parametrize("inst", G.PUBLISHED)
@@ -203,10 +201,6 @@ def test_vector_facade(hip):
     P.case_vector_facade(hip)
 
 
-def test_persistent_kernel(hip):
-    P.case_persistent_kernel(hip, batch=173, n_steps=400)
-
-
 def test_headline_batch_65536(hip):
     """The benchmarked configuration (ta01, 65 536 envs, random masked policy, one launch per step with
     auto-restart): oracle agreement on a sample and size-independent properties on every env."""
@@ -237,3 +231,7 @@ def test_headline_batch_65536(hip):
 
 def test_instance_resampling(hip):
     P.case_instance_resampling(hip)
+
+
+def test_rollout_steps_equals_rollout(hip):
+    P.case_rollout_steps(hip, batch=5000, steps=40, n_sub=4)

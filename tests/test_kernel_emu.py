@@ -17,11 +17,7 @@ def emu(request):
     """auto: 64/G envs per wavefront where the shape fits (ta01 -> G=16, ta21/ta41/dmu16 -> G=32),
     one wavefront per env otherwise (ta51.., ragged batches up to 100 jobs); wave: force the latter."""
     from emu_backend import EmuBackend
-    from jssenv_amd import _abi
-    be = EmuBackend()
-    assert be.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_WAVE if request.param == "wave" else _abi.KERNEL_AUTO) == 0
-    yield be
-    be.lib.jss_set_option(_abi.OPT_KERNEL, _abi.KERNEL_AUTO)
+    return EmuBackend(default_kernel=request.param)     # the flavour travels per call in JssDesc.kernel
 
 
 def test_published_ta01(emu):
@@ -102,9 +98,9 @@ def test_vector_facade(emu):
     P.case_vector_facade(emu)
 
 
-def test_persistent_kernel(emu):
-    P.case_persistent_kernel(emu, batch=41, n_steps=24)
-
-
 def test_instance_resampling(emu):
     P.case_instance_resampling(emu)
+
+
+def test_rollout_steps_equals_rollout(emu):
+    P.case_rollout_steps(emu, batch=150, steps=4, n_sub=3)
