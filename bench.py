@@ -1,30 +1,36 @@
 #!/usr/bin/env python
 """bench.py -- env steps/sec of the batched JSS hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: re-executes itself under torch.distributed.run,
+                                                            one rank per GPU, RCCL; fails loudly with fewer GPUs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over the batch: ONE launch of the fused
-policy+step kernel (jss_rollout with n_iter = 1) that, for every env, picks a random
-masked action on the device, executes step() and writes the full gym outputs
-(real_obs, action_mask, reward, done) to HBM -- exactly what a reference
-``obs, r, done, _, _ = env.step(policy(obs))`` iteration produces.  Envs found done
-are reset by that launch instead (the iteration is not counted as an env step).
-value = env steps executed by all ranks / max-over-ranks wall time of the K launches.
+One "step" = one pass of the hot path over the batch: for every env, pick a random masked action on the
+device, execute step() and write the full gym outputs (real_obs, action_mask, reward, done) to HBM -- exactly
+what a reference ``obs, r, done, _, _ = env.step(policy(obs))`` iteration produces, fused in one kernel
+(jss_rollout with n_iter = 1).  Envs found done are reset by that pass instead (the iteration is not counted as
+an env step).  A pass is ONE launch over the batch, or -- whichever a short probe finds faster -- n_sub launches
+over n_sub contiguous sub-batches on n_sub HIP streams (jss_rollout_steps): step s of a sub-batch depends only on
+its own step s-1, so one sub-batch's drain overlaps another's fill; results are identical either way.
 
-Workload: BASELINE.json configs[1] shape (ta01, 15x15, one shared instance, random
-masked policy) at the north_star's target batch of 65 536 envs per GPU (weak scaling:
-every rank owns its own 65 536 envs, no data-path collective; one RCCL all-reduce of
-the counters after the timed region).  The configs[1] batch of 4 096 and the fused
-multi-step rollout (state kept in registers for 64 iterations) are measured after the
-timed region and reported as extra fields.
+Timing: W untimed warm-up steps, then >= 5 windows of EXACTLY K steps, each bracketed by barrier +
+torch.cuda.synchronize() on both sides; per window the wall time is the MAX over ranks and the env steps the SUM
+over ranks (one RCCL all-reduce each, outside the timed region).  value = median window; min/max are printed too.
 
-Extra objects: roofline (HBM; algorithmic bytes per launch / HIP-event kernel time) and
-cpu_baseline (the C oracle of oracle/, timed on this box's host cores, rank 0, N = 1).
+Workload: BASELINE.json configs[1] shape (ta01, 15x15, one shared instance, random masked policy) at the
+north_star's target batch of 65 536 envs per GPU (weak scaling: every rank owns its own 65 536 envs, no data-path
+collective).  Extras on the same line (N = 1): the plain one-launch-per-step figure, 4x the batch (beyond the
+256 MB Infinity Cache), per-env synthetic 15x15 tables, BASELINE configs 2-5, the fused 64-step rollout.
+
+Extra objects: roofline (HBM; algorithmic bytes per step / HIP-event time per step), cpu_baseline (the C oracle
+of oracle/, kind "port") and cpu_baseline_twin (libjss_cpu.so, 1 core and all cores), timed on this box's host cores,
+rank 0, N = 1.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
@@ -32,7 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_MEASURED_PEAK_GBS = 6290.0  # measured copy bandwidth, same guide (SURVEY.md 8(d) asks for both)
+N_WINDOWS = 5
 
 
 def b_alg(J, M):
@@ -42,7 +50,10 @@ def b_alg(J, M):
     return 89 * J + 10 * M + 40
 
 
-def cpu_baseline(inst_name, seed, target_seconds=10.0):
+# ------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1, after the GPU measurement)
+# ------------------------------------------------------------------------------------------------------------
+def cpu_baseline_port(inst_name, seed, target_seconds=8.0):
     """The C oracle (a scalar restatement of the reference's step(), oracle/jss_oracle.c) running
     the same policy+step loop on this box's host cores, one env per thread."""
     import concurrent.futures as cf
@@ -74,23 +85,59 @@ def cpu_baseline(inst_name, seed, target_seconds=10.0):
                       f"({steps} env steps, {dt:.1f} s, one env per thread; 1 thread alone = {1.0 / per_step:.0f} steps/s)"}
 
 
-def main():
+def cpu_baseline_twin(inst_name, seed, target_seconds=4.0):
+    """libjss_cpu.so (the from-scratch C++/OpenMP twin with the HIP library's C ABI): same policy+step loop over a
+    batch of envs, on one core and on all cores."""
+    from jssenv_amd import BatchedJssEnv
+    from jssenv_amd.env import CpuBackend
+    cores = os.cpu_count() or 1
+    out = {"unit": "env steps/s", "kind": "twin", "library": "libjss_cpu.so (C++17 + OpenMP over envs)"}
+    for label, threads, batch in (("one_core", 1, 256), ("all_cores", cores, 64 * cores)):
+        env = BatchedJssEnv(inst_name, batch=batch, seed=seed, _backend=CpuBackend(threads=threads))
+        env.reset()
+        env.rollout("random", n_iter=300)
+        env.zero_counters()
+        t0 = time.perf_counter()
+        env.rollout("random", n_iter=200)
+        cal = time.perf_counter() - t0
+        iters = int(max(200, 200 * target_seconds / max(cal, 1e-6)))
+        env.zero_counters()
+        t0 = time.perf_counter()
+        env.rollout("random", n_iter=iters)
+        dt = time.perf_counter() - t0
+        steps = env.stats()["steps"]
+        out[label] = {"value": steps / dt, "cores": threads,
+                      "sample": f"{inst_name} random-masked policy+step, {batch} envs x {iters} iterations ({steps} env steps, {dt:.1f} s)"}
+    out["value"], out["cores"] = out["all_cores"]["value"], cores
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--batch", type=int, default=65536, help="envs per GPU (weak scaling) / whole job (strong scaling)")
     ap.add_argument("--instance", default="ta01")
     ap.add_argument("--policy", default="random")
-    ap.add_argument("--workload", default="shared", choices=["shared", "synthetic50x20", "mixed"],
+    ap.add_argument("--workload", default="shared",
+                    choices=["shared", "synthetic15x15", "synthetic50x20", "mixed"],
                     help="shared: one instance (--instance) for the whole batch [default, the headline]; "
-                         "synthetic50x20: BASELINE config 4, one Taillard-LCG instance per env; "
+                         "synthetic15x15 / synthetic50x20: one Taillard-LCG instance per env (50x20 = BASELINE config 4); "
                          "mixed: BASELINE config 5, env i <- ta(1 + i %% 80), padded 100x20")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch envs per GPU; strong: --batch envs in total, split by shard_bounds")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
-                    help="graph: replay a hipGraph of the K launches; eager: one Python/ctypes launch per step; "
-                         "auto: whichever is faster on a short probe (graphs win when the kernel is shorter than "
-                         "the ~7 us host enqueue, eager wins at large batches)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager", "sub2", "sub4"],
+                    help="how a step is issued: eager = one ctypes launch; graph = hipGraph replay of the K launches; "
+                         "sub2 / sub4 = 2 / 4 sub-batches on as many streams (jss_rollout_steps); auto = fastest on a probe")
     ap.add_argument("--bucketed", action="store_true",
                     help="mixed workload only: one compact sub-batch per shape class (BucketedJssEnv) instead of "
                          "padding every env to 100x20")
@@ -100,20 +147,43 @@ def main():
                          "--dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: become N ranks."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and not args.share_device:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s); refusing to run "
+                         f"{args.gpus} ranks on fewer devices (no oversubscription, no silent fallback to 1 GPU)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    os.execv(sys.executable, cmd)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
 
     import torch
     import torch.distributed as dist
     from jssenv_amd import BatchedJssEnv, builtin_instance
-    from jssenv_amd.distributed import reduce_counters
+    from jssenv_amd.distributed import reduce_counters, shard_bounds
+    from jssenv_amd.instances import synthetic_packed
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+        raise SystemExit("bench.py needs an MI355X; the GPU path has no CPU fallback")
     if args.share_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = args.dist_backend or "nccl"   # "nccl" is RCCL on ROCm
@@ -121,199 +191,268 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": dev} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        assert dist.get_world_size() == world
+    on_host = world > 1 and backend != "nccl"
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    inst = builtin_instance(args.instance)
-    B = args.batch
+    def agree_max(values):
+        """element-wise MAX over ranks of a list of floats (every rank must take the same decisions)"""
+        t = torch.tensor(values, dtype=torch.float64)
+        if world > 1:
+            t = t if on_host else t.to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
 
-    def instances_for(batch):
-        """(instances, mean algorithmic bytes per env step, label)."""
-        if args.workload == "synthetic50x20":
-            from jssenv_amd import synthetic_batch
-            return synthetic_batch(batch, 50, 20, first=rank * batch), b_alg(50, 20), "synthetic 50x20 (Taillard LCG), one instance per env"
-        if args.workload == "mixed":
+    # ---- workloads ------------------------------------------------------------------------------------------
+    def describe(workload, instance="ta01"):
+        """(mean algorithmic bytes per env step, label, traffic key)"""
+        if workload == "synthetic15x15":
+            return b_alg(15, 15), "synthetic 15x15 (Taillard LCG), one instance per env", "syn15x15"
+        if workload == "synthetic50x20":
+            return b_alg(50, 20), "synthetic 50x20 (Taillard LCG), one instance per env", "syn50x20"
+        if workload == "mixed":
             insts = [builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
-            mean = sum(b_alg(i.jobs, i.machines) for i in insts) / 80.0
-            return insts, mean, "mixed ta01-ta80 (env i <- ta(1 + i % 80)), padded 100x20"
-        return inst, b_alg(inst.jobs, inst.machines), f"{args.instance} ({inst.jobs}x{inst.machines}) shared instance"
+            return sum(b_alg(i.jobs, i.machines) for i in insts) / 80.0, "mixed ta01-ta80 (env i <- ta(1 + i % 80))", "mixed"
+        inst = builtin_instance(instance)
+        return b_alg(inst.jobs, inst.machines), f"{instance} ({inst.jobs}x{inst.machines}) one instance shared by the batch", instance
 
-    def make_env(batch):
-        insts, _, _ = instances_for(batch)
-        if args.bucketed and args.workload == "mixed":
+    def make_env(workload, batch, first_env, policy, instance="ta01", bucketed=False, spread=True):
+        if workload == "mixed" and bucketed:
             from jssenv_amd import BucketedJssEnv
-            e = BucketedJssEnv(insts, batch=batch, device=dev, seed=args.seed, env_id_base=rank * batch)
+            insts = [builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
+            e = BucketedJssEnv(insts, batch=batch, device=dev, seed=args.seed, env_id_base=first_env)
             e.reset()
-            e.rollout(args.policy, n_iter=333, autoreset=True)
+            e.rollout(policy, n_iter=333, autoreset=True)
             e.zero_counters()
             return e
-        e = BatchedJssEnv(insts, batch=batch, device=dev, seed=args.seed, env_id_base=rank * batch)
+        if workload == "synthetic15x15":
+            src = synthetic_packed(batch, 15, 15, first=first_env)
+        elif workload == "synthetic50x20":
+            src = synthetic_packed(batch, 50, 20, first=first_env)
+        elif workload == "mixed":
+            src = [builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
+        else:
+            src = builtin_instance(instance)
+        e = BatchedJssEnv(src, batch=batch, device=dev, seed=args.seed, env_id_base=first_env)
         e.reset()
-        # Spread the episode phases (a fresh batch is in lock step: every env at step 0) so the timed
-        # window sees the steady-state mix of episode stages: env i is advanced (i % 16) * 16 extra
-        # steps through the separate policy + step kernels, skipping (-1) the envs that are ahead.
-        ids = torch.arange(batch, device=dev) % 16
-        for r in range(15):
-            for _ in range(16):
-                a = e.policy(args.policy)
-                a = torch.where(ids > r, a, torch.full_like(a, -1))
-                e.step(a)
-        e.rollout(args.policy, n_iter=64, autoreset=True)
+        if spread:
+            # Spread the episode phases (a fresh batch is in lock step: every env at step 0) so the timed
+            # window sees the steady-state mix of episode stages: env i is advanced (i % 16) * 16 extra
+            # steps through the separate policy + step kernels, skipping (-1) the envs that are ahead.
+            ids = torch.arange(batch, device=dev) % 16
+            skip = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+            for r in range(15):
+                for _ in range(16):
+                    e.step(torch.where(ids > r, e.policy(policy), skip))
+        e.rollout(policy, n_iter=64, autoreset=True)
         e.zero_counters()
         return e
 
-    def timed(env, n_launch, n_iter, mode):
-        """Time n_launch launches of jss_rollout(n_iter).  Returns (max-over-ranks-able wall seconds,
-        GPU ms per launch from HIP events on the launch stream)."""
+    # ---- timing ---------------------------------------------------------------------------------------------
+    def window(env, policy, n_launch, n_iter, mode, graph=None):
+        """Time n_launch steps.  Returns (wall seconds, GPU ms per step from HIP events on the launch stream)."""
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        graph = None
-        bucketed = hasattr(env, "rollout_steps")
-        if mode == "graph" and not bucketed:
-            # the launches go to torch's current stream, so a torch CUDAGraph captures them: one host call
-            # replays all n_launch kernels (the Python+ctypes enqueue costs ~7 us per launch otherwise)
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
-                    for _ in range(n_launch):
-                        env.rollout(args.policy, n_iter=n_iter, autoreset=True)
-            torch.cuda.current_stream(dev).wait_stream(side)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record()
         if graph is not None:
             graph.replay()
-        elif bucketed:   # one fork/join around the window, every bucket's launches on its own stream
-            env.rollout_steps(args.policy, steps=n_launch, n_iter=n_iter, autoreset=True)
+        elif hasattr(env, "rollout_steps") and mode.startswith("sub"):
+            env.rollout_steps(policy, steps=n_launch, n_sub=int(mode[3:]), autoreset=True)
+        elif hasattr(env, "buckets"):   # one fork/join around the window, every bucket's launches on its own stream
+            env.rollout_steps(policy, steps=n_launch, n_iter=n_iter, autoreset=True)
         else:
             for _ in range(n_launch):
-                env.rollout(args.policy, n_iter=n_iter, autoreset=True)
+                env.rollout(policy, n_iter=n_iter, autoreset=True)
         ev1.record()
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
         return dt, ev0.elapsed_time(ev1) / n_launch
 
-    env = make_env(B)
-    for _ in range(args.warmup):
-        env.rollout(args.policy, n_iter=1, autoreset=True)
-    torch.cuda.synchronize()
+    def capture(env, policy, n_launch):
+        # the launches go to torch's current stream, so a torch CUDAGraph captures them: one host call
+        # replays all n_launch kernels (the Python+ctypes enqueue costs ~7 us per launch otherwise)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(n_launch):
+                    env.rollout(policy, n_iter=1, autoreset=True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        return graph
 
-    def pick_mode(e):
-        if hasattr(e, "rollout_steps"):
+    def pick_mode(env, policy, candidates):
+        if hasattr(env, "buckets"):
             return "eager"
         if args.launch != "auto":
             return args.launch
-        probe = {m: timed(e, 40, 1, m)[0] for m in ("graph", "eager")}
-        t = torch.tensor([probe["graph"], probe["eager"]], dtype=torch.float64)
-        if world > 1:   # every rank must take the same decision
-            t = t.to(dev) if backend == "nccl" else t
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return "graph" if float(t[0]) <= float(t[1]) else "eager"
+        probe = []
+        for m in candidates:
+            g = capture(env, policy, 40) if m == "graph" else None
+            window(env, policy, 40, 1, m, g)
+            probe.append(min(window(env, policy, 40, 1, m, g)[0] for _ in range(2)))
+            del g
+        probe = agree_max(probe)
+        return candidates[probe.index(min(probe))]
 
-    mode = pick_mode(env)
-    env.zero_counters()
-    dt, kernel_ms = timed(env, args.steps, 1, mode)
-    # the only collectives: SUM of the 4 counters and MAX of the wall time, over RCCL/xGMI
-    on_host = world > 1 and backend != "nccl"
-    tot = reduce_counters(env.counter_totals().cpu() if on_host else env.counter_totals(), dt)
-    steps_total, episodes, makespan_sum, reward_num = tot["steps"], tot["episodes"], tot["makespan_sum"], tot["reward_num_sum"]
-    dt_max = tot["seconds"]
-    value = steps_total / dt_max
+    def measure(env, policy, steps, mode, n_iter=1, windows=N_WINDOWS):
+        """`windows` windows of `steps` steps each.  Returns the per-window lists, already reduced over ranks."""
+        graph = capture(env, policy, steps) if mode == "graph" else None
+        rows = []
+        for _ in range(windows):
+            env.zero_counters()
+            dt, ms = window(env, policy, steps, n_iter, mode, graph)
+            tot = reduce_counters(env.counter_totals().cpu() if on_host else env.counter_totals(), dt)
+            ms = agree_max([ms])[0]
+            rows.append({"steps": tot["steps"], "seconds": tot["seconds"], "rate": tot["steps"] / tot["seconds"],
+                         "kernel_ms": ms, "episodes": tot["episodes"], "makespan_sum": tot["makespan_sum"],
+                         "reward_num": tot["reward_num_sum"]})
+        del graph
+        rows.sort(key=lambda r: r["rate"])
+        med = rows[len(rows) // 2]
+        return med, rows
 
-    # roofline of the dominant (only) kernel: algorithmic bytes per launch / HIP-event time per launch
-    stepped_per_launch = steps_total / world / args.steps
-    _, alg_per_step, wl_label = instances_for(1 if args.workload != "mixed" else 80)
-    alg_bytes = stepped_per_launch * alg_per_step
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    jm, mm = env.jmax, env.mmax
-    kernel_name = ("jss_packed_kernel<%d,kRollout1>" % (16 if max(jm, mm) <= 16 else 32)
-                   if max(jm, mm) <= 32 else "jss_kernel<%d,kRollout1>" % (1 if jm <= 64 else 2))
-    if args.bucketed and args.workload == "mixed":
-        kernel_name = "four launches per step: jss_packed_kernel<16|32,kRollout1>, jss_kernel<1|2,kRollout1>"
-        wl_label += ", shape-bucketed (no padding)"
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.isfile(prof):
+    def launch_label(mode):
+        return {"eager": "one launch per step (ctypes, eager)", "graph": "one launch per step, hipGraph replay of the K launches",
+                "sub2": "2 sub-batches on 2 HIP streams per step (jss_rollout_steps)",
+                "sub4": "4 sub-batches on 4 HIP streams per step (jss_rollout_steps)"}.get(mode, mode)
+
+    def kernel_name(env):
+        if hasattr(env, "buckets"):
+            return "four launches per step: jss_packed_kernel<16|32,kRollout1,*>, jss_kernel<1|2,kRollout1,*>"
+        tab = "kTabLds" if env.n_tables == 1 else "kTabGlobal"
+        jm, mm = env.jmax, env.mmax
+        if max(jm, mm) <= 32:
+            return f"jss_packed_kernel<{16 if max(jm, mm) <= 16 else 32},kRollout1,{tab}>"
+        return f"jss_kernel<{1 if jm <= 64 else 2},kRollout1,{tab}>"
+
+    def static_traffic(key, batch):
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         try:
             with open(prof) as fh:
-                traffic = json.load(fh).get(f"{args.instance}_b{B}", {}).get("bytes_per_launch")
+                ent = json.load(fh).get(f"{key}_b{batch}")
+            return (ent["bytes_per_launch"], f"profiles/{ent['source']} (static: rocprofv3 PMC passes, not re-measured in this run)") if ent else (None, None)
         except Exception:
-            traffic = None
+            return None, None
 
+    def roofline(med, alg_per_step, steps, env, key, batch):
+        stepped = med["steps"] / world / steps
+        achieved = stepped * alg_per_step / (med["kernel_ms"] * 1e-3) / 1e9
+        traffic, src = static_traffic(key, batch)
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_PEAK_GBS,
+                "measured_peak": HBM_MEASURED_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                "kernel": kernel_name(env), "kernel_ms": med["kernel_ms"],
+                "alg_bytes_per_env_step": alg_per_step, "env_steps_per_launch": stepped}
+
+    def side_run(workload, batch, policy, label_extra="", instance="ta01", bucketed=False, modes=("eager", "graph", "sub2")):
+        """One extra workload on this GPU: median of N_WINDOWS windows, same timing discipline as the headline."""
+        alg, label, key = describe(workload, instance)
+        env = make_env(workload, batch, rank * batch, policy, instance=instance, bucketed=bucketed)
+        for _ in range(args.warmup):
+            env.rollout(policy, n_iter=1, autoreset=True)
+        mode = pick_mode(env, policy, list(modes))
+        med, rows = measure(env, policy, args.steps, mode)
+        rf = roofline(med, alg, args.steps, env, key, batch)
+        out = {"workload": label + label_extra, "batch": batch, "policy": policy, "value": med["rate"],
+               "min": rows[0]["rate"], "max": rows[-1]["rate"], "unit": "env steps/s", "ms_per_step": med["seconds"] / args.steps * 1e3,
+               "launch": launch_label(mode), "kernel": rf["kernel"], "roofline_frac": rf["frac"],
+               "roofline_frac_of_measured_peak": rf["frac_of_measured_peak"], "alg_bytes_per_env_step": alg,
+               "traffic": rf["traffic"], "mean_makespan": med["makespan_sum"] / med["episodes"] if med["episodes"] else None}
+        if hasattr(env, "close"):
+            env.close()
+        del env
+        return out
+
+    # ---- the headline ------------------------------------------------------------------------------------------
+    alg_per_step, wl_label, key = describe(args.workload, args.instance)
+    if args.scaling == "strong":
+        lo, hi = shard_bounds(args.batch, world, rank)
+        B, first_env = hi - lo, lo
+    else:
+        B, first_env = args.batch, rank * args.batch
+    env = make_env(args.workload, B, first_env, args.policy, instance=args.instance, bucketed=args.bucketed)
+    for _ in range(args.warmup):
+        env.rollout(args.policy, n_iter=1, autoreset=True)
+    torch.cuda.synchronize()
+    mode = pick_mode(env, args.policy, ["eager", "graph", "sub2", "sub4"])
+    med, rows = measure(env, args.policy, args.steps, mode)
+    bucket_note = ", shape-bucketed (no padding)" if (args.bucketed and args.workload == "mixed") else \
+        (", padded 100x20" if args.workload == "mixed" else "")
+    inst0 = builtin_instance(args.instance)
     out = {
-        "metric": "env steps/sec (batched)", "value": value, "unit": "env steps/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "launch": ("per-bucket streams, eager launches, one fork/join around the K steps" if hasattr(env, "rollout_steps")
-                   else "eager (one ctypes launch per step)" if mode == "eager" else "hipGraph replay of the K launches"),
-        "config": {"workload": f"{wl_label}, {args.policy} masked "
-                               f"policy fused with step(), batch {B} envs per GPU, one launch per env step, "
+        "metric": "env steps/sec (batched)", "value": med["rate"], "unit": "env steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": med["seconds"] / args.steps * 1e3,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int32",
+        "data": ("ta01 (the reference's Taillard instance; no dataset involved)" if args.workload == "shared" and args.instance == "ta01"
+                 else "synthetic" if args.workload.startswith("synthetic") else "reference instances (ta01-ta80)"),
+        "windows": {"n": len(rows), "steps_each": args.steps, "statistic": "median", "min": rows[0]["rate"], "max": rows[-1]["rate"],
+                    "all": [r["rate"] for r in rows]},
+        "launch": launch_label(mode),
+        "config": {"workload": f"{wl_label}{bucket_note}, {args.policy} masked policy fused with step(), "
+                               f"{'batch %d envs per GPU' % B if args.scaling == 'weak' else 'batch %d envs in total (%d on this rank)' % (args.batch, B)}, "
                                f"full obs/mask/reward/done written every step, auto-restart",
-                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"env-shard x{world}",
-                   "policy": args.policy},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": kernel_name, "kernel_ms": kernel_ms,
-                     "alg_bytes_per_env_step": alg_per_step,
-                     "env_steps_per_launch": stepped_per_launch},
-        "episodes_finished": episodes,
-        "mean_makespan": makespan_sum / episodes if episodes else None,
-        "mean_reward_per_step": reward_num / inst.max_time_op / steps_total if steps_total else None,
+                   "batch_per_gpu": B, "global_batch": args.batch * world if args.scaling == "weak" else args.batch,
+                   "parallelism": f"env-shard x{world}", "policy": args.policy},
+        "roofline": roofline(med, alg_per_step, args.steps, env, key, B),
+        "episodes_finished": med["episodes"],
+        "mean_makespan": med["makespan_sum"] / med["episodes"] if med["episodes"] else None,
+        "mean_reward_per_step": (med["reward_num"] / inst0.max_time_op / med["steps"]) if (med["steps"] and args.workload == "shared") else None,
     }
 
-    if not args.no_extras:
+    if not args.no_extras and not hasattr(env, "buckets"):
+        if mode != "eager" and mode != "graph":
+            # the plain form: ONE launch per step over the whole batch (the kernel duration rocprofv3 reports)
+            m1 = pick_mode(env, args.policy, ["eager", "graph"]) if args.launch == "auto" else "eager"
+            med1, rows1 = measure(env, args.policy, args.steps, m1)
+            out["single_launch_per_step"] = {"value": med1["rate"], "min": rows1[0]["rate"], "max": rows1[-1]["rate"],
+                                             "kernel_ms": med1["kernel_ms"], "launch": launch_label(m1),
+                                             "roofline_frac": roofline(med1, alg_per_step, args.steps, env, key, B)["frac"]}
         # fused multi-step rollout: 64 iterations per launch, state in registers, outputs once per launch
-        env.zero_counters()
         n_l = max(4, args.steps // 16)
-        dtf, _ = timed(env, n_l, 64, "eager")
-        totf = reduce_counters(env.counter_totals().cpu() if on_host else env.counter_totals(), dtf)
-        out["fused_rollout"] = {"value": totf["steps_per_second"], "unit": "env steps/s",
-                                "iterations_per_launch": 64, "launches": n_l,
+        medf, _ = measure(env, args.policy, n_l, "eager", n_iter=64, windows=3)
+        out["fused_rollout"] = {"value": medf["rate"], "unit": "env steps/s", "iterations_per_launch": 64, "launches": n_l,
                                 "note": "policy+step x64 per launch, observation written once per launch"}
-        if world == 1 and args.workload == "shared":
-            # twice the contract batch: same kernel, four rounds of resident waves instead of two
-            env2x = make_env(2 * B)
-            for _ in range(args.warmup):
-                env2x.rollout(args.policy, n_iter=1, autoreset=True)
-            mode2 = pick_mode(env2x)
-            env2x.zero_counters()
-            dt2, ms2 = timed(env2x, args.steps, 1, mode2)
-            steps2 = float(env2x.counter_totals()[0].item())
-            out["batch_x2"] = {"batch": 2 * B, "value": steps2 / dt2, "unit": "env steps/s", "kernel_ms": ms2,
-                               "roofline_frac": steps2 / args.steps * alg_per_step / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "launch": mode2}
-            del env2x
-            env4k = make_env(4096)
-            for _ in range(args.warmup):
-                env4k.rollout(args.policy, n_iter=1, autoreset=True)
-            mode4 = pick_mode(env4k)
-            env4k.counters.zero_()
-            dt4, ms4 = timed(env4k, args.steps, 1, mode4)
-            out["configs1_batch4096"] = {"value": float(env4k.counters[:, 0].sum().item()) / dt4,
-                                         "unit": "env steps/s", "kernel_ms": ms4, "launch": mode4}
+    if not args.no_extras and world == 1 and args.workload == "shared" and args.scaling == "weak":
+        if hasattr(env, "close"):
+            env.close()
+        del env
+        env = None
+        out["batch_x4"] = side_run("shared", 4 * B, args.policy, label_extra=" -- 4x the batch: 420 MB working set, beyond the Infinity Cache",
+                                   instance=args.instance, modes=("eager", "sub2", "sub4"))
+        out["synthetic15x15_per_env_tables"] = side_run("synthetic15x15", B, args.policy, modes=("eager", "graph", "sub2", "sub4"))
+        out["config2_ta01_batch4096_random"] = side_run("shared", 4096, "random", modes=("eager", "graph"))
+        out["config3_ta41_spt_batch16384"] = side_run("shared", 16384, "SPT", instance="ta41")
+        out["config4_synthetic50x20_batch8192"] = side_run("synthetic50x20", 8192, "random")
+        out["config5_mixed_padded_batch32768"] = side_run("mixed", 32768, "random", label_extra=", padded 100x20")
+        out["config5_mixed_bucketed_batch32768"] = side_run("mixed", 32768, "random", label_extra=", shape-bucketed (no padding)",
+                                                            bucketed=True)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "shared":
-        out["cpu_baseline"] = cpu_baseline(args.instance, args.seed)
+        out["cpu_baseline"] = cpu_baseline_port(args.instance, args.seed)
+        out["cpu_baseline_twin"] = cpu_baseline_twin(args.instance, args.seed)
     elif rank == 0:
         out["cpu_baseline"] = None
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    # orderly teardown: graphs were local to timed(); drop the envs (and the bucketed env's side streams)
-    # while the runtime is still fully alive
+    # orderly teardown: graphs were local to measure(); drop the envs (and their side streams) while the
+    # runtime is still fully alive
     torch.cuda.synchronize()
-    if hasattr(env, "close"):
+    if env is not None and hasattr(env, "close"):
         env.close()
     del env
     import gc
     gc.collect()
     torch.cuda.synchronize()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -217,6 +217,7 @@ class BatchedJssEnv:
     def __init__(self, instances, batch: Optional[int] = None, device=None, env_id_base: int = 0,
                  table_of_env: Optional[Sequence[int]] = None, seed: int = 0, kernel: Optional[str] = None,
                  _backend=None):
+        self._owns_backend = _backend is None
         self.backend = be = _backend if _backend is not None else make_backend(device)
         if isinstance(instances, PackedBatch):
             pk = instances
@@ -430,6 +431,12 @@ class BatchedJssEnv:
 
     def synchronize(self):
         self.backend.sync()
+
+    def close(self):
+        """Wait for outstanding work and drop the side streams this env's own backend created."""
+        self.synchronize()
+        if self._owns_backend:
+            self.backend.close()
 
     # -- state views with the reference's names (device arrays, batch first) ---------------
     @property

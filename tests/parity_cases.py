@@ -577,3 +577,95 @@ def case_rollout_steps(backend, batch=150, steps=6, n_sub=3, seed=31):
         raise AssertionError("n_sub > 16 must be rejected")
     except ValueError:
         pass
+
+
+# -----------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5: size-independent properties on every env + the oracle on a sample
+# -----------------------------------------------------------------------------------------
+def one_episode_properties(env, dur, mach, jobs, machines, sum_op, what):
+    """Checks on EVERY env of a batch that ran exactly one episode (no auto-restart): all ops scheduled, job
+    order respected, makespan = last op end = clock, reward identity sum(reward numerators) =
+    2 * sum_op - M * makespan, no error flags; machine exclusivity on a sample.
+    dur / mach: (B, Jmax, Mmax) arrays (padding = 0), jobs / machines / sum_op: (B,)."""
+    N = env.backend.numpy
+    B = env.batch
+    assert N(env.done).all(), f"{what}: every episode must have ended"
+    assert int(N(env.err).max()) == 0, f"{what}: error flags"
+    sol = N(env.solution)
+    mk = N(env.makespan).astype(np.int64)
+    cnt = N(env.counters)
+    jj = np.arange(sol.shape[1])[None, :, None] < jobs[:, None, None]
+    mm = np.arange(sol.shape[2])[None, None, :] < machines[:, None, None]
+    real = jj & mm
+    assert (sol[real] >= 0).all(), f"{what}: unscheduled ops"
+    end = np.where(real, sol + dur, 0)
+    order_ok = (sol[:, :, 1:] >= end[:, :, :-1]) | ~real[:, :, 1:]
+    assert order_ok.all(), f"{what}: ops of a job out of order"
+    assert (end.max(axis=(1, 2)) == mk).all() and (mk == N(env.clock)).all(), f"{what}: makespan"
+    assert (cnt[:, 1] == 1).all() and (cnt[:, 2] == mk).all(), f"{what}: episode counters"
+    assert (cnt[:, 3] == 2 * sum_op.astype(np.int64) - machines.astype(np.int64) * mk).all(), f"{what}: reward identity"
+    todo = N(env.todo_time_step_job)
+    assert (np.where(jj[:, :, 0], todo, machines[:, None]) == machines[:, None]).all(), f"{what}: todo"
+    for b in range(0, B, max(1, B // 257)):                       # machine exclusivity on ~257 envs
+        J, M = int(jobs[b]), int(machines[b])
+        for m in range(M):
+            sel = mach[b, :J, :M] == m
+            s0, e0 = sol[b, :J, :M][sel], end[b, :J, :M][sel]
+            o = np.argsort(s0)
+            assert (s0[o][1:] >= e0[o][:-1]).all(), f"{what}: env {b} machine {m} overlaps"
+    return sol, mk, cnt
+
+
+def oracle_episode(inst, seed, env_id, episode=1):
+    orc = OracleEnv(inst, strict=True)
+    orc.reset()
+    st = 0
+    while orc.nb_legal_actions:
+        orc.step(orc.policy("random", seed=seed, env_id=env_id, episode=episode, step=st))
+        st += 1
+    return orc, st
+
+
+def case_config5_mixed(backend, batch=32768, seed=21):
+    """env i <- ta(1 + i % 80), padded 100x20, ragged J/M; one random episode per env, then the benchmarked
+    auto-restart mode against the oracle's rollout."""
+    insts = [I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
+    env = BatchedJssEnv(insts, batch=batch, seed=seed, _backend=backend)
+    env.reset()
+    env.rollout("random", n_iter=6000, autoreset=False)
+    pk, t = env.packed, env.table_of_env_host
+    dur, mach = (pk.ops & 0xFFFF)[t], (pk.ops >> 16)[t]
+    sol, mk, cnt = one_episode_properties(env, dur, mach, pk.jobs[t], pk.machines[t], pk.sum_op[t], "config 5")
+    first = 80 * 5 if batch >= 80 * 6 else 0
+    for i in range(first, min(batch, first + 80)):                  # one env per instance
+        orc, st = oracle_episode(insts[i % 80], seed, i)
+        J, M = orc.jobs, orc.machines
+        assert orc.current_time_step == mk[i] and (orc.solution == sol[i, :J, :M]).all() and st == cnt[i, 0], f"mixed env {i}"
+        assert_matches_oracle(env.host_state(i), orc, f"mixed env {i}")
+    env.reset()
+    env.zero_counters()
+    env.rollout("random", n_iter=700, autoreset=True)
+    cnt = env.backend.numpy(env.counters)
+    for i in sorted({x for x in list(range(0, 80, 9)) + [79, 80 + 70, batch - 1] if x < batch}):
+        orc = OracleEnv(insts[i % 80], strict=True)
+        orc.reset()
+        r = orc.rollout("random", seed, i, 700, episode=2, step_in_episode=0)
+        assert_matches_oracle(env.host_state(i), orc, f"mixed env {i} (auto-restart)")
+        assert cnt[i, 0] == r["steps"] and cnt[i, 1] == r["episodes"] and cnt[i, 2] == r["makespan_sum"]
+
+
+def case_config4_synthetic(backend, batch=8192, seed=4, sample=64):
+    """Taillard-LCG 50x20 instances, one table per env (time_seed = 1 + 2i, machine_seed = 2 + 2i)."""
+    pk = I.synthetic_packed(batch, 50, 20)
+    env = BatchedJssEnv(pk, seed=seed, _backend=backend)
+    assert env.n_tables == batch
+    env.reset()
+    env.rollout("random", n_iter=4000, autoreset=False)
+    dur, mach = pk.ops & 0xFFFF, pk.ops >> 16
+    sol, mk, cnt = one_episode_properties(env, dur, mach, pk.jobs, pk.machines, pk.sum_op, "config 4")
+    for i in range(0, batch, max(1, batch // sample)):
+        inst = I.Instance(f"syn{i}", mach[i], dur[i])
+        assert (inst.packed() == I.synthetic_batch(1, 50, 20, first=i)[0].packed()).all()
+        orc, st = oracle_episode(inst, seed, i)
+        assert orc.current_time_step == mk[i] and (orc.solution == sol[i]).all() and st == cnt[i, 0], f"synthetic env {i}"
+        assert_matches_oracle(env.host_state(i), orc, f"synthetic env {i}")

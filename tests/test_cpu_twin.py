@@ -115,3 +115,9 @@ def test_thread_count_does_not_change_results():
         outs.append((env.job_state.copy(), env.counters.copy(), env.real_obs.copy()))
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b)
+
+
+def test_configs_4_and_5_reduced(cpu):
+    """The GPU suite's full-size config 4 / 5 cases at a size the host cores finish in seconds."""
+    P.case_config4_synthetic(cpu, batch=192, sample=16)
+    P.case_config5_mixed(cpu, batch=640)

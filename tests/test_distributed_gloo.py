@@ -1,16 +1,22 @@
-"""World-size-2 gloo test (CPU) of the sharding + counter reduction used by bench.py --gpus N.
-Each rank steps its own shard of envs with the oracle as a stand-in stepping engine (the
-partitioning, RNG keying by global env id and the collectives are what is under test)."""
+"""World-size-2 tests of the sharding + counter reduction used by bench.py --gpus N (gloo; the GPU box runs
+the same worker through the HIP engine with both ranks on its one GPU).
+
+Each rank owns the contiguous slice shard_bounds() gives it, builds its own BatchedJssEnv with
+env_id_base = first env of the slice (the RNG is keyed by the GLOBAL env id) and steps it with no data-path
+collective; the only exchange is reduce_counters().  The union of the shards must be bit-identical to one
+process stepping the whole batch."""
 import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INSTANCES = ("ta01", "ta31", "ta02")
 
 
 def _free_port():
@@ -19,28 +25,60 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, global_batch, iters, q):
+def _run_shard(device, lo, hi, iters, seed):
+    from jssenv_amd import BatchedJssEnv
+    env = BatchedJssEnv(list(INSTANCES), batch=hi - lo, device=device, seed=seed, env_id_base=lo,
+                        table_of_env=(np.arange(lo, hi) % len(INSTANCES)))
+    env.reset()
+    env.rollout("random", n_iter=iters)             # fused policy + step, auto-restart
+    env.rollout_steps("random", steps=5, n_sub=2)   # and the sub-batch form on top
+    env.synchronize()
+    n = env.backend.numpy
+    return env, {k: n(getattr(env, k)) for k in env._STATE_TENSORS}
+
+
+def _worker(rank, world, port, device, global_batch, iters, seed, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
-    from jssenv_amd import builtin_instance
     from jssenv_amd.distributed import init_from_env, reduce_counters, shard_bounds
-    from oracle import OracleEnv
     r, w, _ = init_from_env("gloo")
     assert (r, w) == (rank, world)
     lo, hi = shard_bounds(global_batch, world, rank)
-    inst = builtin_instance("ta01")
-    counters = torch.zeros(hi - lo, 4, dtype=torch.int64)
-    for i, env_id in enumerate(range(lo, hi)):          # env_id_base = lo keys the RNG by GLOBAL env id
-        o = OracleEnv(inst, strict=True)
-        o.reset()
-        res = o.rollout("random", 7, env_id, iters, episode=1)
-        counters[i] = torch.tensor([res["steps"], res["episodes"], res["makespan_sum"],
-                                    round(res["reward_sum"] * inst.max_time_op)])
+    env, tensors = _run_shard(device, lo, hi, iters, seed)
     dist.barrier()
-    out = reduce_counters(counters, wall_seconds=1.0 + rank)
-    q.put((rank, lo, hi, out))
+    out = reduce_counters(torch.from_numpy(tensors["counters"]), wall_seconds=1.0 + rank)
+    q.put((rank, lo, hi, env.backend.lib.jss_backend().decode(), tensors, out))
+    dist.barrier()
     dist.destroy_process_group()
+
+
+def _two_ranks_equal_one_process(device, global_batch, iters, seed=7):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, device, global_batch, iters, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    half = global_batch // 2
+    assert [(r[1], r[2]) for r in results] == [(0, global_batch - half), (global_batch - half, global_batch)]
+    # both ranks hold the same whole-job totals, and the wall time is the MAX over ranks
+    assert results[0][5] == results[1][5] and results[0][5]["seconds"] == 2.0
+    # single-process ground truth over the whole batch, same engine
+    _, whole = _run_shard(device, 0, global_batch, iters, seed)
+    for name, want in whole.items():
+        got = np.concatenate([results[0][4][name], results[1][4][name]], axis=0)
+        assert np.array_equal(got, want), f"union of the two shards differs from the unsharded batch in {name}"
+    tot = results[0][5]
+    c = whole["counters"].sum(axis=0)
+    assert (tot["steps"], tot["episodes"], tot["makespan_sum"], tot["reward_num_sum"]) == tuple(float(x) for x in c)
+    assert tot["steps"] > 0 and tot["steps_per_second"] == tot["steps"] / 2.0
+    return results[0][3]
 
 
 def test_shard_bounds():
@@ -54,33 +92,13 @@ def test_shard_bounds():
         shard_bounds(4, 2, 2)
 
 
-def test_two_rank_counters_match_single_process():
-    world, B, iters = 2, 6, 400
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, B, iters, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = sorted(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert [(r[1], r[2]) for r in results] == [(0, 3), (3, 6)]
-    # both ranks hold the same whole-job totals, and the wall time is the MAX over ranks
-    assert results[0][3] == results[1][3]
-    tot = results[0][3]
-    assert tot["seconds"] == 2.0
-    # single-process ground truth over the whole batch
-    sys.path.insert(0, ROOT)
-    from jssenv_amd import builtin_instance
-    from oracle import OracleEnv
-    inst = builtin_instance("ta01")
-    steps = episodes = mk = 0
-    for env_id in range(B):
-        o = OracleEnv(inst, strict=True)
-        o.reset()
-        res = o.rollout("random", 7, env_id, iters, episode=1)
-        steps, episodes, mk = steps + res["steps"], episodes + res["episodes"], mk + res["makespan_sum"]
-    assert (tot["steps"], tot["episodes"], tot["makespan_sum"]) == (steps, episodes, mk)
-    assert tot["steps_per_second"] == steps / 2.0
+def test_two_ranks_equal_one_process_cpu_twin():
+    """CPU (this container): the two ranks step their shards with libjss_cpu.so."""
+    assert _two_ranks_equal_one_process("cpu", global_batch=37, iters=400).startswith("cpu")
+
+
+@pytest.mark.gpu
+def test_two_ranks_equal_one_process_hip_engine():
+    """GPU box: both ranks drive the HIP engine on the one GPU (gloo for the counters): the union of the two
+    shards' state tensors and counters is bit-identical to a single-process batch of twice the size."""
+    assert _two_ranks_equal_one_process("cuda:0", global_batch=2 * 4096 + 70, iters=300) == "hip:gfx950"

@@ -121,41 +121,15 @@ def test_config3_ta41_spt_batch16384(hip):
     assert (sol == sol[0]).all()
 
 
-def test_config5_mixed_ta01_ta80_padded(hip):
-    """BASELINE config 5 (reduced batch): env i <- ta(1 + i % 80), padded 100x20, ragged J/M."""
-    from jssenv_amd import BatchedJssEnv, builtin_instance
-    from oracle import OracleEnv
-    insts = [builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
-    B, seed = 1600, 21
-    env = BatchedJssEnv(insts, batch=B, seed=seed, _backend=hip)
-    env.reset()
-    env.rollout("random", n_iter=700, autoreset=True)
-    cnt = env.counters.cpu().numpy()
-    assert int(env.err.max().item()) == 0
-    for i in list(range(0, 80, 9)) + [79, 80 + 70, 1599]:
-        orc = OracleEnv(insts[i % 80], strict=True)
-        orc.reset()
-        r = orc.rollout("random", seed, i, 700, episode=1, step_in_episode=0)
-        P.assert_matches_oracle(env.host_state(i), orc, f"mixed env {i}")
-        assert cnt[i, 0] == r["steps"] and cnt[i, 1] == r["episodes"] and cnt[i, 2] == r["makespan_sum"]
+def test_config5_mixed_ta01_ta80_padded_batch32768(hip):
+    """BASELINE config 5 at full size (32 768 envs): properties on every env, the oracle on one env per instance."""
+    P.case_config5_mixed(hip, batch=32768)
 
 
-def test_config4_synthetic_50x20(hip):
-    """BASELINE config 4 (one GPU's share, reduced): Taillard-LCG 50x20 instances, one table per env."""
-    from jssenv_amd import BatchedJssEnv, synthetic_batch
-    from oracle import OracleEnv
-    insts = synthetic_batch(256, 50, 20)
-    seed = 4
-    env = BatchedJssEnv(insts, seed=seed, _backend=hip)
-    env.reset()
-    env.rollout("random", n_iter=1500, autoreset=True)
-    cnt = env.counters.cpu().numpy()
-    for i in range(0, 256, 4):   # a 64-env sample against the oracle
-        orc = OracleEnv(insts[i], strict=True)
-        orc.reset()
-        r = orc.rollout("random", seed, i, 1500, episode=1, step_in_episode=0)
-        P.assert_matches_oracle(env.host_state(i), orc, f"synthetic env {i}")
-        assert cnt[i, 0] == r["steps"] and cnt[i, 2] == r["makespan_sum"]
+def test_config4_synthetic_50x20_batch8192(hip):
+    """BASELINE config 4, one GPU's share at full size (8 192 envs, one table per env): properties on every env,
+    the oracle on a 64-env sample."""
+    P.case_config4_synthetic(hip, batch=8192)
 
 
 def test_dispatching_module(hip):

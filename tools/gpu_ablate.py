@@ -1,4 +1,8 @@
-"""Profiling aid (GPU box): time the benchmarked kernel with phases switched off (JSS_OPT_ABLATE).
+"""Profiling aid (GPU box): time the benchmarked kernel with phases switched off.  Needs the instrumented build:
+
+    python tools/build_instrumented.py profiling
+    JSSENV_AMD_LIB=$PWD/variants/profiling.so python tools/gpu_ablate.py [batch] [instance|synthetic50x20]
+
 Results of ablated runs are WRONG by construction; only the timing is meaningful."""
 import os
 import sys
@@ -11,9 +15,11 @@ from jssenv_amd import BatchedJssEnv, _abi  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 inst = sys.argv[2] if len(sys.argv) > 2 else "ta01"
+import ctypes  # noqa: E402
+PROF_ABLATE = 1
 if inst == "synthetic50x20":
-    from jssenv_amd import synthetic_batch
-    env = BatchedJssEnv(synthetic_batch(B, 50, 20), device="cuda:0")
+    from jssenv_amd.instances import synthetic_packed
+    env = BatchedJssEnv(synthetic_packed(B, 50, 20), device="cuda:0")
 else:
     env = BatchedJssEnv(inst, batch=B, device="cuda:0")
 env.reset()
@@ -28,7 +34,7 @@ snapshot = [t.clone() for t in (env.env_header, env.job_state, env.machine_state
 def run(mask, n=200):
     for t, s in zip((env.env_header, env.job_state, env.machine_state), snapshot):
         t.copy_(s)
-    env.lib.jss_set_option(_abi.OPT_ABLATE, mask)
+    assert env.lib.jss_profiling_set(PROF_ABLATE, mask) == 0
     for _ in range(10):
         env.rollout("random", n_iter=1)
     torch.cuda.synchronize()
@@ -44,7 +50,7 @@ def run(mask, n=200):
     g.replay()
     e1.record()
     torch.cuda.synchronize()
-    env.lib.jss_set_option(_abi.OPT_ABLATE, 0)
+    env.lib.jss_profiling_set(PROF_ABLATE, 0)
     return e0.elapsed_time(e1) / n * 1e3
 
 
