@@ -135,9 +135,9 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch envs per GPU; strong: --batch envs in total, split by shard_bounds")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager", "sub2", "sub4"],
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager", "sub2", "sub3", "sub4"],
                     help="how a step is issued: eager = one ctypes launch; graph = hipGraph replay of the K launches; "
-                         "sub2 / sub4 = 2 / 4 sub-batches on as many streams (jss_rollout_steps); auto = fastest on a probe")
+                         "subN = N sub-batches on N streams (jss_rollout_steps); auto = fastest on a probe")
     ap.add_argument("--bucketed", action="store_true",
                     help="mixed workload only: one compact sub-batch per shape class (BucketedJssEnv) instead of "
                          "padding every env to 100x20")
@@ -304,6 +304,7 @@ def main():
     def measure(env, policy, steps, mode, n_iter=1, windows=N_WINDOWS):
         """`windows` windows of `steps` steps each.  Returns the per-window lists, already reduced over ranks."""
         graph = capture(env, policy, steps) if mode == "graph" else None
+        window(env, policy, steps, n_iter, mode, graph)     # untimed: side streams / graph exist before the first window
         rows = []
         for _ in range(windows):
             env.zero_counters()
@@ -319,9 +320,10 @@ def main():
         return med, rows
 
     def launch_label(mode):
-        return {"eager": "one launch per step (ctypes, eager)", "graph": "one launch per step, hipGraph replay of the K launches",
-                "sub2": "2 sub-batches on 2 HIP streams per step (jss_rollout_steps)",
-                "sub4": "4 sub-batches on 4 HIP streams per step (jss_rollout_steps)"}.get(mode, mode)
+        if mode.startswith("sub"):
+            return f"{mode[3:]} sub-batches on {mode[3:]} HIP streams per step (jss_rollout_steps)"
+        return {"eager": "one launch per step (ctypes, eager)",
+                "graph": "one launch per step, hipGraph replay of the K launches"}.get(mode, mode)
 
     def kernel_name(env):
         if hasattr(env, "buckets"):
@@ -351,7 +353,7 @@ def main():
                 "kernel": kernel_name(env), "kernel_ms": med["kernel_ms"],
                 "alg_bytes_per_env_step": alg_per_step, "env_steps_per_launch": stepped}
 
-    def side_run(workload, batch, policy, label_extra="", instance="ta01", bucketed=False, modes=("eager", "graph", "sub2")):
+    def side_run(workload, batch, policy, label_extra="", instance="ta01", bucketed=False, modes=("eager", "graph", "sub2", "sub3")):
         """One extra workload on this GPU: median of N_WINDOWS windows, same timing discipline as the headline."""
         alg, label, key = describe(workload, instance)
         env = make_env(workload, batch, rank * batch, policy, instance=instance, bucketed=bucketed)
@@ -381,7 +383,7 @@ def main():
     for _ in range(args.warmup):
         env.rollout(args.policy, n_iter=1, autoreset=True)
     torch.cuda.synchronize()
-    mode = pick_mode(env, args.policy, ["eager", "graph", "sub2", "sub4"])
+    mode = pick_mode(env, args.policy, ["eager", "graph", "sub2", "sub3"])
     med, rows = measure(env, args.policy, args.steps, mode)
     bucket_note = ", shape-bucketed (no padding)" if (args.bucketed and args.workload == "mixed") else \
         (", padded 100x20" if args.workload == "mixed" else "")
@@ -425,8 +427,8 @@ def main():
         del env
         env = None
         out["batch_x4"] = side_run("shared", 4 * B, args.policy, label_extra=" -- 4x the batch: 420 MB working set, beyond the Infinity Cache",
-                                   instance=args.instance, modes=("eager", "sub2", "sub4"))
-        out["synthetic15x15_per_env_tables"] = side_run("synthetic15x15", B, args.policy, modes=("eager", "graph", "sub2", "sub4"))
+                                   instance=args.instance, modes=("eager", "sub2", "sub3"))
+        out["synthetic15x15_per_env_tables"] = side_run("synthetic15x15", B, args.policy)
         out["config2_ta01_batch4096_random"] = side_run("shared", 4096, "random", modes=("eager", "graph"))
         out["config3_ta41_spt_batch16384"] = side_run("shared", 16384, "SPT", instance="ta41")
         out["config4_synthetic50x20_batch8192"] = side_run("synthetic50x20", 8192, "random")

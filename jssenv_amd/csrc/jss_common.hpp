@@ -119,6 +119,14 @@ __device__ __forceinline__ int row_or(int v) {
     return v;
 }
 
+__device__ __forceinline__ int row_sum(int v) {
+    v += JSS_DPP(v, 0xB1);
+    v += JSS_DPP(v, 0x4E);
+    v += JSS_DPP(v, 0x141);
+    v += JSS_DPP(v, 0x140);
+    return v;
+}
+
 // wave-wide: four row results combined on the scalar unit
 __device__ __forceinline__ int wave_min(int v) {
     v = row_min(v);
@@ -131,6 +139,12 @@ __device__ __forceinline__ int wave_max(int v) {
     const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
     const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
     return imax(imax(a, b), imax(c, d));
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+    v = row_sum(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
 }
 
 // the batch's one shared op table -> LDS, whole workgroup (dwordx4 when the table is 16-byte sized)

@@ -81,6 +81,13 @@ __device__ __forceinline__ int grp_max(int v) {
     return v;
 }
 
+template <int G>
+__device__ __forceinline__ int grp_sum(int v) {
+    v = row_sum(v);
+    if (G == 32) v += __builtin_amdgcn_ds_swizzle(v, 0x401F);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------
 // reset(): jss_env.py:145-181 (registers only; `on` = groups being reset)
 // ---------------------------------------------------------------------------------------
@@ -151,6 +158,69 @@ __device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act,
     // re-legalisation :616-634: need[j] free, not legal, not blocked (a finished job has cur = -1)
     if (act && c.jvalid && e.cur >= 0 && tm_need == 0 && !e.blocked) e.legal = true;
     return hole;
+}
+
+// ---------------------------------------------------------------------------------------
+// `while nb_legal_actions == 0 (and a machine is busy): increase_time_step()` (jss_env.py:429-430 / :469-470) in ONE
+// jump for the groups with `want` (no legal job): nothing is allocated inside that loop, so every clock runs down
+// linearly and the first time T at which a job becomes legal is known up front --
+//   a running job with a next op becomes legal at max(its finish time, release time of its next machine),
+//   a waiting, unblocked job when its machine is released,
+// both of which are event times; T is their minimum.  All the events up to T are then applied at once:
+//   job finishing at f = left <= T: perf += f, then waits: idle += T - f, idle_last = T - f (it was reset to 0 at the
+//   finish, :554, where d - left == 0 because a machine and the job on it run down together), feature-4 numerator =
+//   time its next machine still needed at f (:569-578); job still running: perf += T, left -= T; waiting job:
+//   idle / idle_last += T (:596-597); machines: tm = max(0, tm - T), hole_planning = sum of max(0, T - tm) (:606-608).
+// Two rare cases are left to the event-by-event loop (return value: group handled): no job can ever become legal (the
+// tail of an episode), and a waiting job whose machine is already free (suppressed by _prioritization_non_final and
+// then orphaned by a NOPE), which the reference re-legalises at the very next event whatever it is.
+// ---------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ bool p_jump(PEnv<G> &e, const PCtx<G> &c, bool want, int &rn) {
+    const bool running = e.left > 0;
+    const bool waiting = c.jvalid && !running && e.cur >= 0;             // cur >= 0  <=>  todo < M
+    const int tmx = grp_read<G>(e.tm, (running ? e.nxt : e.cur) >> 16, c.gbase);   // release time of the machine I need (next)
+    int cand = kBig;
+    bool orphan = false;
+    if (running) {
+        if (e.nxt >= 0) cand = imax(e.left, tmx);
+    } else if (waiting && !e.blocked) {
+        if (tmx > 0) cand = tmx;
+        else orphan = true;
+    }
+    const int T = grp_min<G>(cand);
+    const bool any_orphan = grp_any<G>(orphan, c.gbase);                 // collective: evaluated on every lane
+    const bool fast = want && T < kBig && !any_orphan;
+    if (__ballot(fast) == 0) return false;
+    const int hole = grp_sum<G>((fast && c.mvalid) ? imax(0, T - e.tm) : 0);      // :606-608 summed over the events
+    if (fast) {
+        rn -= hole;
+        e.t += T;
+        e.tm = imax(0, e.tm - T);                                        // :611
+        if (running) {
+            if (e.left <= T) {                                           // finishes at f = left (:550)
+                const int f = e.left;
+                e.perf += f;                                             // :531, :544
+                e.left = 0;
+                e.todo += 1;                                             // :558
+                e.cur = e.nxt;                                           // :562-566 / :581
+                e.nxt = (e.todo + 1 < c.M) ? c.row[e.todo + 1] : -1;
+                const bool more = e.cur >= 0;
+                e.idle += more ? T - f : 0;                              // :552 (+0 at the finish), then :596 per later event
+                e.idle_last = more ? T - f : 0;                          // :554, then :597
+                e.f4 = more ? imax(0, tmx - f) : JSS_F4_ONE;             // :569-586
+                if (more && tmx <= T && !e.blocked) e.legal = true;      // :616-634 at T
+            } else {
+                e.perf += T;
+                e.left -= T;
+            }
+        } else if (waiting) {
+            e.idle += T;                                                 // :596
+            e.idle_last += T;                                            // :597
+            if (!e.blocked && tmx <= T) e.legal = true;                  // :616-634 at T
+        }
+    }
+    return fast;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -326,6 +396,10 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params
         e.legal = false;
     }
     const bool stepping = alloc || is_nope;
+    {   // :429-430 / :469-470 as one jump where possible; the loop below takes what is left (rare)
+        const bool none_legal = !grp_any<G>(e.legal, c.gbase);
+        if (__ballot(stepping && none_legal) != 0 && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) p_jump(e, c, stepping && none_legal, rn);
+    }
     for (;;) {                                                           // :429-430 / :469-470
         const bool none_legal = !grp_any<G>(e.legal, c.gbase);
         if (__ballot(stepping && none_legal) == 0) break;                // nobody waits for an event: skip the min

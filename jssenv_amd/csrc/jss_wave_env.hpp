@@ -136,6 +136,69 @@ __device__ __forceinline__ int advance(Env<JPL> &e, const Ctx &c) {
 }
 
 // ---------------------------------------------------------------------------------------
+// `while nb_legal_actions == 0 (and a machine is busy): increase_time_step()` in one jump to the first time T at which
+// a job becomes legal (derivation: p_jump in jss_packed_env.hpp).  Caller guarantees no legal job.  Returns false --
+// nothing changed -- in the two rare cases left to the event-by-event loop.
+// ---------------------------------------------------------------------------------------
+template <int JPL>
+__device__ __forceinline__ bool jump(Env<JPL> &e, const Ctx &c, int &rn) {
+    int tmx[JPL];
+    int cand = kBig;
+    bool orphan = false;
+#pragma unroll
+    for (int s = 0; s < JPL; ++s) {
+        const bool v = s * kWave + c.lane < c.J;
+        const bool running = e.left[s] > 0;
+        const bool waiting = v && !running && e.cur[s] >= 0;
+        const bool bl = (e.blocked[s] >> c.lane) & 1;
+        tmx[s] = __shfl(e.tm, ((running ? e.nxt[s] : e.cur[s]) >> 16) & 63);
+        if (running) {
+            if (e.nxt[s] >= 0) cand = imin(cand, imax(e.left[s], tmx[s]));
+        } else if (waiting && !bl) {
+            if (tmx[s] > 0) cand = imin(cand, tmx[s]);
+            else orphan = true;
+        }
+    }
+    const int T = wave_min(cand);
+    if (T >= kBig || __ballot(orphan) != 0) return false;
+    rn -= wave_sum(c.lane < c.M ? imax(0, T - e.tm) : 0);                // :606-608 summed over the events
+    e.t += T;
+    e.tm = imax(0, e.tm - T);                                            // :611
+#pragma unroll
+    for (int s = 0; s < JPL; ++s) {
+        const int j = s * kWave + c.lane;
+        const bool v = j < c.J;
+        const bool running = e.left[s] > 0;
+        const bool waiting = v && !running && e.cur[s] >= 0;
+        bool can = false;
+        if (running) {
+            if (e.left[s] <= T) {                                        // finishes at f = left (:550)
+                const int f = e.left[s];
+                e.perf[s] += f;
+                e.left[s] = 0;
+                e.todo[s] += 1;
+                e.cur[s] = e.nxt[s];
+                e.nxt[s] = (e.todo[s] + 1 < c.M) ? c.tab[j * c.stride + e.todo[s] + 1] : -1;
+                const bool more = e.cur[s] >= 0;
+                e.idle[s] += more ? T - f : 0;
+                e.idle_last[s] = more ? T - f : 0;
+                e.f4[s] = more ? imax(0, tmx[s] - f) : JSS_F4_ONE;
+                can = more && tmx[s] <= T;
+            } else {
+                e.perf[s] += T;
+                e.left[s] -= T;
+            }
+        } else if (waiting) {
+            e.idle[s] += T;
+            e.idle_last[s] += T;
+            can = tmx[s] <= T;
+        }
+        e.legal[s] |= __ballot(can) & ~e.blocked[s];                     // :616-634 at T
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
 // _prioritization_non_final(): jss_env.py:183-254
 // ---------------------------------------------------------------------------------------
 template <int JPL>
@@ -311,7 +374,8 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
             e.blocked[s] |= e.legal[s];
             e.legal[s] = 0;
         }
-        for (;;) {                                                       // :429-430
+        const bool jumped = __ballot(e.tm > 0) != 0 && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE) && jump(e, c, rn);
+        while (!jumped) {                                                // :429-430, event by event (rare)
             if (__ballot(e.tm > 0) == 0) {  // reference: IndexError (pop from empty list, :517)
                 e.err |= JSS_ERR_NOPE_IDLE;
                 break;
@@ -343,7 +407,10 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
             e.legal[s] &= ~same;                                         // :455-463
             e.blocked[s] &= ~same;                                       // :464-467
         }
-        while (!any_legal(e) && __ballot(e.tm > 0) != 0 && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) rn -= advance(e, c);  // :469-470
+        if (!JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) {                       // :469-470: one jump, else event by event (rare)
+            if (!any_legal(e) && __ballot(e.tm > 0) != 0) jump(e, c, rn);
+            while (!any_legal(e) && __ballot(e.tm > 0) != 0) rn -= advance(e, c);
+        }
     }
     if (!JSS_ABLATED(p, JSS_ABLATE_PRIORITIZE)) prioritize(e, c);        // :432 / :471
     if (!JSS_ABLATED(p, JSS_ABLATE_CHECK_NO_OP)) check_no_op(e, c);      // :433 / :472
