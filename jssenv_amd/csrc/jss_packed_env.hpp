@@ -27,6 +27,34 @@ template <class T>
 __device__ __forceinline__ void st_off(void *base, unsigned byte_off, T v) {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
+// Streaming ("nt") store for the observation, the one large output stream that is written once per step in whole
+// cache lines and never read back by a kernel: it should not displace state lines in L2.  Measured on the headline
+// (profiles/README.md): 20.2 -> 17.7 us per step.  The same hint on the small outputs (1- and 4-byte stores of mask,
+// reward, done) or on the state records makes things WORSE (partial lines go out uncombined; 17.7 -> 18.8 / 19.5 us),
+// and nt state loads cost 25 %: those stay ordinary accesses (A/B builds: tools/build_instrumented.py).
+typedef int jss_v4i __attribute__((vector_size(16)));
+typedef float jss_v4f __attribute__((vector_size(16)));
+template <class T>
+__device__ __forceinline__ void st_nt(void *base, unsigned byte_off, T v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off));
+}
+__device__ __forceinline__ void st_nt(void *base, unsigned byte_off, int4 v) {
+    const jss_v4i x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<jss_v4i *>(reinterpret_cast<char *>(base) + byte_off));
+}
+__device__ __forceinline__ void st_nt(void *base, unsigned byte_off, float4 v) {
+    const jss_v4f x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<jss_v4f *>(reinterpret_cast<char *>(base) + byte_off));
+}
+__device__ __forceinline__ int4 ld_nt_int4(const void *base, unsigned byte_off) {
+    const jss_v4i x = __builtin_nontemporal_load(reinterpret_cast<const jss_v4i *>(reinterpret_cast<const char *>(base) + byte_off));
+    return make_int4(x[0], x[1], x[2], x[3]);
+}
+#ifdef JSS_VAR_NT_STATE_ST
+#define JSS_ST_STATE st_nt
+#else
+#define JSS_ST_STATE st_off
+#endif
 
 template <int G>
 struct PCtx {                 // per-lane view of "my env"
@@ -171,12 +199,14 @@ __device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act,
 //   finish, :554, where d - left == 0 because a machine and the job on it run down together), feature-4 numerator =
 //   time its next machine still needed at f (:569-578); job still running: perf += T, left -= T; waiting job:
 //   idle / idle_last += T (:596-597); machines: tm = max(0, tm - T), hole_planning = sum of max(0, T - tm) (:606-608).
-// Two rare cases are left to the event-by-event loop (return value: group handled): no job can ever become legal (the
-// tail of an episode), and a waiting job whose machine is already free (suppressed by _prioritization_non_final and
-// then orphaned by a NOPE), which the reference re-legalises at the very next event whatever it is.
+// Two rare cases (one wave-uniform branch): a waiting job whose machine is already free ("orphan": suppressed by
+// _prioritization_non_final, then left behind by a NOPE) is re-legalised by the reference at the very next event,
+// so T = min(T, first event); and when no job can ever become legal again (the tail of an episode) the loop runs
+// until every machine is idle, T = last event.  With nothing busy there is no event at all: a NOPE then is the
+// reference's IndexError (:517) and is flagged.
 // ---------------------------------------------------------------------------------------
 template <int G>
-__device__ __forceinline__ bool p_jump(PEnv<G> &e, const PCtx<G> &c, bool want, int &rn) {
+__device__ __forceinline__ void p_jump(PEnv<G> &e, const PCtx<G> &c, bool want, bool is_nope, int &rn) {
     const bool running = e.left > 0;
     const bool waiting = c.jvalid && !running && e.cur >= 0;             // cur >= 0  <=>  todo < M
     const int tmx = grp_read<G>(e.tm, (running ? e.nxt : e.cur) >> 16, c.gbase);   // release time of the machine I need (next)
@@ -188,10 +218,22 @@ __device__ __forceinline__ bool p_jump(PEnv<G> &e, const PCtx<G> &c, bool want, 
         if (tmx > 0) cand = tmx;
         else orphan = true;
     }
-    const int T = grp_min<G>(cand);
-    const bool any_orphan = grp_any<G>(orphan, c.gbase);                 // collective: evaluated on every lane
-    const bool fast = want && T < kBig && !any_orphan;
-    if (__ballot(fast) == 0) return false;
+    int T = grp_min<G>(cand);
+    bool fast = want;
+    if (__ballot(want && (orphan || T >= kBig)) != 0) {                  // rare; collectives below run on every lane
+        const int first = grp_min<G>(e.tm > 0 ? e.tm : kBig);            // first event (kBig: nothing busy)
+        const int last = grp_max<G>(e.tm);                               // last event
+        const bool any_orphan = grp_any<G>(orphan, c.gbase);
+        if (any_orphan) T = imin(T, first);
+        else if (T >= kBig) {                                            // nobody will ever be legal again: run out of
+            T = last > 0 ? last : kBig;                                  // events; a NOPE then pops the reference's empty
+            if (want && is_nope) e.err |= JSS_ERR_NOPE_IDLE;             // event list (:517)
+        }
+        if (T >= kBig) {                                                 // no event to advance to at all
+            if (want && is_nope) e.err |= JSS_ERR_NOPE_IDLE;
+            fast = false;
+        }
+    }
     const int hole = grp_sum<G>((fast && c.mvalid) ? imax(0, T - e.tm) : 0);      // :606-608 summed over the events
     if (fast) {
         rn -= hole;
@@ -220,7 +262,6 @@ __device__ __forceinline__ bool p_jump(PEnv<G> &e, const PCtx<G> &c, bool want, 
             if (!e.blocked && tmx <= T) e.legal = true;                  // :616-634 at T
         }
     }
-    return fast;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -396,21 +437,10 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params
         e.legal = false;
     }
     const bool stepping = alloc || is_nope;
-    {   // :429-430 / :469-470 as one jump where possible; the loop below takes what is left (rare)
+    {   // :429-430 / :469-470: `while nb_legal_actions == 0: increase_time_step()` as one jump
         const bool none_legal = !grp_any<G>(e.legal, c.gbase);
-        if (__ballot(stepping && none_legal) != 0 && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) p_jump(e, c, stepping && none_legal, rn);
-    }
-    for (;;) {                                                           // :429-430 / :469-470
-        const bool none_legal = !grp_any<G>(e.legal, c.gbase);
-        if (__ballot(stepping && none_legal) == 0) break;                // nobody waits for an event: skip the min
-        const int d = p_next_event(e);
-        const bool busy = d < kBig;
-        bool act = stepping && none_legal;
-        if (act && !busy && is_nope) e.err |= JSS_ERR_NOPE_IDLE;         // reference: IndexError (:517)
-        act = act && busy;
-        if (__ballot(act) == 0 || JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) break;
-        const int hole = p_advance(e, c, act, d);
-        if (act) rn -= hole;
+        if (__ballot(stepping && none_legal) != 0 && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE))
+            p_jump(e, c, stepping && none_legal, is_nope, rn);
     }
     if (!JSS_ABLATED(p, JSS_ABLATE_PRIORITIZE)) p_prioritize(e, c, stepping);        // :432 / :471
     if (!JSS_ABLATED(p, JSS_ABLATE_CHECK_NO_OP)) p_check_no_op(e, c, stepping, mvtab);  // :433 / :472
@@ -491,8 +521,13 @@ __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G> &c, const Params 
     r.h = ld_off<int4>(p.s.env + fe * 4, c.rel * 16u);
     const int32_t *jb = p.s.job + fe * jm * JSS_NF;
     const unsigned jo = (c.rel * jm + jc) * 32u;
+#ifdef JSS_VAR_NT_STATE_LD
+    r.lo = ld_nt_int4(jb, jo);
+    r.hi = ld_nt_int4(jb, jo + 16u);
+#else
     r.lo = ld_off<int4>(jb, jo);
     r.hi = ld_off<int4>(jb, jo + 16u);
+#endif
     r.tm = ld_off<int>(p.s.machine + fe * mm, (c.rel * mm + mc) * 4u);
     return r;
 }
@@ -521,20 +556,27 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G> &c, const 
 }
 
 template <int G>
-__device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G> &c, const Params &p, const PHeader &hd) {
+__device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G> &c, const Params &p, const PHeader &hd,
+                                        const PRaw<G> &raw) {
     if (!c.alive) return;
     const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
     const size_t fe = (size_t)c.first_env;
     if (c.gl == 0)
-        st_off<int4>(p.s.env + fe * 4, c.rel * 16u,
+        JSS_ST_STATE(p.s.env + fe * 4, c.rel * 16u,
                      make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0)));
-    if (c.mvalid) st_off<int>(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
+    if (c.mvalid) JSS_ST_STATE(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
     if (c.jvalid) {
         int32_t *jb = p.s.job + fe * jm * JSS_NF;
         const unsigned jo = (c.rel * jm + c.gl) * 32u;
-        st_off<int4>(jb, jo, make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0), e.cur,
-                                       e.left, e.perf));
-        st_off<int4>(jb, jo + 16u, make_int4(e.idle, e.idle_last, e.f4, e.nxt));
+        const int4 lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0), e.cur, e.left, e.perf);
+        const int4 hi = make_int4(e.idle, e.idle_last, e.f4, e.nxt);
+#ifndef JSS_VAR_NO_DIRTY   // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
+        if (lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) JSS_ST_STATE(jb, jo, lo);
+        if (hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) JSS_ST_STATE(jb, jo + 16u, hi);
+#else
+        JSS_ST_STATE(jb, jo, lo);
+        JSS_ST_STATE(jb, jo + 16u, hi);
+#endif
     }
     // action mask row of jmax + 1 bytes: legal jobs, the NOPE flag at index J, zeros behind it
     uint8_t *mk = p.o.action_mask + fe * (jm + 1);
@@ -574,7 +616,7 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, 
     float *dst = p.o.real_obs + (size_t)c.first_env * row_floats;
     if (wave_whole && (n & 3) == 0) {
         for (int i = c.lane; i < (n >> 2); i += kWave)
-            st_off<float4>(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+            st_nt(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
     } else if (c.alive) {
         for (int i = c.gl; i < row_floats; i += G) st_off<float>(dst, (c.rel * row_floats + i) * 4u, mine[i]);
     }
@@ -721,7 +763,7 @@ __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : (MODE == kStep ? 7 :
     PHeader hd = p_unpack(e, c, raw);
     p_body<G, MODE>(e, hd, c, p, a_in, selected, mvtab);
     if (MODE == kPolicy) return;
-    p_store(e, c, p, hd);
+    p_store(e, c, p, hd, raw);
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS)) p_store_obs<G, TAB>(e, c, p, scratch, wave_whole);
 }
 

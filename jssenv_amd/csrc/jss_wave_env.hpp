@@ -137,11 +137,10 @@ __device__ __forceinline__ int advance(Env<JPL> &e, const Ctx &c) {
 
 // ---------------------------------------------------------------------------------------
 // `while nb_legal_actions == 0 (and a machine is busy): increase_time_step()` in one jump to the first time T at which
-// a job becomes legal (derivation: p_jump in jss_packed_env.hpp).  Caller guarantees no legal job.  Returns false --
-// nothing changed -- in the two rare cases left to the event-by-event loop.
+// a job becomes legal (derivation and the two rare cases: p_jump in jss_packed_env.hpp).  Caller guarantees no legal job.
 // ---------------------------------------------------------------------------------------
 template <int JPL>
-__device__ __forceinline__ bool jump(Env<JPL> &e, const Ctx &c, int &rn) {
+__device__ __forceinline__ void jump(Env<JPL> &e, const Ctx &c, bool is_nope, int &rn) {
     int tmx[JPL];
     int cand = kBig;
     bool orphan = false;
@@ -159,8 +158,20 @@ __device__ __forceinline__ bool jump(Env<JPL> &e, const Ctx &c, int &rn) {
             else orphan = true;
         }
     }
-    const int T = wave_min(cand);
-    if (T >= kBig || __ballot(orphan) != 0) return false;
+    int T = wave_min(cand);
+    const bool any_orphan = __ballot(orphan) != 0;
+    if (any_orphan || T >= kBig) {                                       // rare (wave-uniform)
+        if (any_orphan) T = imin(T, wave_min(e.tm > 0 ? e.tm : kBig));   // re-legalised at the very next event
+        else {
+            const int last = wave_max(e.tm);                             // nobody will ever be legal again: run out of events
+            T = last > 0 ? last : kBig;
+            if (is_nope) e.err |= JSS_ERR_NOPE_IDLE;                     // the reference pops its empty event list (:517)
+        }
+        if (T >= kBig) {                                                 // nothing busy: no event to advance to
+            if (is_nope) e.err |= JSS_ERR_NOPE_IDLE;
+            return;
+        }
+    }
     rn -= wave_sum(c.lane < c.M ? imax(0, T - e.tm) : 0);                // :606-608 summed over the events
     e.t += T;
     e.tm = imax(0, e.tm - T);                                            // :611
@@ -195,7 +206,6 @@ __device__ __forceinline__ bool jump(Env<JPL> &e, const Ctx &c, int &rn) {
         }
         e.legal[s] |= __ballot(can) & ~e.blocked[s];                     // :616-634 at T
     }
-    return true;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -374,15 +384,7 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
             e.blocked[s] |= e.legal[s];
             e.legal[s] = 0;
         }
-        const bool jumped = __ballot(e.tm > 0) != 0 && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE) && jump(e, c, rn);
-        while (!jumped) {                                                // :429-430, event by event (rare)
-            if (__ballot(e.tm > 0) == 0) {  // reference: IndexError (pop from empty list, :517)
-                e.err |= JSS_ERR_NOPE_IDLE;
-                break;
-            }
-            rn -= advance(e, c);
-            if (any_legal(e)) break;
-        }
+        if (!JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) jump(e, c, true, rn);   // :429-430 in one jump
     } else {                                                             // :441 allocate job a
         const int sa = a >> 6, la = a & 63;
         uint64_t lg = e.legal[0];
@@ -407,10 +409,7 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
             e.legal[s] &= ~same;                                         // :455-463
             e.blocked[s] &= ~same;                                       // :464-467
         }
-        if (!JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) {                       // :469-470: one jump, else event by event (rare)
-            if (!any_legal(e) && __ballot(e.tm > 0) != 0) jump(e, c, rn);
-            while (!any_legal(e) && __ballot(e.tm > 0) != 0) rn -= advance(e, c);
-        }
+        if (!any_legal(e) && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) jump(e, c, false, rn);   // :469-470 in one jump
     }
     if (!JSS_ABLATED(p, JSS_ABLATE_PRIORITIZE)) prioritize(e, c);        // :432 / :471
     if (!JSS_ABLATED(p, JSS_ABLATE_CHECK_NO_OP)) check_no_op(e, c);      // :433 / :472
@@ -565,7 +564,8 @@ __device__ __forceinline__ Header unpack_env(Env<JPL> &e, const Ctx &c, const Ra
 }
 
 template <int JPL>
-__device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p, const Header &hd) {
+__device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p, const Header &hd,
+                                          const RawEnv<JPL> &raw) {
     const int jm = p.d.jmax;
     int32_t *jb = p.s.job + (size_t)c.b * jm * JSS_NF;
     uint8_t *mk = p.o.action_mask + (size_t)c.b * (jm + 1);
@@ -579,10 +579,17 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = (int)((e.blocked[s] >> c.lane) & 1);
-        if (j < c.J) {
-            st_off<int4>(jb, (unsigned)j * 32u, make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0),
-                                                          e.cur[s], e.left[s], e.perf[s]));
-            st_off<int4>(jb, (unsigned)j * 32u + 16u, make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]));
+        if (j < c.J) {   // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
+            const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0), e.cur[s], e.left[s], e.perf[s]);
+            const int4 hi = make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]);
+            const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
+#ifndef JSS_VAR_NO_DIRTY
+            if (lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w) st_off<int4>(jb, (unsigned)j * 32u, lo);
+            if (hi.x != hi0.x || hi.y != hi0.y || hi.z != hi0.z || hi.w != hi0.w) st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
+#else
+            st_off<int4>(jb, (unsigned)j * 32u, lo);
+            st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
+#endif
         }
         // action mask: legal jobs, the NOPE flag at index J, zeros behind it
         if (j < jm) st_off<uint8_t>(mk, (unsigned)j, (uint8_t)(j < c.J ? lg : (j == c.J ? e.noop : 0)));
@@ -618,8 +625,8 @@ __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const
     float *dst = p.o.real_obs + (size_t)c.b * p.d.jmax * 7;
     const int n = p.d.jmax * 7;
     if ((n & 3) == 0 && (((size_t)c.b * n) & 3) == 0) {
-        for (int i = c.lane; i < (n >> 2); i += kWave)
-            st_off<float4>(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+        for (int i = c.lane; i < (n >> 2); i += kWave)     // streaming store: whole lines, never read back (see st_nt)
+            st_nt(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
     } else {
         for (int i = c.lane; i < n; i += kWave) st_off<float>(dst, (unsigned)i * 4u, scratch[i]);
     }
@@ -738,7 +745,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE 
             if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, n_steps, n_done, sum_makespan, sum_rn);
         }
     }
-    store_env(e, c, p, hd);
+    store_env(e, c, p, hd, raw);
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS)) store_obs(e, c, p, scratch);
 }
 

@@ -60,6 +60,9 @@ struct float4 {
 };
 inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+// cache-policy hints have no meaning on the CPU
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+#define __builtin_nontemporal_load(p) (*(p))
 
 namespace emu {
 

@@ -669,3 +669,49 @@ def case_config4_synthetic(backend, batch=8192, seed=4, sample=64):
         orc, st = oracle_episode(inst, seed, i)
         assert orc.current_time_step == mk[i] and (orc.solution == sol[i]).all() and st == cnt[i, 0], f"synthetic env {i}"
         assert_matches_oracle(env.host_state(i), orc, f"synthetic env {i}")
+
+
+def case_nope_fuzz(backend, shapes=((2, 2), (3, 3), (4, 2), (5, 4)), batch=12, steps=50, seed=99):
+    """Tiny instances with a NOPE forced on half of the envs every other step: drives the rare branches of the
+    event jump (a suppressed job left behind by a NOPE; no job that can ever become legal again, with and without
+    the reference's IndexError) far more often than the real instances do.  Error flags included."""
+    rng = np.random.default_rng(seed)
+    for (J, M) in shapes:
+        insts = [random_instance(rng, J, M, max_dur=7, permutation=(i % 2 == 0)) for i in range(batch)]
+        case_batch_lockstep(backend, insts, batch=batch, n_steps=steps, kind="random", seed=seed + J, nope_every=2, check_every=1)
+
+
+def case_file_round_trips(backend, tmpdir, seed=12):
+    """a packed batch written to disk and read back builds the same env; a checkpoint FILE
+    resumes bit-exactly (same state now, same future)."""
+    import os
+    insts = [I.builtin_instance(n) for n in ("ta01", "ta21", "ta02")]
+    pk = I.pack_batch(insts)
+    path = os.path.join(str(tmpdir), "batch.npz")
+    I.save_batch(path, pk)
+    back = I.load_batch(path)
+    for f in ("ops", "rem", "inst", "jobs", "machines", "max_time_op", "max_time_jobs", "sum_op"):
+        assert np.array_equal(getattr(pk, f), getattr(back, f)), f
+    a = BatchedJssEnv(insts, batch=9, seed=seed, env_id_base=3, _backend=backend)
+    b = BatchedJssEnv(back, batch=9, seed=seed, env_id_base=3, _backend=backend)       # from the file
+    a.reset()
+    b.reset()
+    a.rollout("random", n_iter=150)
+    b.rollout("random", n_iter=150)
+    for name in BatchedJssEnv._STATE_TENSORS:
+        assert np.array_equal(a.backend.numpy(getattr(a, name)), b.backend.numpy(getattr(b, name))), name
+    ck = os.path.join(str(tmpdir), "state.npz")
+    a.save_checkpoint(ck)
+    a.rollout("random", n_iter=77)                                                      # the future to reproduce
+    want = {name: a.backend.numpy(getattr(a, name)) for name in BatchedJssEnv._STATE_TENSORS}
+    c = BatchedJssEnv(back, batch=9, seed=seed, env_id_base=3, _backend=backend)       # a fresh object: no reset()
+    c.load_checkpoint(ck)
+    c.rollout("random", n_iter=77)
+    for name, w in want.items():
+        assert np.array_equal(c.backend.numpy(getattr(c, name)), w), f"resumed run differs in {name}"
+    other = BatchedJssEnv(insts[:2], batch=9, _backend=backend)
+    try:
+        other.load_checkpoint(ck)
+        raise AssertionError("a checkpoint of another batch must be rejected")
+    except ValueError:
+        pass

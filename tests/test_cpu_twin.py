@@ -121,3 +121,7 @@ def test_configs_4_and_5_reduced(cpu):
     """The GPU suite's full-size config 4 / 5 cases at a size the host cores finish in seconds."""
     P.case_config4_synthetic(cpu, batch=192, sample=16)
     P.case_config5_mixed(cpu, batch=640)
+
+
+def test_nope_fuzz_tiny_instances(cpu):
+    P.case_nope_fuzz(cpu, batch=64, steps=200)

@@ -1,0 +1,98 @@
+"""CPU-only: the gymnasium registration / spaces path (JSSEnv/__init__.py:6-9, jss_env.py:97,112-119) executed
+against a stand-in gymnasium (the package is absent from this image), and the on-disk formats of SURVEY row N3."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import parity_cases as P
+from jssenv_amd import instances as I
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_GYM_SCRIPT = textwrap.dedent('''
+    import importlib, sys, types
+    # a stand-in for the handful of gymnasium names the registration path touches
+    gym = types.ModuleType("gymnasium"); spaces = types.ModuleType("gymnasium.spaces")
+    envs = types.ModuleType("gymnasium.envs"); registration = types.ModuleType("gymnasium.envs.registration")
+    table = {}
+    class Discrete:
+        def __init__(self, n): self.n = n
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=None): self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+    class Dict:
+        def __init__(self, d): self.spaces = dict(d)
+    def register(id, entry_point=None, **kw): table[id] = entry_point
+    def make(id, **kw):
+        mod, cls = table[id].split(":")
+        return getattr(importlib.import_module(mod), cls)(**kw)
+    gym.spaces, gym.envs, gym.make = spaces, envs, make
+    spaces.Discrete, spaces.Box, spaces.Dict = Discrete, Box, Dict
+    registration.register = register; envs.registration = registration
+    sys.modules.update({"gymnasium": gym, "gymnasium.spaces": spaces, "gymnasium.envs": envs,
+                        "gymnasium.envs.registration": registration})
+    sys.path.insert(0, %r)
+    import gymnasium
+    import jssenv_amd
+    assert table == {"jss-v1": "jssenv_amd.env:JssEnv"}, table
+    env = gymnasium.make("jss-v1", env_config={"instance_path": "ta01"}, device="cpu")
+    assert type(env) is jssenv_amd.JssEnv
+    assert isinstance(env.action_space, Discrete) and env.action_space.n == 16
+    d = env.observation_space.spaces
+    assert set(d) == {"action_mask", "real_obs"}
+    assert d["action_mask"].shape == (16,) and (d["action_mask"].low, d["action_mask"].high) == (0, 1)
+    assert d["real_obs"].shape == (15, 7) and (d["real_obs"].low, d["real_obs"].high) == (0.0, 1.0)
+    obs = env.reset()
+    assert obs["real_obs"].shape == (15, 7) and obs["action_mask"].shape == (16,)
+    obs, reward, done, truncated, info = env.step(3)
+    assert truncated is False and info == {} and not done and obs["action_mask"][3] == False
+    # default instance (env_config=None) is ta80, as at jss_env.py:35-38
+    assert gymnasium.make("jss-v1", device="cpu").jobs == 100
+    # the vector facade gets its spaces from the same package
+    from jssenv_amd.vector import JssVectorEnv
+    v = JssVectorEnv("ta01", num_envs=3, device="cpu")
+    assert v.single_action_space.n == 16 and v.single_observation_space.spaces["real_obs"].shape == (15, 7)
+    print("GYM-PATH-OK")
+''')
+
+
+def test_gymnasium_registration_and_spaces():
+    out = subprocess.run([sys.executable, "-c", _GYM_SCRIPT % ROOT], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "GYM-PATH-OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_packed_batch_and_checkpoint_files(tmp_path):
+    from jssenv_amd.env import CpuBackend
+    P.case_file_round_trips(CpuBackend(), tmp_path)
+
+
+def test_load_batch_rejects_garbage(tmp_path):
+    pk = I.pack_batch([I.builtin_instance("ta01")])
+    p = tmp_path / "b.npz"
+    I.save_batch(p, pk)
+    bad = pk.inst.copy()
+    bad[0, 4] += 1                                # sum_op no longer matches the op table
+    with open(tmp_path / "bad.npz", "wb") as fh:
+        np.savez(fh, format=np.int32(1), ops=pk.ops, inst=bad)
+    with pytest.raises(ValueError):
+        I.load_batch(tmp_path / "bad.npz")
+    with open(tmp_path / "v2.npz", "wb") as fh:
+        np.savez(fh, format=np.int32(2), ops=pk.ops, inst=pk.inst)
+    with pytest.raises(ValueError):
+        I.load_batch(tmp_path / "v2.npz")
+    assert np.array_equal(I.load_batch(p).ops, pk.ops)
+
+
+def test_instance_text_file_round_trip(tmp_path):
+    """The reference's only on-disk format (jss_env.py:72-88): write, re-read, and run from a path."""
+    from jssenv_amd import make
+    ta = I.builtin_instance("ta03")
+    p = tmp_path / "my_instance"
+    p.write_text(ta.to_text())
+    again = I.load_instance_file(p)
+    assert (again.packed() == ta.packed()).all()
+    env = make("jss-v1", env_config={"instance_path": str(p)}, device="cpu")
+    assert (env.jobs, env.machines, env.max_time_op) == (15, 15, ta.max_time_op)

@@ -209,3 +209,12 @@ def test_instance_resampling(hip):
 
 def test_rollout_steps_equals_rollout(hip):
     P.case_rollout_steps(hip, batch=5000, steps=40, n_sub=4)
+
+
+def test_nope_fuzz_tiny_instances(hip):
+    P.case_nope_fuzz(hip, batch=64, steps=200)
+
+
+def test_checkpoint_file_resume(hip, tmp_path):
+    """N3 on the GPU: packed batch file -> env, checkpoint FILE -> bit-exact resume."""
+    P.case_file_round_trips(hip, tmp_path)

@@ -104,3 +104,7 @@ def test_instance_resampling(emu):
 
 def test_rollout_steps_equals_rollout(emu):
     P.case_rollout_steps(emu, batch=150, steps=4, n_sub=3)
+
+
+def test_nope_fuzz_tiny_instances(emu):
+    P.case_nope_fuzz(emu, batch=8, steps=30)

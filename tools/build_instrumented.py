@@ -4,6 +4,8 @@ JSSENV_AMD_LIB points somewhere else.
 
     variants/profiling.so   -DJSS_PROFILING: exports jss_profiling_set (phase ablation, LDS padding)
     variants/occ7.so        -DJSS_WAVE_MIN_BLOCKS=7: wave-per-env step kernels at 7 waves/SIMD (SGPR budget 102)
+    variants/nodirty.so     -DJSS_VAR_NO_DIRTY: rewrite every job record every step (packed kernel)
+    variants/ntst.so, ntstld.so   streaming hints on the state stores / loads too (measured slower)
 """
 import os
 import sys
@@ -12,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from jssenv_amd.build import build_extension  # noqa: E402
 
-VARIANTS = {"profiling": ["-DJSS_PROFILING"], "occ7": ["-DJSS_WAVE_MIN_BLOCKS=7"]}
+VARIANTS = {"profiling": ["-DJSS_PROFILING"], "occ7": ["-DJSS_WAVE_MIN_BLOCKS=7"], "nodirty": ["-DJSS_VAR_NO_DIRTY"],
+            "ntst": ["-DJSS_VAR_NT_STATE_ST"], "ntstld": ["-DJSS_VAR_NT_STATE_ST", "-DJSS_VAR_NT_STATE_LD"]}
 
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)

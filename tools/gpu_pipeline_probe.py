@@ -30,8 +30,11 @@ for r in range(15):
     for _ in range(16):
         env.step(torch.where(ids > r, env.policy("random"), skip))
 env.rollout("random", n_iter=64)
+if os.environ.get("JSS_ABLATE"):      # instrumented build only (JSSENV_AMD_LIB=variants/profiling.so): phase ablation mask
+    assert env.lib.jss_profiling_set(1, int(os.environ["JSS_ABLATE"])) == 0
+    print("ablation mask", os.environ["JSS_ABLATE"], "(results are wrong by construction; timing only)")
 K = 200
-for n_sub in (1, 2, 3, 4, 6, 8):
+for n_sub in [int(x) for x in os.environ.get("JSS_NSUB", "1,2,3,4,6,8").split(",")]:
     env.rollout_steps("random", steps=K, n_sub=n_sub)          # warm (stream creation)
     torch.cuda.synchronize()
     best = None
