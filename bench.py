@@ -53,6 +53,22 @@ def b_alg(J, M):
 # ------------------------------------------------------------------------------------------------------------
 # CPU baselines (rank 0, N = 1, after the GPU measurement)
 # ------------------------------------------------------------------------------------------------------------
+def host_cores():
+    """What this box gives us: logical CPUs, the affinity mask, and the cgroup CPU quota (a container may see 256
+    logical CPUs and be allowed 8 cores' worth of time -- the thread counts below are what was USED, this is what
+    was AVAILABLE)."""
+    info = {"logical": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cgroup_quota_cores": None}
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            info["cgroup_quota_cores"] = float(quota) / float(period)
+    except Exception:
+        pass
+    return info
+
+
+
 def cpu_baseline_port(inst_name, seed, target_seconds=8.0):
     """The C oracle (a scalar restatement of the reference's step(), oracle/jss_oracle.c) running
     the same policy+step loop on this box's host cores, one env per thread."""
@@ -439,6 +455,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "shared":
         out["cpu_baseline"] = cpu_baseline_port(args.instance, args.seed)
         out["cpu_baseline_twin"] = cpu_baseline_twin(args.instance, args.seed)
+        out["cpu_baseline"]["host"] = out["cpu_baseline_twin"]["host"] = host_cores()
     elif rank == 0:
         out["cpu_baseline"] = None
 
