@@ -151,6 +151,10 @@ typedef struct JssDesc {
     int32_t kernel;              /* JSS_KERNEL_*                                            */
     int32_t threads;             /* libjss_cpu.so: OpenMP threads for this call (0 = runtime default);
                                     libjss_hip.so ignores it                                */
+    int32_t jmin;                /* hint: smallest J among the batch's instances (0 = unknown, read as jmax).  When
+                                    jmin < jmax (a ragged, padded batch) the one-wavefront-per-env kernels read the
+                                    instance record BEFORE the job records and never load the rows behind J(env)  */
+    int32_t reserved;            /* 0                                                       */
 } JssDesc;
 
 typedef struct JssState {

@@ -518,18 +518,20 @@ struct RawEnv {  // loads issued first; unpacked once the instance record is kno
 };
 
 template <int JPL>
-__device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params &p) {
+__device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params &p, int jlimit) {   // rows j < jlimit
     RawEnv<JPL> r;
-    const int jm = p.d.jmax;
+    const int jm = jlimit;
     r.h = *reinterpret_cast<const int4 *>(p.s.env + (size_t)b * 4);
-    const int32_t *jb = p.s.job + (size_t)b * jm * JSS_NF;
+    const int32_t *jb = p.s.job + (size_t)b * p.d.jmax * JSS_NF;
     r.tm = ld_off<int>(p.s.machine + (size_t)b * p.d.mmax, (unsigned)(lane < p.d.mmax ? lane : 0) * 4u);
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + lane;
-        const unsigned jo = (unsigned)(j < jm ? j : 0) * 32u;
-        r.lo[s] = ld_off<int4>(jb, jo);
-        r.hi[s] = ld_off<int4>(jb, jo + 16u);
+        r.lo[s] = r.hi[s] = make_int4(0, -1, 0, 0);
+        if (j < jm) {                                                    // lanes behind the limit issue no request
+            r.lo[s] = ld_off<int4>(jb, (unsigned)j * 32u);
+            r.hi[s] = ld_off<int4>(jb, (unsigned)j * 32u + 16u);
+        }
     }
     return r;
 }
@@ -600,7 +602,9 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
 // integer state (column 4 of its own stored numerator: the reference writes it only when an
 // op finishes).  Transposed through LDS so the HBM write is jmax*7 contiguous floats.
 template <int JPL>
-__device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const Params &p, float *scratch) {
+__device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const Params &p, float *scratch, int rows) {
+    // rows = jmax when the env is (re)initialised by a reset call, J(env) otherwise: the rows behind J are zeros
+    // from that reset on and nothing ever changes them, so a step does not rewrite them (ragged, padded batches)
     const int32_t *ir = p.d.inst + (size_t)c.tid * JSS_NI;
     const float f_op = (float)c.max_time_op, f_jobs = (float)ir[JSS_I_MAX_TIME_JOBS], f_sum = (float)ir[JSS_I_SUM_OP];
     const float f_m = (float)c.M;
@@ -609,7 +613,7 @@ __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
-        if (j < p.d.jmax) {
+        if (j < rows) {
             const bool v = j < c.J;  // padding rows are written as zeros
             float *row = scratch + j * 7;
             row[0] = v ? (float)((e.legal[s] >> c.lane) & 1) : 0.f;                       // :130
@@ -623,13 +627,14 @@ __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const
     }
     wave_lds_sync();
     float *dst = p.o.real_obs + (size_t)c.b * p.d.jmax * 7;
-    const int n = p.d.jmax * 7;
-    if ((n & 3) == 0 && (((size_t)c.b * n) & 3) == 0) {
+    const int n = rows * 7;
+    int done = 0;
+    if ((((size_t)c.b * p.d.jmax * 7) & 3) == 0) {                       // 16-byte aligned row block: whole float4s first
         for (int i = c.lane; i < (n >> 2); i += kWave)     // streaming store: whole lines, never read back (see st_nt)
             st_nt(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
-    } else {
-        for (int i = c.lane; i < n; i += kWave) st_off<float>(dst, (unsigned)i * 4u, scratch[i]);
+        done = n & ~3;
     }
+    for (int i = done + c.lane; i < n; i += kWave) st_off<float>(dst, (unsigned)i * 4u, scratch[i]);
     wave_lds_sync();
 }
 
@@ -656,8 +661,11 @@ __global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE 
     const int b_raw = blockIdx.x * kWavesPerBlock + wave;                 // one env per wave
     const bool alive = b_raw < p.d.batch;
     const int b = alive ? b_raw : p.d.batch - 1;
-    // 1. state loads first: they depend on nothing but the env index
-    const RawEnv<JPL> raw = issue_loads<JPL>(b, lane, p);
+    // 1. state loads first: they depend on nothing but the env index -- unless the batch is ragged (jmin < jmax):
+    //    then the instance record goes first (two scalar loads) and the rows behind J(env) are never requested
+    const bool ragged = p.d.jmin > 0 && p.d.jmin < p.d.jmax;
+    RawEnv<JPL> raw;
+    if (!ragged) raw = issue_loads<JPL>(b, lane, p, p.d.jmax);
     int a_in = JSS_ACTION_SKIP;
     if (MODE == kStep) a_in = __builtin_amdgcn_readfirstlane(p.actions[b]);
     bool selected = true;
@@ -672,6 +680,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE 
     c.M = __builtin_amdgcn_readfirstlane(ir[JSS_I_MACHINES]);
     c.max_time_op = __builtin_amdgcn_readfirstlane(ir[JSS_I_MAX_TIME_OP]);
     c.stride = p.d.mmax;
+    if (ragged) raw = issue_loads<JPL>(b, lane, p, c.J);
     if (TAB == kTabLds) {
         stage_shared_table(lds, p.d.ops, c.J * p.d.mmax, (int)threadIdx.x);
         __syncthreads();
@@ -746,7 +755,7 @@ __global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE 
         }
     }
     store_env(e, c, p, hd, raw);
-    if (!JSS_ABLATED(p, JSS_ABLATE_OBS)) store_obs(e, c, p, scratch);
+    if (!JSS_ABLATED(p, JSS_ABLATE_OBS)) store_obs(e, c, p, scratch, MODE == kReset ? p.d.jmax : c.J);
 }
 
 }  // namespace jss

@@ -278,7 +278,8 @@ class BatchedJssEnv:
 
         p = be.ptr
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._rem), p(self._inst), p(self._table_of_env), None,
-                                  self.env_id_base, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)))
+                                  self.env_id_base, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)),
+                                  int(pk.jobs.min()), 0)
         self._state = _abi.JssState(p(self.env_header), p(self.job_state), p(self.machine_state), p(self.solution),
                                     p(self.counters))
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))

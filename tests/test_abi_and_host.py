@@ -49,7 +49,7 @@ def test_header_constants_match_python_mirror():
     assert defs["JSS_ERR_NOPE_IDLE"] == _abi.ERR_NOPE_IDLE and defs["JSS_ERR_ILLEGAL_ACTION"] == _abi.ERR_ILLEGAL_ACTION
     for name, kid in _abi.POLICY.items():
         assert defs["JSS_POLICY_" + name.upper()] == kid
-    assert ctypes.sizeof(_abi.JssDesc) == 16 + 5 * 8 + 8 + 8 and ctypes.sizeof(_abi.JssState) == 40 and ctypes.sizeof(_abi.JssOut) == 40
+    assert ctypes.sizeof(_abi.JssDesc) == 16 + 5 * 8 + 8 + 16 and ctypes.sizeof(_abi.JssState) == 40 and ctypes.sizeof(_abi.JssOut) == 40
 
 
 def test_argument_errors_without_gpu(hip_lib):

@@ -125,3 +125,27 @@ def test_configs_4_and_5_reduced(cpu):
 
 def test_nope_fuzz_tiny_instances(cpu):
     P.case_nope_fuzz(cpu, batch=64, steps=200)
+
+
+def test_critical_ratio_custom_due_date_factor(cpu):
+    """The device selector hard-codes the reference's default factor 1.5; any other factor must take the host loop
+    (ADVICE r1): the rule then gives the same episode on the package's env as on the oracle (no device selector)."""
+    from jssenv_amd import dispatching as D
+    from jssenv_amd import instances as I
+    from jssenv_amd.env import JssEnv
+    from oracle import OracleEnv
+    real = np.random.random
+    np.random.random = lambda *a, **k: 1.0
+    try:
+        res = {}
+        for factor in (1.5, 0.5):
+            rule = D.CriticalRatio(due_date_factor=factor)
+            env = JssEnv({"instance_path": "ta01"}, _backend=cpu)
+            _, mk_pkg = rule.run_episode(env)
+            orc = OracleEnv(I.builtin_instance("ta01"))
+            _, mk_orc = D.CriticalRatio(due_date_factor=factor).run_episode(orc)
+            assert mk_pkg == mk_orc, (factor, mk_pkg, mk_orc)
+            res[factor] = mk_pkg
+        assert res[1.5] == 1426 and res[0.5] != 1426      # G3 value for the default; another schedule otherwise
+    finally:
+        np.random.random = real

@@ -14,7 +14,12 @@ from jssenv_amd import BatchedJssEnv  # noqa: E402
 mask = int(sys.argv[1])
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 inst = sys.argv[3] if len(sys.argv) > 3 else "ta01"
-env = BatchedJssEnv(inst, batch=B, device="cuda:0")
+if inst.startswith("synthetic"):
+    from jssenv_amd.instances import synthetic_packed
+    J, M = (int(x) for x in inst[len("synthetic"):].split("x"))
+    env = BatchedJssEnv(synthetic_packed(B, J, M), device="cuda:0")
+else:
+    env = BatchedJssEnv(inst, batch=B, device="cuda:0")
 env.reset()
 ids = torch.arange(B, device="cuda:0") % 16
 skip = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")

@@ -1,3 +1,4 @@
+# Usage: [JSS_KERNEL_REGEX='jss_kernel.*5, 1'] bash tools/gpu_pmc_ablate.sh [batch] [instance|synthetic50x20]
 # Per-phase dynamic instruction counts of the benchmarked kernel (GPU box): SQ_INSTS_VALU / SALU per wave with
 # phases ablated (instrumented build variants/profiling.so; results of ablated runs are wrong by construction).
 cd /tmp && export TMPDIR=/tmp
@@ -5,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_abl
 mkdir -p $OUT
 for mask in 0 1 2 4 8 16 31; do
-  JSSENV_AMD_LIB=$R/variants/profiling.so rocprofv3 -f csv --kernel-include-regex "jss_packed_kernel.*5, 0" --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS -d $OUT/m$mask -o m -- python $R/tools/gpu_pmc_ablate.py $mask "$@" > $OUT/m$mask.log 2>&1
+  JSSENV_AMD_LIB=$R/variants/profiling.so rocprofv3 -f csv --kernel-include-regex "${JSS_KERNEL_REGEX:-jss_packed_kernel.*5, 0}" --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS -d $OUT/m$mask -o m -- python $R/tools/gpu_pmc_ablate.py $mask "$@" > $OUT/m$mask.log 2>&1
   python - <<PY
 import csv, glob, collections, statistics
 acc = collections.defaultdict(list)
