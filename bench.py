@@ -352,6 +352,8 @@ def main():
 
     def static_traffic(key, batch):
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if key is None:
+            return None, None
         try:
             with open(prof) as fh:
                 ent = json.load(fh).get(f"{key}_b{batch}")
@@ -377,10 +379,11 @@ def main():
             env.rollout(policy, n_iter=1, autoreset=True)
         mode = pick_mode(env, policy, list(modes))
         med, rows = measure(env, policy, args.steps, mode)
-        rf = roofline(med, alg, args.steps, env, key, batch)
+        rf = roofline(med, alg, args.steps, env, None if bucketed else key, batch)
         out = {"workload": label + label_extra, "batch": batch, "policy": policy, "value": med["rate"],
                "min": rows[0]["rate"], "max": rows[-1]["rate"], "unit": "env steps/s", "ms_per_step": med["seconds"] / args.steps * 1e3,
-               "launch": launch_label(mode), "kernel": rf["kernel"], "roofline_frac": rf["frac"],
+               "launch": ("one launch per shape bucket per step, every bucket on its own HIP stream" if bucketed else launch_label(mode)),
+               "kernel": rf["kernel"], "roofline_frac": rf["frac"],
                "roofline_frac_of_measured_peak": rf["frac_of_measured_peak"], "alg_bytes_per_env_step": alg,
                "traffic": rf["traffic"], "mean_makespan": med["makespan_sum"] / med["episodes"] if med["episodes"] else None}
         if hasattr(env, "close"):
@@ -412,13 +415,14 @@ def main():
                  else "synthetic" if args.workload.startswith("synthetic") else "reference instances (ta01-ta80)"),
         "windows": {"n": len(rows), "steps_each": args.steps, "statistic": "median", "min": rows[0]["rate"], "max": rows[-1]["rate"],
                     "all": [r["rate"] for r in rows]},
-        "launch": launch_label(mode),
+        "launch": ("one launch per shape bucket per step, every bucket on its own HIP stream (C launch loop per bucket)"
+                   if hasattr(env, "buckets") else launch_label(mode)),
         "config": {"workload": f"{wl_label}{bucket_note}, {args.policy} masked policy fused with step(), "
                                f"{'batch %d envs per GPU' % B if args.scaling == 'weak' else 'batch %d envs in total (%d on this rank)' % (args.batch, B)}, "
                                f"full obs/mask/reward/done written every step, auto-restart",
                    "batch_per_gpu": B, "global_batch": args.batch * world if args.scaling == "weak" else args.batch,
                    "parallelism": f"env-shard x{world}", "policy": args.policy},
-        "roofline": roofline(med, alg_per_step, args.steps, env, key, B),
+        "roofline": roofline(med, alg_per_step, args.steps, env, None if hasattr(env, "buckets") else key, B),
         "episodes_finished": med["episodes"],
         "mean_makespan": med["makespan_sum"] / med["episodes"] if med["episodes"] else None,
         "mean_reward_per_step": (med["reward_num"] / inst0.max_time_op / med["steps"]) if (med["steps"] and args.workload == "shared") else None,

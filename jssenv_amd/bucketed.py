@@ -119,10 +119,15 @@ class BucketedJssEnv:
     def rollout_steps(self, kind="random", steps=1, n_iter=1, seed=None, autoreset=True, explore=0.0):
         """`steps` consecutive rollout(n_iter) launches per bucket with ONE fork/join around the whole
         window: bucket k's launch i+1 depends only on bucket k's launch i, so the buckets run ahead of
-        each other on their own streams (no per-step synchronisation, no graph capture needed)."""
+        each other on their own streams (no per-step synchronisation, no graph capture needed).  With
+        n_iter == 1 each bucket's launches are issued by the C loop of jss_rollout_steps (2.7 us of host time
+        per launch instead of a Python/ctypes call each)."""
         def run(k, b):
-            for _ in range(steps):
-                b.rollout(kind, n_iter=n_iter, seed=seed, autoreset=autoreset, explore=explore)
+            if n_iter == 1:
+                b.rollout_steps(kind, steps=steps, n_sub=1, seed=seed, autoreset=autoreset, explore=explore)
+            else:
+                for _ in range(steps):
+                    b.rollout(kind, n_iter=n_iter, seed=seed, autoreset=autoreset, explore=explore)
         self._fan_out(run)
 
     def policy(self, kind="random", seed=None, explore=0.0):

@@ -467,6 +467,9 @@ def case_bucketed_equals_padded(backend, n_envs=24, n_iter=260, seed=13):
     bucketed.reset()
     padded.rollout("random", n_iter=n_iter)
     bucketed.rollout("random", n_iter=n_iter)
+    padded.rollout_steps("random", steps=7, n_sub=2)        # the step-per-launch forms on top: sub-batches / per-bucket streams
+    bucketed.rollout_steps("random", steps=7)
+    n_iter += 7
     for i in range(n_envs):
         a, b = padded.host_state(i), bucketed.host_state(i)
         assert a["clock"] == b["clock"] and (a["job_state"] == b["job_state"]).all(), f"env {i}"
