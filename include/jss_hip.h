@@ -68,7 +68,9 @@ extern "C" {
 #define JSS_MAX_MACHINES 64
 
 /* words of the per-job record */
-#define JSS_F_TODO 0      /* bits 0-7 todo_time_step_job, bit 8 legal_actions[j], bit 9 action_illegal_no_op[j] */
+#define JSS_F_TODO 0      /* bits 0-7 todo_time_step_job, bit 8 legal_actions[j], bit 9 action_illegal_no_op[j],
+                             bits 10-31 the op after the next one (op table entry [j][todo + 2] as machine << 16 |
+                             duration: 22 bits), 0 = none                                                       */
 #define JSS_F_CUR 1       /* current op, machine << 16 | duration; -1 = job finished.
                              needed_machine_jobs == cur >> 16 (arithmetic shift)   */
 #define JSS_F_LEFT 2      /* time_until_finish_current_op_jobs                    */
@@ -77,13 +79,16 @@ extern "C" {
 #define JSS_F_IDLE_LAST 5 /* idle_time_jobs_last_op                               */
 #define JSS_F_F4 6        /* numerator of observation feature 4 (written only when an
                              op finishes, jss_env.py:569-586); JSS_F4_ONE = "1.0"  */
-#define JSS_F_NEXT 7      /* the op after the current one (op table entry [j][todo + 1]), -1 = none: kept next
-                             to the state so that a step touches the op table only when a job moves on */
+#define JSS_F_NEXT 7      /* the op after the current one (op table entry [j][todo + 1]), -1 = none.  The record
+                             carries the job's next THREE ops (cur, next, bits 10-31 of word 0) so that a step
+                             touches the op table only when a job moves on, or when a look-ahead walk of
+                             _check_no_op goes further than three ops */
 #define JSS_NF 8
 #define JSS_F4_ONE (-1)
 #define JSS_TODO_MASK 255
 #define JSS_FLAG_LEGAL 256
 #define JSS_FLAG_BLOCKED 512
+#define JSS_NEXT2_SHIFT 10
 
 /* words of the per-env header */
 #define JSS_H_CLOCK 0    /* current_time_step                                     */

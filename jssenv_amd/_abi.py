@@ -12,7 +12,7 @@ import os
 ABI_VERSION = 5
 MAX_JOBS, MAX_MACHINES = 128, 64
 F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_NEXT, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
-TODO_MASK, FLAG_LEGAL, FLAG_BLOCKED = 255, 256, 512
+TODO_MASK, FLAG_LEGAL, FLAG_BLOCKED, NEXT2_SHIFT = 255, 256, 512, 10
 H_CLOCK, H_EPISODE, H_STEP, H_STATUS = 0, 1, 2, 3
 STATUS_NOOP = 256
 F4_ONE = -1

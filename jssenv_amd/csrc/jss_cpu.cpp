@@ -54,6 +54,14 @@ struct Env {
     bool blocked(int j) const { return w(j, JSS_F_TODO) & JSS_FLAG_BLOCKED; }
     void set_legal(int j, bool v) const { w(j, JSS_F_TODO) = (w(j, JSS_F_TODO) & ~JSS_FLAG_LEGAL) | (v ? JSS_FLAG_LEGAL : 0); }
     void set_blocked(int j, bool v) const { w(j, JSS_F_TODO) = (w(j, JSS_F_TODO) & ~JSS_FLAG_BLOCKED) | (v ? JSS_FLAG_BLOCKED : 0); }
+    int next2(int j) const {                                             // op table entry [j][todo + 2], -1 = none
+        const unsigned v = (unsigned)w(j, JSS_F_TODO) >> JSS_NEXT2_SHIFT;
+        return v ? (int)v : -1;
+    }
+    void set_next2(int j, int op) const {
+        w(j, JSS_F_TODO) = (int32_t)(((unsigned)w(j, JSS_F_TODO) & ((1u << JSS_NEXT2_SHIFT) - 1u)) |
+                                     (op >= 0 ? (unsigned)op << JSS_NEXT2_SHIFT : 0u));
+    }
     int &t() const { return hdr[JSS_H_CLOCK]; }
     int noop() const { return (hdr[JSS_H_STATUS] & JSS_STATUS_NOOP) ? 1 : 0; }
     void set_noop(int v) const { hdr[JSS_H_STATUS] = (hdr[JSS_H_STATUS] & ~JSS_STATUS_NOOP) | (v ? JSS_STATUS_NOOP : 0); }
@@ -100,6 +108,7 @@ void reset_env(const Env &e) {
         e.w(j, JSS_F_TODO) = JSS_FLAG_LEGAL;                              // todo 0 (:166), legal (:160), not blocked (:171)
         e.w(j, JSS_F_CUR) = e.ops[j * e.stride];                          // :174-176 needed machine = op 0
         e.w(j, JSS_F_NEXT) = 1 < e.M ? e.ops[j * e.stride + 1] : -1;
+        e.set_next2(j, 2 < e.M ? e.ops[j * e.stride + 2] : -1);
         e.w(j, JSS_F_LEFT) = e.w(j, JSS_F_PERF) = e.w(j, JSS_F_IDLE) = e.w(j, JSS_F_IDLE_LAST) = 0;   // :165-170
         e.w(j, JSS_F_F4) = 0;                                             // :180
     }
@@ -129,7 +138,8 @@ int advance(const Env &e) {
                 e.w(j, JSS_F_TODO) = (e.w(j, JSS_F_TODO) & ~JSS_TODO_MASK) | k;
                 const int cur = e.w(j, JSS_F_NEXT);                       // :562-566 the job moves on (-1: complete, :581)
                 e.w(j, JSS_F_CUR) = cur;
-                e.w(j, JSS_F_NEXT) = k + 1 < e.M ? e.ops[j * e.stride + k + 1] : -1;
+                e.w(j, JSS_F_NEXT) = e.next2(j);                          // the record carries the next three ops
+                e.set_next2(j, k + 2 < e.M ? e.ops[j * e.stride + k + 2] : -1);
                 e.w(j, JSS_F_F4) = cur >= 0 ? e.tm[cur >> 16] : JSS_F4_ONE;   // :569-586 (machine clocks already advanced)
             }
         } else if (e.todo(j) < e.M) {                                     // :594 waiting
@@ -215,7 +225,9 @@ void check_no_op(const Env &e) {
         int k = caseA ? todo + 1 : todo;                                  // :332 / :370
         int tn = caseA ? t + e.w(j, JSS_F_LEFT) : t + e.tm[e.w(j, JSS_F_CUR) >> 16];   // :334-337 / :374-377
         while (k < e.M - 1 && max_horizon > tn) {                         // :340-342 / :380-382
-            const int op = k == todo ? e.w(j, JSS_F_CUR) : (k == todo + 1 ? e.w(j, JSS_F_NEXT) : e.ops[j * e.stride + k]);
+            const int op = k == todo ? e.w(j, JSS_F_CUR)
+                           : k == todo + 1 ? e.w(j, JSS_F_NEXT)
+                           : k == todo + 2 ? e.next2(j) : e.ops[j * e.stride + k];
             const int m = op >> 16;
             if (m_legal[m] && horizon[m] > tn) covered[m] = true;         // :346-351
             tn += op & kDurMask;                                          // :362

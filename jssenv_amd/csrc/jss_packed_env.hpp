@@ -56,7 +56,7 @@ __device__ __forceinline__ int4 ld_nt_int4(const void *base, unsigned byte_off) 
 #define JSS_ST_STATE st_off
 #endif
 
-template <int G>
+template <int G, int TAB>
 struct PCtx {                 // per-lane view of "my env"
     int lane, gl, gbase;      // gl = lane within the group, gbase = first lane of the group
     unsigned rel;             // my env's index within the wave's env set (clamped like b)
@@ -65,13 +65,19 @@ struct PCtx {                 // per-lane view of "my env"
     bool jvalid, mvalid;      // gl < J, gl < M
     int tid;                  // instance of my env
     int J, M, max_time_op;
-    const int32_t *row;       // op table row of my job (LDS with kTabLds, global with kTabGlobal)
+    const int32_t *lds_row;   // kTabLds: op table row of my job in LDS
+    // op table row of my job.  With kTabGlobal the 64-bit address is rebuilt from `tid` at each of its (few) uses
+    // rather than carried in two VGPRs through the whole kernel (the kernel sits at the 64-VGPR occupancy edge).
+    __device__ __forceinline__ const int32_t *row(const Params &p) const {
+        if (TAB == kTabLds) return lds_row;
+        return p.d.ops + (size_t)tid * p.region_ints + (gl < p.d.jmax ? gl : 0) * p.d.mmax;
+    }
 };
 
 template <int G>
 struct PEnv {
     int t;                    // group-uniform
-    int todo, cur, nxt, left, perf, idle, idle_last, f4;  // job gl
+    int todo, cur, nxt, nxt2, left, perf, idle, idle_last, f4;  // job gl (cur / nxt / nxt2: the job's next three ops, -1 = none)
     int tm;                   // machine gl
     bool legal, blocked;      // job gl
     int noop, err;            // group-uniform
@@ -119,16 +125,17 @@ __device__ __forceinline__ int grp_sum(int v) {
 // ---------------------------------------------------------------------------------------
 // reset(): jss_env.py:145-181 (registers only; `on` = groups being reset)
 // ---------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G> &c, const Params &p, bool on) {
+template <int G, int TAB>
+__device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, bool on) {
     if (on) {
         e.t = 0;                                                         // :154
         e.tm = 0;                                                        // :164
         e.noop = 0;                                                      // :161
         e.err = 0;
         e.todo = 0;                                                      // :166
-        e.cur = c.jvalid ? c.row[0] : -1;                                // :174-176
-        e.nxt = (c.jvalid && 1 < c.M) ? c.row[1] : -1;
+        e.cur = c.jvalid ? c.row(p)[0] : -1;                                // :174-176
+        e.nxt = (c.jvalid && 1 < c.M) ? c.row(p)[1] : -1;
+        e.nxt2 = (c.jvalid && 2 < c.M) ? c.row(p)[2] : -1;
         e.left = e.perf = e.idle = e.idle_last = 0;                      // :165-170
         e.f4 = 0;                                                        // :180
         e.legal = c.jvalid;                                              // :160
@@ -151,8 +158,8 @@ __device__ __forceinline__ int p_next_event(const PEnv<G> &e) {
     return grp_min<G>(e.tm > 0 ? e.tm : kBig);
 }
 
-template <int G>
-__device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act, int d) {
+template <int G, int TAB>
+__device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, bool act, int d) {
     const int idle_machines = __popc(grp_ballot<G>(c.mvalid && e.tm < d, c.gbase));
     const int hole = d * idle_machines;                                  // :606-608 (tm < d only when tm == 0)
     bool fin = false;
@@ -175,9 +182,10 @@ __device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act,
         }
         e.tm = imax(0, e.tm - d);                                        // :611
         if (fin) {                                                       // :562-566 / :581: the job moves on to its next op,
-            e.cur = e.nxt;                                               // which the record carries; the one after it is the
-            e.nxt = (e.todo + 1 < c.M) ? c.row[e.todo + 1] : -1;         // step's only op table read (not needed before the
-        }                                                                // job's next finish, a prioritisation or a long walk)
+            e.cur = e.nxt;                                               // which the record carries (cur <- nxt <- nxt2); the
+            e.nxt = e.nxt2;                                              // op two further on is the step's only op table read
+            e.nxt2 = (e.todo + 2 < c.M) ? c.row(p)[e.todo + 2] : -1;        // (not needed before a long look-ahead walk)
+        }
     }
     // time left on the machine my job needs (after the update): feature-4 numerator
     // max(0, tm_old[need] - d) (:569-578) and the "machine is free" test of :616 in one read
@@ -205,8 +213,8 @@ __device__ __forceinline__ int p_advance(PEnv<G> &e, const PCtx<G> &c, bool act,
 // until every machine is idle, T = last event.  With nothing busy there is no event at all: a NOPE then is the
 // reference's IndexError (:517) and is flagged.
 // ---------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ void p_jump(PEnv<G> &e, const PCtx<G> &c, bool want, bool is_nope, int &rn) {
+template <int G, int TAB>
+__device__ __forceinline__ void p_jump(PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, bool want, bool is_nope, int &rn) {
     const bool running = e.left > 0;
     const bool waiting = c.jvalid && !running && e.cur >= 0;             // cur >= 0  <=>  todo < M
     const int tmx = grp_read<G>(e.tm, (running ? e.nxt : e.cur) >> 16, c.gbase);   // release time of the machine I need (next)
@@ -246,7 +254,8 @@ __device__ __forceinline__ void p_jump(PEnv<G> &e, const PCtx<G> &c, bool want, 
                 e.left = 0;
                 e.todo += 1;                                             // :558
                 e.cur = e.nxt;                                           // :562-566 / :581
-                e.nxt = (e.todo + 1 < c.M) ? c.row[e.todo + 1] : -1;
+                e.nxt = e.nxt2;
+                e.nxt2 = (e.todo + 2 < c.M) ? c.row(p)[e.todo + 2] : -1;
                 const bool more = e.cur >= 0;
                 e.idle += more ? T - f : 0;                              // :552 (+0 at the finish), then :596 per later event
                 e.idle_last = more ? T - f : 0;                          // :554, then :597
@@ -267,8 +276,8 @@ __device__ __forceinline__ void p_jump(PEnv<G> &e, const PCtx<G> &c, bool want, 
 // ---------------------------------------------------------------------------------------
 // _prioritization_non_final(): jss_env.py:183-254 for the groups with `on`
 // ---------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ void p_prioritize(PEnv<G> &e, const PCtx<G> &c, bool on) {
+template <int G, int TAB>
+__device__ __forceinline__ void p_prioritize(PEnv<G> &e, const PCtx<G, TAB> &c, bool on) {
     const bool fin = on && e.legal && e.todo == c.M - 1;                 // :217 final ops among legal jobs
     uint32_t bits = grp_ballot<G>(fin, c.gbase);
     if (__ballot(bits != 0) == 0) return;                                // nothing to suppress anywhere in the wave
@@ -306,8 +315,8 @@ __device__ __forceinline__ void p_prioritize(PEnv<G> &e, const PCtx<G> &c, bool 
 // first ops are the ones the job record carries (current op, next op); only a walk that goes further
 // reads the op table (about one lane in ten, tools/walk_depth.py).
 // ---------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool on, int32_t *mvtab) {
+template <int G, int TAB>
+__device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, bool on, int32_t *mvtab) {
     if (on) e.noop = 0;                                                  // :278
     const uint32_t lm = grp_ballot<G>(e.legal, c.gbase);
     const int nl = __popc(lm);
@@ -384,9 +393,17 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool
         ++k;
         go = k < last && mh > tn;
     }
+    if (go) {                                                                         // op k == todo + 2: the one after it
+        const int m = e.nxt2 >> 16;
+        if (tab[m] > tn) u |= 1 << m;
+        tn += e.nxt2 & kDurMask;
+        ++k;
+        go = k < last && mh > tn;
+    }
     if (go) {                                                                         // further: the op table, two entries per trip
         do {
-            const int op0 = c.row[k], op1 = c.row[k + 1];                             // k + 1 <= M - 1: inside the row
+            const int32_t *row = c.row(p);
+            const int op0 = row[k], op1 = row[k + 1];                             // k + 1 <= M - 1: inside the row
             int m = op0 >> 16;
             if (tab[m] > tn) u |= 1 << m;
             tn += op0 & kDurMask;
@@ -408,8 +425,8 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G> &c, bool
 // ---------------------------------------------------------------------------------------
 // step(): jss_env.py:403-481.  `a` is group-uniform.  Returns the reward numerator.
 // ---------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params &p, int a, int32_t *mvtab) {
+template <int G, int TAB>
+__device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, int a, int32_t *mvtab) {
     const bool is_nope = c.alive && a == c.J;                            // :419
     const bool is_job = c.alive && a >= 0 && a < c.J;
     if (c.alive && (a < JSS_ACTION_SKIP || a > c.J)) e.err |= JSS_ERR_BAD_ACTION;
@@ -440,18 +457,18 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G> &c, const Params
     {   // :429-430 / :469-470: `while nb_legal_actions == 0: increase_time_step()` as one jump
         const bool none_legal = !grp_any<G>(e.legal, c.gbase);
         if (__ballot(stepping && none_legal) != 0 && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE))
-            p_jump(e, c, stepping && none_legal, is_nope, rn);
+            p_jump(e, c, p, stepping && none_legal, is_nope, rn);
     }
     if (!JSS_ABLATED(p, JSS_ABLATE_PRIORITIZE)) p_prioritize(e, c, stepping);        // :432 / :471
-    if (!JSS_ABLATED(p, JSS_ABLATE_CHECK_NO_OP)) p_check_no_op(e, c, stepping, mvtab);  // :433 / :472
+    if (!JSS_ABLATED(p, JSS_ABLATE_CHECK_NO_OP)) p_check_no_op(e, c, p, stepping, mvtab);  // :433 / :472
     return rn;
 }
 
 // ---------------------------------------------------------------------------------------
 // action selectors (group-uniform result; -1 when nothing is legal)
 // ---------------------------------------------------------------------------------------
-template <int G>
-__device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G> &c, const Params &p, uint64_t env_id,
+template <int G, int TAB>
+__device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, uint64_t env_id,
                                         uint32_t episode, uint32_t step) {
     const int kind = p.kind;
     const uint32_t lm = grp_ballot<G>(e.legal, c.gbase);
@@ -511,8 +528,8 @@ struct PRaw {  // loads issued before the op table is staged; unpacked after the
     int tm;
 };
 
-template <int G>
-__device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G> &c, const Params &p) {
+template <int G, int TAB>
+__device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G, TAB> &c, const Params &p) {
     PRaw<G> r;
     const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
     const unsigned jc = (unsigned)c.gl < jm ? c.gl : 0;
@@ -532,8 +549,8 @@ __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G> &c, const Params 
     return r;
 }
 
-template <int G>
-__device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G> &c, const PRaw<G> &r) {
+template <int G, int TAB>
+__device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, const PRaw<G> &r) {
     e.t = r.h.x;
     e.err = r.h.w & 0xFF;
     e.noop = (r.h.w & JSS_STATUS_NOOP) ? 1 : 0;
@@ -547,6 +564,7 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G> &c, const 
     e.idle_last = v ? r.hi.y : 0;
     e.f4 = v ? r.hi.z : 0;
     e.nxt = v ? r.hi.w : -1;
+    e.nxt2 = (v && ((unsigned)r.lo.x >> JSS_NEXT2_SHIFT)) ? (int)((unsigned)r.lo.x >> JSS_NEXT2_SHIFT) : -1;
     e.legal = v && (r.lo.x & JSS_FLAG_LEGAL);
     e.blocked = v && (r.lo.x & JSS_FLAG_BLOCKED);
     PHeader hd;
@@ -555,8 +573,8 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G> &c, const 
     return hd;
 }
 
-template <int G>
-__device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G> &c, const Params &p, const PHeader &hd,
+template <int G, int TAB>
+__device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, const PHeader &hd,
                                         const PRaw<G> &raw) {
     if (!c.alive) return;
     const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
@@ -568,7 +586,8 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G> &c, cons
     if (c.jvalid) {
         int32_t *jb = p.s.job + fe * jm * JSS_NF;
         const unsigned jo = (c.rel * jm + c.gl) * 32u;
-        const int4 lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0), e.cur, e.left, e.perf);
+        const int4 lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0) |
+                                      (e.nxt2 >= 0 ? (int)((unsigned)e.nxt2 << JSS_NEXT2_SHIFT) : 0), e.cur, e.left, e.perf);
         const int4 hi = make_int4(e.idle, e.idle_last, e.f4, e.nxt);
 #ifndef JSS_VAR_NO_DIRTY   // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
         if (lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) JSS_ST_STATE(jb, jo, lo);
@@ -590,7 +609,7 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G> &c, cons
 // image of the wave's E consecutive envs ([E][jmax][7], padding rows zero), which then goes out as
 // one linear copy -- dwordx4 per lane when the wave's block is whole and 16-byte sized.
 template <int G, int TAB>
-__device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, const Params &p, float *scratch,
+__device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, float *scratch,
                                             bool wave_whole) {
     constexpr int E = kWave / G;
     const int row_floats = p.d.jmax * 7;
@@ -626,8 +645,8 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G> &c, 
 // ---------------------------------------------------------------------------------------
 // mode bodies: everything between "state unpacked into registers" and "state stored"
 // ---------------------------------------------------------------------------------------
-template <int G, int MODE>
-__device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c, const Params &p, int a_in, bool selected,
+template <int G, int MODE, int TAB>
+__device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G, TAB> &c, const Params &p, int a_in, bool selected,
                                        int32_t *mvtab) {
     const size_t fe = (size_t)c.first_env;
     if (MODE == kReset) {
@@ -657,7 +676,7 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c
         const int d = p_next_event(e);
         const bool busy = d < kBig;
         if (on && !busy) e.err |= JSS_ERR_NOPE_IDLE;                     // reference: IndexError (:517)
-        const int hole = p_advance(e, c, on && busy, d);
+        const int hole = p_advance(e, c, p, on && busy, d);
         if (on && c.gl == 0 && p.hole) st_off<int>(p.hole + fe, c.rel * 4u, busy ? hole : 0);
     } else if (MODE == kPolicy) {
         const uint64_t env_id = (uint64_t)(p.d.env_ids ? ld_off<int64_t>(p.d.env_ids + fe, c.rel * 8u)
@@ -711,8 +730,15 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G> &c
 // the packed kernel, one env set (E = 64/G envs) per wave
 // ---------------------------------------------------------------------------------------
 // launch bounds: the largest occupancy each mode reaches without spilling (8 waves per SIMD = 64 VGPRs)
+// With kTabGlobal the instance (tid, J, M, max_time_op) is group-uniform data in VGPRs instead of SGPRs: the step
+// kernels need 66-70 VGPRs.  7 waves/SIMD (72 VGPRs) beats 8 with two VGPRs in scratch: 19.4 vs 21.5 us per step
+// on synthetic 15x15, B = 65 536 (profiles/README.md).
+#ifndef JSS_PACKED_GLOBAL_MIN_BLOCKS
+#define JSS_PACKED_GLOBAL_MIN_BLOCKS 7
+#endif
 template <int G, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : (MODE == kStep ? 7 : 8)) void jss_packed_kernel(Params p) {
+__global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : ((TAB == kTabGlobal && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
+void jss_packed_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     constexpr int E = kWave / G;                      // envs per wave
     constexpr int EB = E * kWavesPerBlock;            // envs per workgroup
@@ -722,7 +748,7 @@ __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : (MODE == kStep ? 7 :
     float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;
     int32_t *mvtab = lds + p.mv_off_ints + wave * kWave;                 // one int per lane, see p_check_no_op
 
-    PCtx<G> c;
+    PCtx<G, TAB> c;
     c.lane = lane;
     c.gl = lane & (G - 1);
     c.gbase = lane & ~(G - 1);
@@ -739,7 +765,7 @@ __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : (MODE == kStep ? 7 :
     bool selected = true;
     c.tid = 0;
     if (!wave_dead) {
-        raw = p_issue_loads<G>(c, p);
+        raw = p_issue_loads<G, TAB>(c, p);
         if (MODE == kStep) a_in = ld_off<int>(p.actions + fe, c.rel * 4u);
         if ((MODE == kReset || MODE == kAdvance) && p.which) selected = ld_off<uint8_t>(p.which + fe, c.rel) != 0;
         if (TAB == kTabGlobal)
@@ -757,11 +783,11 @@ __global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : (MODE == kStep ? 7 :
     c.max_time_op = ir[JSS_I_MAX_TIME_OP];
     c.jvalid = c.gl < c.J;
     c.mvalid = c.gl < c.M;
-    c.row = (TAB == kTabLds ? lds : p.d.ops + (size_t)c.tid * p.region_ints) + (c.gl < p.d.jmax ? c.gl : 0) * p.d.mmax;
+    c.lds_row = lds + (c.gl < p.d.jmax ? c.gl : 0) * p.d.mmax;
 
     PEnv<G> e;
     PHeader hd = p_unpack(e, c, raw);
-    p_body<G, MODE>(e, hd, c, p, a_in, selected, mvtab);
+    p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab);
     if (MODE == kPolicy) return;
     p_store(e, c, p, hd, raw);
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS)) p_store_obs<G, TAB>(e, c, p, scratch, wave_whole);

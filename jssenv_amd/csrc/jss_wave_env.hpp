@@ -22,7 +22,7 @@ struct Ctx {
 template <int JPL>
 struct Env {
     int t;                                                               // current_time_step
-    int todo[JPL], cur[JPL], nxt[JPL], left[JPL], perf[JPL], idle[JPL], idle_last[JPL], f4[JPL];
+    int todo[JPL], cur[JPL], nxt[JPL], nxt2[JPL], left[JPL], perf[JPL], idle[JPL], idle_last[JPL], f4[JPL];
     uint64_t legal[JPL], blocked[JPL];                                   // job sets, wave-uniform
     int tm;                                                              // lane m: time_until_available_machine[m]
     int noop;                                                            // legal_actions[J]
@@ -69,6 +69,7 @@ __device__ __forceinline__ void reset_env(Env<JPL> &e, const Ctx &c, const Param
         e.todo[s] = 0;                                                   // :166
         e.cur[s] = v ? c.tab[j * c.stride] : -1;                         // :174-176 needed machine = op 0
         e.nxt[s] = (v && 1 < c.M) ? c.tab[j * c.stride + 1] : -1;
+        e.nxt2[s] = (v && 2 < c.M) ? c.tab[j * c.stride + 2] : -1;
         e.left[s] = e.perf[s] = e.idle[s] = e.idle_last[s] = 0;          // :165-170
         e.f4[s] = 0;                                                     // :180 state zeros
         e.legal[s] = __ballot(v);                                        // :160
@@ -120,8 +121,9 @@ __device__ __forceinline__ int advance(Env<JPL> &e, const Ctx &c) {
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         if (fin[s]) {                                                    // :562-566 / :581: the job moves on to the op its
-            e.cur[s] = e.nxt[s];                                         // record carries; the op after that is the only
-            e.nxt[s] = (e.todo[s] + 1 < c.M) ? c.tab[j * c.stride + e.todo[s] + 1] : -1;   // op table read of the step
+            e.cur[s] = e.nxt[s];                                         // record carries (cur <- nxt <- nxt2); the op two
+            e.nxt[s] = e.nxt2[s];                                        // further on is the only op table read of the step
+            e.nxt2[s] = (e.todo[s] + 2 < c.M) ? c.tab[j * c.stride + e.todo[s] + 2] : -1;
         }
         const int ncur = e.cur[s];
         // feature 4 numerator: max(0, tm_old[need] - d) (:569-578) == tm_new[need]
@@ -189,7 +191,8 @@ __device__ __forceinline__ void jump(Env<JPL> &e, const Ctx &c, bool is_nope, in
                 e.left[s] = 0;
                 e.todo[s] += 1;
                 e.cur[s] = e.nxt[s];
-                e.nxt[s] = (e.todo[s] + 1 < c.M) ? c.tab[j * c.stride + e.todo[s] + 1] : -1;
+                e.nxt[s] = e.nxt2[s];
+                e.nxt2[s] = (e.todo[s] + 2 < c.M) ? c.tab[j * c.stride + e.todo[s] + 2] : -1;
                 const bool more = e.cur[s] >= 0;
                 e.idle[s] += more ? T - f : 0;
                 e.idle_last[s] = more ? T - f : 0;
@@ -349,6 +352,14 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
             ++k;
             go = k < last && hz.mh > tn;
         }
+        if (go) {                                                                 // op k == todo + 2: the one after it
+            tn = walk_op(hz, e.nxt2[s], tn, u);
+            ++k;
+            go = k < last && hz.mh > tn;
+        }
+#ifdef JSS_VAR_NO_DEEP_WALK   // timing experiment only (wrong results): how much do the walk's op table reads cost?
+        go = false;
+#endif
         if (go) {                                                                 // further: the op table, two entries per trip
             const int32_t *row = c.tab + j * c.stride;
             do {
@@ -559,6 +570,7 @@ __device__ __forceinline__ Header unpack_env(Env<JPL> &e, const Ctx &c, const Ra
         e.idle_last[s] = v ? hi.y : 0;
         e.f4[s] = v ? hi.z : 0;
         e.nxt[s] = v ? hi.w : -1;
+        e.nxt2[s] = (v && ((unsigned)lo.x >> JSS_NEXT2_SHIFT)) ? (int)((unsigned)lo.x >> JSS_NEXT2_SHIFT) : -1;
         e.legal[s] = __ballot(v && (lo.x & JSS_FLAG_LEGAL));
         e.blocked[s] = __ballot(v && (lo.x & JSS_FLAG_BLOCKED));
     }
@@ -582,7 +594,8 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
         const int j = s * kWave + c.lane;
         const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = (int)((e.blocked[s] >> c.lane) & 1);
         if (j < c.J) {   // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
-            const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0), e.cur[s], e.left[s], e.perf[s]);
+            const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0) |
+                                          (e.nxt2[s] >= 0 ? (int)((unsigned)e.nxt2[s] << JSS_NEXT2_SHIFT) : 0), e.cur[s], e.left[s], e.perf[s]);
             const int4 hi = make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]);
             const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
 #ifndef JSS_VAR_NO_DIRTY

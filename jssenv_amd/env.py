@@ -554,7 +554,7 @@ class BatchedJssEnv:
     def host_state(self, i: int = 0):
         """Everything about env i as NumPy, sliced to its true (J, M).  ``job_state`` rows follow the JSS_F_* word
         order with the packed word 0 decoded: row 0 = todo_time_step_job, row 7 = flags (1 legal, 2 blocked);
-        ``next_op`` is the record's cached next op."""
+        ``next_op`` / ``next2_op`` are the record's cached next ops."""
         n = self.backend.numpy
         J, M = int(self.jobs_per_env[i]), int(self.machines_per_env[i])
         raw = n(self.job_state[i])[:J].astype(np.int64).T         # (NF, J): rows = JSS_F_* words
@@ -567,6 +567,7 @@ class BatchedJssEnv:
             "clock": int(hdr[_abi.H_CLOCK]),
             "job_state": js,
             "next_op": raw[_abi.F_NEXT],
+            "next2_op": np.where((raw[_abi.F_TODO] & 0xFFFFFFFF) >> _abi.NEXT2_SHIFT, (raw[_abi.F_TODO] & 0xFFFFFFFF) >> _abi.NEXT2_SHIFT, -1),
             "tm": n(self.machine_state[i])[:M].astype(np.int64),
             "mask": n(self.action_mask[i])[:J + 1].astype(bool),
             "mask_padding": n(self.action_mask[i])[J + 1:],

@@ -59,6 +59,10 @@ def assert_matches_oracle(h, orc, where, fresh_col0=True, check_outputs=True):
         if todo[j] + 1 < orc.machines:
             want_next = (int(orc.instance_matrix[j, todo[j] + 1, 0]) << 16) | int(orc.instance_matrix[j, todo[j] + 1, 1])
         assert h["next_op"][j] == want_next, f"{where}: next op of job {j}"
+        want2 = -1
+        if todo[j] + 2 < orc.machines:
+            want2 = (int(orc.instance_matrix[j, todo[j] + 2, 0]) << 16) | int(orc.instance_matrix[j, todo[j] + 2, 1])
+        assert h["next2_op"][j] == want2, f"{where}: next-but-one op of job {j}"
     assert h["noop_flag"] == bool(orc.legal_actions[-1]), f"{where}: NOPE flag in the header"
     if check_outputs:
         assert h["done"] == (orc.nb_legal_actions == 0), f"{where}: done"

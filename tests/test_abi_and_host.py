@@ -39,7 +39,8 @@ def test_header_constants_match_python_mirror():
     defs = {k: int(v) for k, v in re.findall(r"#define (JSS_\w+) \(?(-?\d+)\)?", hdr)}
     assert defs["JSS_NF"] == _abi.NF and defs["JSS_F_CUR"] == _abi.F_CUR and defs["JSS_F_F4"] == _abi.F_F4
     assert defs["JSS_F_NEXT"] == _abi.F_NEXT and defs["JSS_H_STATUS"] == _abi.H_STATUS and defs["JSS_STATUS_NOOP"] == _abi.STATUS_NOOP
-    assert (defs["JSS_TODO_MASK"], defs["JSS_FLAG_LEGAL"], defs["JSS_FLAG_BLOCKED"]) == (_abi.TODO_MASK, _abi.FLAG_LEGAL, _abi.FLAG_BLOCKED)
+    assert (defs["JSS_TODO_MASK"], defs["JSS_FLAG_LEGAL"], defs["JSS_FLAG_BLOCKED"], defs["JSS_NEXT2_SHIFT"]) == \
+        (_abi.TODO_MASK, _abi.FLAG_LEGAL, _abi.FLAG_BLOCKED, _abi.NEXT2_SHIFT)
     assert defs["JSS_NI"] == _abi.NI == I.INST_RECORD_INTS and defs["JSS_I_RCP_MACHINES"] == _abi.I_RCP_MACHINES
     for name, kid in _abi.KERNEL.items():
         assert defs["JSS_KERNEL_" + name.upper()] == kid

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from jssenv_amd.build import build_extension  # noqa: E402
 
-VARIANTS = {"profiling": ["-DJSS_PROFILING"], "occ7": ["-DJSS_WAVE_MIN_BLOCKS=7"], "nodirty": ["-DJSS_VAR_NO_DIRTY"],
+VARIANTS = {"profiling": ["-DJSS_PROFILING"], "occ7": ["-DJSS_WAVE_MIN_BLOCKS=7"], "nodirty": ["-DJSS_VAR_NO_DIRTY"], "nodeepwalk": ["-DJSS_VAR_NO_DEEP_WALK"], "pg8": ["-DJSS_PACKED_GLOBAL_MIN_BLOCKS=8"],
             "ntst": ["-DJSS_VAR_NT_STATE_ST"], "ntstld": ["-DJSS_VAR_NT_STATE_ST", "-DJSS_VAR_NT_STATE_LD"]}
 
 if __name__ == "__main__":
