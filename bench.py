@@ -286,8 +286,8 @@ def main():
                 env.rollout(policy, n_iter=n_iter, autoreset=True)
         ev1.record()
         torch.cuda.synchronize()
+        dt = time.perf_counter() - t0          # this rank's time; the job's time is the MAX over ranks (reduce_counters)
         barrier()
-        dt = time.perf_counter() - t0
         return dt, ev0.elapsed_time(ev1) / n_launch
 
     def capture(env, policy, n_launch):

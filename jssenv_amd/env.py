@@ -79,10 +79,11 @@ class HipBackend:
             src = self.torch.from_numpy(np.ascontiguousarray(src))
         dst.copy_(src)
 
-    def select_into(self, out, cond, a, b):
-        """out[...] = where(cond, a (scalar), b) without allocating."""
+    def select_into(self, out, flags, a, b, scratch):
+        """out[...] = where(flags != 0, a (scalar), b) without allocating: `scratch` is a preallocated bool tensor."""
+        scratch.copy_(flags)                      # uint8 -> bool conversion in place
         out.copy_(b)
-        out.masked_fill_(cond, a)
+        out.masked_fill_(scratch, a)
 
     # -- execution -------------------------------------------------------------------------
     def stream(self):
@@ -176,9 +177,9 @@ class CpuBackend:
     def copy_into(self, dst, src):
         dst[...] = src
 
-    def select_into(self, out, cond, a, b):
+    def select_into(self, out, flags, a, b, scratch):
         np.copyto(out, b)
-        out[cond] = a
+        out[flags != 0] = a
 
     def stream(self):
         return 0
@@ -275,6 +276,7 @@ class BatchedJssEnv:
             self._hole = be.zeros((B,), "int32")
             self._act_buf = be.zeros((B,), "int32")
             self._was_done = be.zeros((B,), "uint8")
+            self._was_done_mask = be.zeros((B,), "bool")
 
         p = be.ptr
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._rem), p(self._inst), p(self._table_of_env), None,
@@ -365,7 +367,7 @@ class BatchedJssEnv:
                 raise ValueError("actions must have shape (B,)")
             if autoreset:
                 be.copy_into(self._was_done, self.done)
-                be.select_into(self._act_buf, self._was_done != 0, -1, a)
+                be.select_into(self._act_buf, self._was_done, -1, a, self._was_done_mask)
                 a = self._act_buf
             _abi.check(be.lib, be.lib.jss_step(d, s, be.ptr(a), o, be.stream()), "jss_step")
             if autoreset:

@@ -66,9 +66,9 @@ class EmuBackend:
         self._keep = [a]
         return a
 
-    def select_into(self, out, cond, a, b):
+    def select_into(self, out, flags, a, b, scratch):
         np.copyto(out, b)
-        out[cond] = a
+        out[flags != 0] = a
 
     def copy_into(self, dst, src):
         dst[...] = src
