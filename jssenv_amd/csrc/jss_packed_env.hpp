@@ -31,30 +31,12 @@ __device__ __forceinline__ void st_off(void *base, unsigned byte_off, T v) {
 // cache lines and never read back by a kernel: it should not displace state lines in L2.  Measured on the headline
 // (profiles/README.md): 20.2 -> 17.7 us per step.  The same hint on the small outputs (1- and 4-byte stores of mask,
 // reward, done) or on the state records makes things WORSE (partial lines go out uncombined; 17.7 -> 18.8 / 19.5 us),
-// and nt state loads cost 25 %: those stay ordinary accesses (A/B builds: tools/build_instrumented.py).
-typedef int jss_v4i __attribute__((vector_size(16)));
+// and nt state loads cost 25 %: those stay ordinary accesses.
 typedef float jss_v4f __attribute__((vector_size(16)));
-template <class T>
-__device__ __forceinline__ void st_nt(void *base, unsigned byte_off, T v) {
-    __builtin_nontemporal_store(v, reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off));
-}
-__device__ __forceinline__ void st_nt(void *base, unsigned byte_off, int4 v) {
-    const jss_v4i x = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(x, reinterpret_cast<jss_v4i *>(reinterpret_cast<char *>(base) + byte_off));
-}
 __device__ __forceinline__ void st_nt(void *base, unsigned byte_off, float4 v) {
     const jss_v4f x = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(x, reinterpret_cast<jss_v4f *>(reinterpret_cast<char *>(base) + byte_off));
 }
-__device__ __forceinline__ int4 ld_nt_int4(const void *base, unsigned byte_off) {
-    const jss_v4i x = __builtin_nontemporal_load(reinterpret_cast<const jss_v4i *>(reinterpret_cast<const char *>(base) + byte_off));
-    return make_int4(x[0], x[1], x[2], x[3]);
-}
-#ifdef JSS_VAR_NT_STATE_ST
-#define JSS_ST_STATE st_nt
-#else
-#define JSS_ST_STATE st_off
-#endif
 
 template <int G, int TAB>
 struct PCtx {                 // per-lane view of "my env"
@@ -67,7 +49,7 @@ struct PCtx {                 // per-lane view of "my env"
     int J, M, max_time_op;
     const int32_t *lds_row;   // kTabLds: op table row of my job in LDS
     // op table row of my job.  With kTabGlobal the 64-bit address is rebuilt from `tid` at each of its (few) uses
-    // rather than carried in two VGPRs through the whole kernel (the kernel sits at the 64-VGPR occupancy edge).
+    // rather than carried in two VGPRs through the whole kernel (these kernels are the register-hungry ones).
     __device__ __forceinline__ const int32_t *row(const Params &p) const {
         if (TAB == kTabLds) return lds_row;
         return p.d.ops + (size_t)tid * p.region_ints + (gl < p.d.jmax ? gl : 0) * p.d.mmax;
@@ -538,13 +520,8 @@ __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G, TAB> &c, const Pa
     r.h = ld_off<int4>(p.s.env + fe * 4, c.rel * 16u);
     const int32_t *jb = p.s.job + fe * jm * JSS_NF;
     const unsigned jo = (c.rel * jm + jc) * 32u;
-#ifdef JSS_VAR_NT_STATE_LD
-    r.lo = ld_nt_int4(jb, jo);
-    r.hi = ld_nt_int4(jb, jo + 16u);
-#else
     r.lo = ld_off<int4>(jb, jo);
     r.hi = ld_off<int4>(jb, jo + 16u);
-#endif
     r.tm = ld_off<int>(p.s.machine + fe * mm, (c.rel * mm + mc) * 4u);
     return r;
 }
@@ -580,22 +557,18 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
     const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
     const size_t fe = (size_t)c.first_env;
     if (c.gl == 0)
-        JSS_ST_STATE(p.s.env + fe * 4, c.rel * 16u,
+        st_off(p.s.env + fe * 4, c.rel * 16u,
                      make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0)));
-    if (c.mvalid) JSS_ST_STATE(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
+    if (c.mvalid) st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
     if (c.jvalid) {
         int32_t *jb = p.s.job + fe * jm * JSS_NF;
         const unsigned jo = (c.rel * jm + c.gl) * 32u;
         const int4 lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0) |
                                       (e.nxt2 >= 0 ? (int)((unsigned)e.nxt2 << JSS_NEXT2_SHIFT) : 0), e.cur, e.left, e.perf);
         const int4 hi = make_int4(e.idle, e.idle_last, e.f4, e.nxt);
-#ifndef JSS_VAR_NO_DIRTY   // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
-        if (lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) JSS_ST_STATE(jb, jo, lo);
-        if (hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) JSS_ST_STATE(jb, jo + 16u, hi);
-#else
-        JSS_ST_STATE(jb, jo, lo);
-        JSS_ST_STATE(jb, jo + 16u, hi);
-#endif
+        // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
+        if (lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
+        if (hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) st_off(jb, jo + 16u, hi);
     }
     // action mask row of jmax + 1 bytes: legal jobs, the NOPE flag at index J, zeros behind it
     uint8_t *mk = p.o.action_mask + fe * (jm + 1);

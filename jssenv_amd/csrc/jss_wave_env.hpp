@@ -357,9 +357,6 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
             ++k;
             go = k < last && hz.mh > tn;
         }
-#ifdef JSS_VAR_NO_DEEP_WALK   // timing experiment only (wrong results): how much do the walk's op table reads cost?
-        go = false;
-#endif
         if (go) {                                                                 // further: the op table, two entries per trip
             const int32_t *row = c.tab + j * c.stride;
             do {
@@ -598,13 +595,8 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
                                           (e.nxt2[s] >= 0 ? (int)((unsigned)e.nxt2[s] << JSS_NEXT2_SHIFT) : 0), e.cur[s], e.left[s], e.perf[s]);
             const int4 hi = make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]);
             const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
-#ifndef JSS_VAR_NO_DIRTY
             if (lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w) st_off<int4>(jb, (unsigned)j * 32u, lo);
             if (hi.x != hi0.x || hi.y != hi0.y || hi.z != hi0.z || hi.w != hi0.w) st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
-#else
-            st_off<int4>(jb, (unsigned)j * 32u, lo);
-            st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
-#endif
         }
         // action mask: legal jobs, the NOPE flag at index J, zeros behind it
         if (j < jm) st_off<uint8_t>(mk, (unsigned)j, (uint8_t)(j < c.J ? lg : (j == c.J ? e.noop : 0)));

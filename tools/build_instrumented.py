@@ -4,8 +4,11 @@ JSSENV_AMD_LIB points somewhere else.
 
     variants/profiling.so   -DJSS_PROFILING: exports jss_profiling_set (phase ablation, LDS padding)
     variants/occ7.so        -DJSS_WAVE_MIN_BLOCKS=7: wave-per-env step kernels at 7 waves/SIMD (SGPR budget 102)
-    variants/nodirty.so     -DJSS_VAR_NO_DIRTY: rewrite every job record every step (packed kernel)
-    variants/ntst.so, ntstld.so   streaming hints on the state stores / loads too (measured slower)
+    variants/pg8.so         -DJSS_PACKED_GLOBAL_MIN_BLOCKS=8: packed per-env-table step kernels at 8 waves/SIMD (2 VGPRs in scratch)
+
+One-off experiments whose findings are recorded in profiles/README.md (streaming hints on other streams, rewriting
+every record, the walk without op table reads) were compile-time variants of the same sources at the commits named
+there; they are not kept in the tree.
 """
 import os
 import sys
@@ -14,8 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from jssenv_amd.build import build_extension  # noqa: E402
 
-VARIANTS = {"profiling": ["-DJSS_PROFILING"], "occ7": ["-DJSS_WAVE_MIN_BLOCKS=7"], "nodirty": ["-DJSS_VAR_NO_DIRTY"], "nodeepwalk": ["-DJSS_VAR_NO_DEEP_WALK"], "pg8": ["-DJSS_PACKED_GLOBAL_MIN_BLOCKS=8"],
-            "ntst": ["-DJSS_VAR_NT_STATE_ST"], "ntstld": ["-DJSS_VAR_NT_STATE_ST", "-DJSS_VAR_NT_STATE_LD"]}
+VARIANTS = {"profiling": ["-DJSS_PROFILING"], "occ7": ["-DJSS_WAVE_MIN_BLOCKS=7"], "pg8": ["-DJSS_PACKED_GLOBAL_MIN_BLOCKS=8"]}
 
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)

@@ -2,7 +2,7 @@
 per step (how long the C launch loop keeps the host busy) and GPU time per step, eager and -- optionally --
 captured into one hipGraph (multi-stream capture: fork/join events become graph edges).
 
-    python tools/gpu_pipeline_probe.py [batch] [instance|synthetic50x20|synthetic15x15] [--graph]
+    python tools/gpu_pipeline_probe.py [batch] [instance|synthetic50x20|synthetic15x15] [--graph] [--wave]
 """
 import os
 import sys
@@ -18,11 +18,12 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(args[0]) if args else 65536
 what = args[1] if len(args) > 1 else "ta01"
 use_graph = "--graph" in sys.argv
+kernel = "wave" if "--wave" in sys.argv else None      # force one wavefront per env (A/B against the packed kernels)
 if what.startswith("synthetic"):
     J, M = (int(x) for x in what[len("synthetic"):].split("x"))
-    env = BatchedJssEnv(synthetic_packed(B, J, M), device="cuda:0")
+    env = BatchedJssEnv(synthetic_packed(B, J, M), device="cuda:0", kernel=kernel)
 else:
-    env = BatchedJssEnv(what, batch=B, device="cuda:0")
+    env = BatchedJssEnv(what, batch=B, device="cuda:0", kernel=kernel)
 env.reset()
 ids = torch.arange(B, device="cuda:0") % 16
 skip = torch.full((B,), -1, dtype=torch.int32, device="cuda:0")
