@@ -294,8 +294,8 @@ __device__ __forceinline__ void p_prioritize(PEnv<G> &e, const PCtx<G, TAB> &c, 
 // machine's final minimum `mv`.  One round per legal job broadcasts that job's (machine, end).
 // Pass 2 looks max_horizon_machine up in a per-group LDS table (`mvtab`, one int per lane) because
 // the walk is divergent, and collects the covered machines as a bit mask (M <= G <= 32).  The walk's
-// first ops are the ones the job record carries (current op, next op); only a walk that goes further
-// reads the op table (about one lane in ten, tools/walk_depth.py).
+// first ops are the three the job record carries (current, next, the one after it); only a walk that goes
+// further reads the op table (2-3 % of the walking lanes, tools/walk_depth.py).
 // ---------------------------------------------------------------------------------------
 template <int G, int TAB>
 __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, bool on, int32_t *mvtab) {
