@@ -559,7 +559,7 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
     if (c.gl == 0)
         st_off(p.s.env + fe * 4, c.rel * 16u,
                      make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0)));
-    if (c.mvalid) st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
+    if (c.mvalid && e.tm != raw.tm) st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);   // idle machines stay 0
     if (c.jvalid) {
         int32_t *jb = p.s.job + fe * jm * JSS_NF;
         const unsigned jo = (c.rel * jm + c.gl) * 32u;

@@ -585,7 +585,7 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
             make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
         mk[jm] = (uint8_t)(c.J == jm ? e.noop : 0);                      // last byte of the row (lanes cover 0..jmax-1)
     }
-    if (c.lane < c.M) st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
+    if (c.lane < c.M && e.tm != raw.tm) st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);   // idle machines stay 0
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
