@@ -310,9 +310,9 @@ def main():
             return args.launch
         probe = []
         for m in candidates:
-            g = capture(env, policy, 40) if m == "graph" else None
-            window(env, policy, 40, 1, m, g)
-            probe.append(min(window(env, policy, 40, 1, m, g)[0] for _ in range(2)))
+            g = capture(env, policy, 60) if m == "graph" else None
+            window(env, policy, 60, 1, m, g)                                   # warm (streams, graph upload)
+            probe.append(min(window(env, policy, 60, 1, m, g)[0] for _ in range(4)))
             del g
         probe = agree_max(probe)
         return candidates[probe.index(min(probe))]
@@ -452,6 +452,8 @@ def main():
         out["config2_ta01_batch4096_random"] = side_run("shared", 4096, "random", modes=("eager", "graph"))
         out["config3_ta41_spt_batch16384"] = side_run("shared", 16384, "SPT", instance="ta41")
         out["config4_synthetic50x20_batch8192"] = side_run("synthetic50x20", 8192, "random")
+        out["config4_synthetic50x20_batch65536_one_gpu"] = side_run("synthetic50x20", 65536, "random",
+                                                                    label_extra=" -- all of config 4 on one GPU")
         out["config5_mixed_padded_batch32768"] = side_run("mixed", 32768, "random", label_extra=", padded 100x20")
         out["config5_mixed_bucketed_batch32768"] = side_run("mixed", 32768, "random", label_extra=", shape-bucketed (no padding)",
                                                             bucketed=True)
