@@ -315,6 +315,8 @@ def main():
             probe.append(min(window(env, policy, 60, 1, m, g)[0] for _ in range(4)))
             del g
         probe = agree_max(probe)
+        if rank == 0:
+            print("launch-mode probe (s per 60 steps): " + ", ".join(f"{m} {t:.6f}" for m, t in zip(candidates, probe)), file=sys.stderr)
         return candidates[probe.index(min(probe))]
 
     def measure(env, policy, steps, mode, n_iter=1, windows=N_WINDOWS):

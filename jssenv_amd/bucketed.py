@@ -74,16 +74,15 @@ class BucketedJssEnv:
         self._streams = None
         self._device = getattr(_backend, "device", None)
         if self._torch is not None and len(self._each()) > 1:
-            dev = self._device
-            self._streams = {k: self._torch.cuda.Stream(device=dev) for k, _ in self._each()}
-            # events are allocated once and re-recorded every call (no allocation/destruction while a
-            # hipGraph capture of the caller's stream is in progress)
-            self._fork_event = self._torch.cuda.Event()
-            self._join_events = {k: self._torch.cuda.Event() for k, _ in self._each()}
+            # the process-wide side streams of the device (HipBackend.side_pool): creating fresh streams per object
+            # lets late-created ones alias the caller's hardware queue
+            pool = _backend.side_pool(len(self._each()))
+            self._streams = {k: pool["streams"][i] for i, (k, _) in enumerate(self._each())}
+            self._fork_event = pool["fork"]
+            self._join_events = {k: pool["join"][i] for i, (k, _) in enumerate(self._each())}
 
     def close(self):
-        """Drop the side streams/events (after a synchronize) so nothing multi-stream is left for
-        interpreter shutdown to tear down in an arbitrary order."""
+        """Wait for outstanding work and stop using the (process-wide) side streams."""
         self.synchronize()
         self._streams = None
         self._fork_event = None

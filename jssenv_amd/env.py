@@ -53,9 +53,6 @@ class HipBackend:
         self.lib = _abi.bind(C.CDLL(path))
         if not self.lib.jss_backend().startswith(b"hip"):
             raise RuntimeError(f"{path} is not the HIP library ({self.lib.jss_backend()!r})")
-        self._side = []          # side streams for rollout_steps (sub-batch pipelining)
-        self._fork = None
-        self._join = []
 
     # -- memory ----------------------------------------------------------------------------
     def zeros(self, shape, dtype):
@@ -102,28 +99,41 @@ class HipBackend:
     def with_streams(self, n, fn):
         """Call fn(streams) where streams is a (void* * n) array: the current stream plus n-1 side streams that
         are forked from it before the call and joined back into it afterwards (stream-ordered for the caller,
-        capturable in a hipGraph)."""
+        capturable in a hipGraph).  The side streams are created once per process and device and shared by every
+        env: HIP deals streams onto a handful of hardware queues in creation order, and a side stream that lands
+        on the caller's queue serialises the sub-batches it was created to overlap (seen in a long-running bench
+        process: 2 sub-batches slower than one launch until the streams were pinned like this)."""
         t = self.torch
         main = t.cuda.current_stream(self.device)
-        while len(self._side) < n - 1:
-            self._side.append(t.cuda.Stream(device=self.device))
-            self._join.append(t.cuda.Event())
-        if self._fork is None:
-            self._fork = t.cuda.Event()
-        side = self._side[:n - 1]
+        pool = self.side_pool(n - 1)
+        side = pool["streams"][:n - 1]
         if side:
-            self._fork.record(main)
+            pool["fork"].record(main)
             for st in side:
-                st.wait_event(self._fork)
+                st.wait_event(pool["fork"])
         arr = (C.c_void_p * n)(main.cuda_stream, *[st.cuda_stream for st in side])
         rc = fn(arr)
         for i, st in enumerate(side):
-            self._join[i].record(st)
-            main.wait_event(self._join[i])
+            pool["join"][i].record(st)
+            main.wait_event(pool["join"][i])
         return rc
 
+    def side_pool(self, n):
+        """The process-wide side streams of this device (at least n of them) with their join events and the fork event."""
+        t = self.torch
+        pool = _SIDE_STREAMS.setdefault(self.device.index, {"streams": [], "join": [], "fork": None})
+        while len(pool["streams"]) < n:
+            pool["streams"].append(t.cuda.Stream(device=self.device))
+            pool["join"].append(t.cuda.Event())
+        if pool["fork"] is None:
+            pool["fork"] = t.cuda.Event()
+        return pool
+
     def close(self):
-        self._side, self._join, self._fork = [], [], None
+        pass
+
+
+_SIDE_STREAMS = {}    # device index -> side streams / events of HipBackend.with_streams (process-wide)
 
 
 class _NullCtx:
