@@ -68,6 +68,14 @@ def host_cores():
     return info
 
 
+def usable_threads():
+    """Threads worth starting: the cgroup quota when there is one (more only oversubscribes), else the affinity mask."""
+    h = host_cores()
+    if h["cgroup_quota_cores"]:
+        return max(1, int(h["cgroup_quota_cores"] + 0.5))
+    return h["affinity"] or h["logical"] or 1
+
+
 
 def cpu_baseline_port(inst_name, seed, target_seconds=8.0):
     """The C oracle (a scalar restatement of the reference's step(), oracle/jss_oracle.c) running
@@ -76,7 +84,7 @@ def cpu_baseline_port(inst_name, seed, target_seconds=8.0):
     from jssenv_amd import builtin_instance
     from oracle import OracleEnv
     inst = builtin_instance(inst_name)
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    threads = max(1, min(usable_threads(), 64))
     envs = [OracleEnv(inst, strict=True) for _ in range(threads)]
 
     def run(iters):
@@ -106,7 +114,7 @@ def cpu_baseline_twin(inst_name, seed, target_seconds=4.0):
     batch of envs, on one core and on all cores."""
     from jssenv_amd import BatchedJssEnv
     from jssenv_amd.env import CpuBackend
-    cores = os.cpu_count() or 1
+    cores = usable_threads()
     out = {"unit": "env steps/s", "kind": "twin", "library": "libjss_cpu.so (C++17 + OpenMP over envs)"}
     for label, threads, batch in (("one_core", 1, 256), ("all_cores", cores, 64 * cores)):
         env = BatchedJssEnv(inst_name, batch=batch, seed=seed, _backend=CpuBackend(threads=threads))
