@@ -472,7 +472,7 @@ def case_bucketed_equals_padded(backend, n_envs=24, n_iter=260, seed=13):
     padded.rollout("random", n_iter=n_iter)
     bucketed.rollout("random", n_iter=n_iter)
     padded.rollout_steps("random", steps=7, n_sub=2)        # the step-per-launch forms on top: sub-batches / per-bucket streams
-    bucketed.rollout_steps("random", steps=7)
+    bucketed.rollout_steps("random", steps=7, chunk=3)      # three chunks: 3 + 3 + 1 steps, dealt round-robin over the buckets
     n_iter += 7
     for i in range(n_envs):
         a, b = padded.host_state(i), bucketed.host_state(i)
