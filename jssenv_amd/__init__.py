@@ -4,11 +4,13 @@ Drop-in for the hot path of prosysscience/JSSEnv (``JssEnv.reset()/step()`` and
 what they call): ``make('jss-v1', env_config=...)`` / ``JssEnv`` keep the
 reference's single-env API, ``BatchedJssEnv`` runs thousands of envs per GPU
 with hand-written HIP kernels (``csrc/jss_kernels.hip``) behind a C ABI
-(``include/jss_hip.h``).
+(``include/jss_hip.h``).  ``device="cpu"`` selects -- explicitly, never as a
+fallback -- the host-core twin ``libjss_cpu.so`` with the same C ABI.
 """
-from .instances import (Instance, available_instances, builtin_instance, load_instance_file,  # noqa: F401
-                        parse_instance_text, synthetic_batch, taillard_instance)
-from .env import BatchedJssEnv, HipBackend, JssEnv, make  # noqa: F401
+from .instances import (Instance, PackedBatch, available_instances, builtin_instance, load_batch,  # noqa: F401
+                        load_instance_file, pack_batch, parse_instance_text, save_batch, synthetic_batch,
+                        synthetic_packed, taillard_instance)
+from .env import BatchedJssEnv, CpuBackend, HipBackend, JssEnv, make, make_backend  # noqa: F401
 from .bucketed import BucketedJssEnv  # noqa: F401
 from .vector import JssVectorEnv  # noqa: F401
 
