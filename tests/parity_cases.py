@@ -722,3 +722,35 @@ def case_file_round_trips(backend, tmpdir, seed=12):
         raise AssertionError("a checkpoint of another batch must be rejected")
     except ValueError:
         pass
+
+
+def case_hip_equals_twin_full_size(hip_backend, configs=None):
+    """EVERY env of the BASELINE-sized batches: the HIP path against the host-core twin (libjss_cpu.so, itself held
+    to the oracle by tests/test_cpu_twin.py) after the same fused rollout -- all integer tensors bit-equal, the
+    float32 observation and reward bit-equal too (both sides evaluate the same fma sequence)."""
+    from jssenv_amd.env import CpuBackend
+    cpu = CpuBackend()
+    configs = configs or [
+        ("config 2: ta01 x 4096, random", dict(instances="ta01", batch=4096), "random", 300),
+        ("config 3: ta41 x 16384, SPT", dict(instances="ta41", batch=16384), "SPT", 700),
+        ("config 4: synthetic 50x20 x 8192, random", dict(instances=I.synthetic_packed(8192, 50, 20)), "random", 400),
+        ("config 5: mixed ta01-80 x 32768, random", dict(instances=[I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=32768), "random", 300),
+        ("headline: ta01 x 65536, random", dict(instances="ta01", batch=65536), "random", 260),
+    ]
+    for what, kw, policy, n_iter in configs:
+        a = BatchedJssEnv(seed=5, env_id_base=123, _backend=hip_backend, **kw)
+        b = BatchedJssEnv(seed=5, env_id_base=123, _backend=cpu, **kw)
+        a.reset()
+        b.reset()
+        a.rollout(policy, n_iter=n_iter)                 # one launch, state in registers
+        a.rollout_steps(policy, steps=8, n_sub=3)        # + the benchmarked step-per-launch form
+        b.rollout(policy, n_iter=n_iter + 8)
+        a.synchronize()
+        for name in BatchedJssEnv._STATE_TENSORS:
+            x, y = a.backend.numpy(getattr(a, name)), b.backend.numpy(getattr(b, name))
+            if x.dtype.kind == "f":
+                same = (x.view(np.int32) == y.view(np.int32))
+            else:
+                same = (x == y)
+            assert same.all(), f"{what}: {name} differs from the twin in {int((~same).sum())} of {same.size} elements"
+        assert a.stats()["steps"] > 0 and a.stats() == b.stats(), what

@@ -218,3 +218,8 @@ def test_nope_fuzz_tiny_instances(hip):
 def test_checkpoint_file_resume(hip, tmp_path):
     """N3 on the GPU: packed batch file -> env, checkpoint FILE -> bit-exact resume."""
     P.case_file_round_trips(hip, tmp_path)
+
+
+def test_every_env_at_full_size_equals_the_cpu_twin(hip):
+    """Configs 2-5 and the headline batch, every env, every tensor, bit for bit against libjss_cpu.so."""
+    P.case_hip_equals_twin_full_size(hip)
