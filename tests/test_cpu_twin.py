@@ -149,3 +149,25 @@ def test_critical_ratio_custom_due_date_factor(cpu):
         assert res[1.5] == 1426 and res[0.5] != 1426      # G3 value for the default; another schedule otherwise
     finally:
         np.random.random = real
+
+
+def test_config2_every_env_against_the_oracle(cpu):
+    """BASELINE config 2 at full size (ta01 x 4096, random masked, auto-restart): EVERY env of the twin's batch against
+    its own oracle run -- the link between the oracle and the GPU suite's `every env bit-equal to the twin` test."""
+    from jssenv_amd import BatchedJssEnv, builtin_instance
+    from oracle import OracleEnv
+    inst = builtin_instance("ta01")
+    B, seed, iters = 4096, 5, 300
+    env = BatchedJssEnv(inst, batch=B, seed=seed, env_id_base=123, _backend=cpu)
+    env.reset()
+    env.rollout("random", n_iter=iters)
+    clock, cnt, sol = env.env_header[:, 0], env.counters, env.solution
+    todo = env.todo_time_step_job
+    orc = OracleEnv(inst, strict=True)
+    for i in range(B):
+        orc.reset()
+        r = orc.rollout("random", seed, 123 + i, iters, episode=1)
+        assert orc.current_time_step == clock[i] and (orc.todo_time_step_job == todo[i]).all(), i
+        assert (orc.solution == sol[i]).all(), i
+        assert (cnt[i, 0], cnt[i, 1], cnt[i, 2]) == (r["steps"], r["episodes"], r["makespan_sum"]), i
+    P.assert_matches_oracle(env.host_state(B - 1), orc, "last env")
