@@ -710,7 +710,8 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G, TA
 #define JSS_PACKED_GLOBAL_MIN_BLOCKS 7
 #endif
 template <int G, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, MODE == kRollout ? 5 : ((TAB == kTabGlobal && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
+__global__ __launch_bounds__(kBlock, MODE == kRollout ? (TAB == kTabGlobal ? 4 : 5)
+                                                    : ((TAB == kTabGlobal && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
 void jss_packed_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     constexpr int E = kWave / G;                      // envs per wave

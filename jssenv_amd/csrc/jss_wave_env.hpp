@@ -649,13 +649,13 @@ __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const
 // Occupancy bound: 8 waves per SIMD keeps 8 192 envs (BASELINE config 4's share of one GPU) in ONE round of resident
 // waves; the price is an SGPR budget of 80, which the step/rollout modes overrun by 30-60 values that live in spare
 // VGPR lanes (v_writelane / v_readlane, no scratch).  JSS_WAVE_MIN_BLOCKS = 7 lifts the budget to 102 (A/B builds).
-// Two jobs per lane (J > 64) runs at 7 (6 for the multi-iteration rollout): at 8 it would spill VGPRs to scratch.
+// Two jobs per lane (J > 64) runs at 7 (5 for the multi-iteration rollout): more would spill VGPRs to scratch.
 #ifndef JSS_WAVE_MIN_BLOCKS
 #define JSS_WAVE_MIN_BLOCKS 8
 #endif
 template <int JPL, int MODE, int TAB>
 __global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE == kRollout1)
-                                         ? (JPL == 2 ? (MODE == kRollout ? 6 : 7) : JSS_WAVE_MIN_BLOCKS)
+                                         ? (JPL == 2 ? (MODE == kRollout ? 5 : 7) : JSS_WAVE_MIN_BLOCKS)
                                          : 8) void jss_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     const int lane = threadIdx.x & (kWave - 1);
