@@ -112,10 +112,12 @@ extern "C" {
 /* per-env error bits (low byte of the header's status word, sticky until reset) */
 #define JSS_ERR_ILLEGAL_ACTION 1 /* job action outside the mask: ignored (reference: silent corruption) */
 #define JSS_ERR_NOPE_IDLE 2      /* NOPE/advance with no busy machine (reference: IndexError, jss_env.py:517) */
-#define JSS_ERR_BAD_ACTION 4     /* action < -1 or > J: ignored (reference: IndexError) */
+#define JSS_ERR_BAD_ACTION 4     /* action < -2 or > J: ignored (reference: IndexError) */
 
 #define JSS_ACTION_SKIP (-1) /* batched step: this env is not stepped; its state, reward, done and makespan
                                 are left as they were (observation and mask are rewritten unchanged) */
+#define JSS_ACTION_RESET (-2) /* batched step: this env is reset() instead of stepped (reward 0, done 0, episode + 1):
+                                 gymnasium.vector "next-step" auto-reset in the same launch as the other envs' steps */
 
 /* policies */
 #define JSS_POLICY_RANDOM 0
@@ -187,7 +189,7 @@ const char *jss_backend(void);
 /* reset every env (which == NULL) or the envs with which[i] != 0 */
 int jss_reset(const JssDesc *desc, const JssState *state, const JssOut *out, const uint8_t *which, void *stream);
 
-/* one step() per env; actions[i] in [0, J] or JSS_ACTION_SKIP */
+/* one step() per env; actions[i] in [0, J], JSS_ACTION_SKIP or JSS_ACTION_RESET */
 int jss_step(const JssDesc *desc, const JssState *state, const int32_t *actions, const JssOut *out, void *stream);
 
 /* one increase_time_step() per env with which[i] != 0 (NULL = all); hole[i] = returned idle time (may be NULL) */

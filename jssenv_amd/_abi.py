@@ -19,7 +19,7 @@ F4_ONE = -1
 I_JOBS, I_MACHINES, I_MAX_TIME_OP, I_MAX_TIME_JOBS, I_SUM_OP = 0, 1, 2, 3, 4
 I_RCP_MAX_TIME_OP, I_RCP_MAX_TIME_JOBS, I_RCP_SUM_OP, I_RCP_MACHINES, NI = 5, 6, 7, 8, 12
 ERR_ILLEGAL_ACTION, ERR_NOPE_IDLE, ERR_BAD_ACTION = 1, 2, 4
-ACTION_SKIP = -1
+ACTION_SKIP, ACTION_RESET = -1, -2
 POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6, "CR": 7}
 ROLLOUT_AUTORESET = 1
 KERNEL = {"auto": 0, "wave": 1}

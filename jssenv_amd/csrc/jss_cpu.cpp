@@ -415,6 +415,15 @@ void run_env(const Call &c, int mode, int b) {
     case kStep: {
         const int a = c.actions[b];
         if (a == JSS_ACTION_SKIP) break;                                  // untouched: reward / done / makespan stay
+        if (a == JSS_ACTION_RESET) {                                      // reset() instead of a step
+            const int episode = e.hdr[JSS_H_EPISODE];
+            reset_env(e);
+            e.hdr[JSS_H_EPISODE] = episode + 1;
+            e.hdr[JSS_H_STEP] = 0;
+            c.o.reward[b] = 0.f;
+            c.o.done[b] = 0;
+            break;
+        }
         const int rn = step_env(e, a);
         const bool done = n_legal(e) == 0;                                // :639-653
         e.hdr[JSS_H_STEP] += 1;

@@ -411,7 +411,7 @@ template <int G, int TAB>
 __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, int a, int32_t *mvtab) {
     const bool is_nope = c.alive && a == c.J;                            // :419
     const bool is_job = c.alive && a >= 0 && a < c.J;
-    if (c.alive && (a < JSS_ACTION_SKIP || a > c.J)) e.err |= JSS_ERR_BAD_ACTION;
+    if (c.alive && (a < JSS_ACTION_RESET || a > c.J)) e.err |= JSS_ERR_BAD_ACTION;   // SKIP / RESET never reach a job or NOPE branch
     const bool mine = c.gl == a;
     const bool a_legal = grp_any<G>(mine && e.legal, c.gbase);
     if (is_job && !a_legal) e.err |= JSS_ERR_ILLEGAL_ACTION;             // outside the mask: ignored + flagged
@@ -634,8 +634,18 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G, TA
             }
         }
     } else if (MODE == kStep) {
+        const bool restart = c.alive && a_in == JSS_ACTION_RESET;       // reset() this env instead of stepping it
+        p_reset(e, c, p, restart);
+        if (restart) {
+            hd.episode += 1;
+            hd.step = 0;
+            if (c.gl == 0) {
+                st_off<float>(p.o.reward + fe, c.rel * 4u, 0.f);
+                st_off<uint8_t>(p.o.done + fe, c.rel, 0);
+            }
+        }
         const int rn = p_step(e, c, p, a_in, mvtab);
-        const bool called = a_in != JSS_ACTION_SKIP;
+        const bool called = a_in != JSS_ACTION_SKIP && !restart;
         const bool done = !grp_any<G>(e.legal, c.gbase);
         if (called) hd.step += 1;
         if (c.alive && c.gl == 0 && called) {         // a skipped env keeps its reward / done / makespan

@@ -380,7 +380,7 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
 // ---------------------------------------------------------------------------------------
 template <int JPL>
 __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params &p, int a) {
-    if (a == JSS_ACTION_SKIP) return 0;
+    if (a == JSS_ACTION_SKIP || a == JSS_ACTION_RESET) return 0;         // RESET is handled by the caller
     if (a < 0 || a > c.J) {
         e.err |= JSS_ERR_BAD_ACTION;
         return 0;
@@ -707,8 +707,18 @@ __global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE 
             p.o.done[b] = 0;
         }
     } else if (MODE == kStep) {
+        const bool restart = a_in == JSS_ACTION_RESET;                   // reset() this env instead of stepping it
+        if (restart) {
+            hd.episode += 1;
+            hd.step = 0;
+            reset_env(e, c, p);
+            if (lane == 0) {
+                p.o.reward[b] = 0.f;
+                p.o.done[b] = 0;
+            }
+        }
         const int rn = step_env(e, c, p, a_in);
-        const bool called = a_in != JSS_ACTION_SKIP;
+        const bool called = a_in != JSS_ACTION_SKIP && !restart;
         const bool done = !any_legal(e);
         if (called) hd.step += 1;
         if (lane == 0 && called) {                                       // a skipped env keeps its reward / done / makespan

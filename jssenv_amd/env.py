@@ -285,7 +285,6 @@ class BatchedJssEnv:
             self._actions_out = be.zeros((B,), "int32")
             self._hole = be.zeros((B,), "int32")
             self._act_buf = be.zeros((B,), "int32")
-            self._was_done = be.zeros((B,), "uint8")
             self._was_done_mask = be.zeros((B,), "bool")
 
         p = be.ptr
@@ -366,7 +365,7 @@ class BatchedJssEnv:
         Returns (obs, reward (B,) float32, done (B,) uint8, truncated=False, info={}).
         autoreset=True gives gymnasium.vector "next-step" semantics: an env that reported done on the
         previous call is reset by this call instead of being stepped (its action is ignored, reward 0,
-        done 0) -- one extra masked jss_reset launch, no host synchronisation."""
+        done 0) -- same launch (action code JSS_ACTION_RESET), no host synchronisation."""
         if not self._is_reset:
             raise RuntimeError("call reset() before step()")
         be = self.backend
@@ -375,13 +374,10 @@ class BatchedJssEnv:
             a = be.as_device(actions, "int32")
             if tuple(a.shape) != (self.batch,):
                 raise ValueError("actions must have shape (B,)")
-            if autoreset:
-                be.copy_into(self._was_done, self.done)
-                be.select_into(self._act_buf, self._was_done, -1, a, self._was_done_mask)
+            if autoreset:      # envs that reported done last time get JSS_ACTION_RESET: reset in the same launch
+                be.select_into(self._act_buf, self.done, _abi.ACTION_RESET, a, self._was_done_mask)
                 a = self._act_buf
             _abi.check(be.lib, be.lib.jss_step(d, s, be.ptr(a), o, be.stream()), "jss_step")
-            if autoreset:
-                _abi.check(be.lib, be.lib.jss_reset(d, s, o, be.ptr(self._was_done), be.stream()), "jss_reset")
         return self._obs(), self.reward, self.done, False, {}
 
     def increase_time_step(self, which=None):
