@@ -30,7 +30,6 @@ import argparse
 import json
 import os
 import socket
-import statistics
 import sys
 import time
 

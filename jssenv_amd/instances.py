@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import os
 from dataclasses import dataclass
-from typing import Iterable, List, Sequence, Union
+from typing import List, Sequence, Union
 
 import numpy as np
 

@@ -11,11 +11,10 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from jssenv_amd import BatchedJssEnv, _abi  # noqa: E402
+from jssenv_amd import BatchedJssEnv  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 inst = sys.argv[2] if len(sys.argv) > 2 else "ta01"
-import ctypes  # noqa: E402
 PROF_ABLATE = 1
 if inst == "synthetic50x20":
     from jssenv_amd.instances import synthetic_packed
