@@ -6,9 +6,13 @@
 //   * wave flavour (jss_wave_env.hpp): one 64-lane wavefront simulates one env; job j sits on
 //     lane j%64 (slot j/64, JPL = 1 or 2 slots), machine m on lane m.  Packed flavour
 //     (jss_packed_env.hpp): 64/G envs per wavefront, G = 16 or 32 lanes per env.
-//   * the env's whole state lives in registers for the duration of the call: 8 int32 per job
-//     (the seventh-plus-one being the job's NEXT op, so that a step touches the op table only
-//     when a job moves on to a new op or a look-ahead walk goes further than two ops).
+//   * the env's whole state lives in registers for the duration of the call: 8 int32 per job,
+//     which include the job's next THREE ops (current, next, and the one after it in the spare
+//     bits of word 0), so that a step touches the op table only when a job moves on to a new op
+//     or a look-ahead walk goes further than three ops.
+//   * step()'s `while nothing is legal: increase_time_step()` loops are one closed-form jump to
+//     the first time a job becomes legal (p_jump / jump); unchanged halves of a job record and
+//     unchanged machine clocks are not written back; the observation leaves with streaming stores.
 //   * the op table (machine << 16 | duration) of a batch that shares ONE instance is staged in
 //     LDS once per workgroup (kTabLds); batches with one instance per env or an env -> instance
 //     map read the few entries they need straight from global memory (kTabGlobal): staging a
