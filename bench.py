@@ -316,14 +316,15 @@ def main():
         if args.launch != "auto":
             return args.launch
         probe = []
+        n_probe = max(20, min(60, args.steps))      # probe at the window length that will be timed (pipelines ramp up and drain)
         for m in candidates:
-            g = capture(env, policy, 60) if m == "graph" else None
-            window(env, policy, 60, 1, m, g)                                   # warm (streams, graph upload)
-            probe.append(min(window(env, policy, 60, 1, m, g)[0] for _ in range(4)))
+            g = capture(env, policy, n_probe) if m == "graph" else None
+            window(env, policy, n_probe, 1, m, g)                              # warm (streams, graph upload)
+            probe.append(min(window(env, policy, n_probe, 1, m, g)[0] for _ in range(5)))
             del g
         probe = agree_max(probe)
         if rank == 0:
-            print("launch-mode probe (s per 60 steps): " + ", ".join(f"{m} {t:.6f}" for m, t in zip(candidates, probe)), file=sys.stderr)
+            print(f"launch-mode probe (s per {n_probe} steps): " + ", ".join(f"{m} {t:.6f}" for m, t in zip(candidates, probe)), file=sys.stderr)
         return candidates[probe.index(min(probe))]
 
     def measure(env, policy, steps, mode, n_iter=1, windows=N_WINDOWS):
