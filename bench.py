@@ -451,6 +451,33 @@ def main():
         medf, _ = measure(env, args.policy, n_l, "eager", n_iter=64, windows=3)
         out["fused_rollout"] = {"value": medf["rate"], "unit": "env steps/s", "iterations_per_launch": 64, "launches": n_l,
                                 "note": "policy+step x64 per launch, observation written once per launch"}
+    if not args.no_extras and world == 1 and not hasattr(env, "buckets"):
+        # the path an RL trainer with its own policy network uses: jss_policy (stand-in for the network) then
+        # jss_step(actions) with next-step auto-reset -- two launches + the action select per env step, hipGraph replay
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        g2 = torch.cuda.CUDAGraph()
+        n2 = max(20, min(100, args.steps))
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g2, stream=side):
+                for _ in range(n2):
+                    env.step(env.policy(args.policy), autoreset=True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g2.replay()
+        torch.cuda.synchronize()
+        rates = []
+        for _ in range(3):
+            env.zero_counters()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g2.replay()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            rates.append(float(env.counter_totals()[0].item()) / dt2)
+        del g2
+        out["policy_then_step_two_launches"] = {"value": sorted(rates)[1], "unit": "env steps/s", "iterations": n2,
+                                                "note": "jss_policy + jss_step(autoreset) per env step (separate launches, "
+                                                        "actions through HBM), hipGraph replay; median of 3"}
     if not args.no_extras and world == 1 and args.workload == "shared" and args.scaling == "weak":
         if hasattr(env, "close"):
             env.close()

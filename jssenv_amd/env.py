@@ -53,6 +53,7 @@ class HipBackend:
         self.lib = _abi.bind(C.CDLL(path))
         if not self.lib.jss_backend().startswith(b"hip"):
             raise RuntimeError(f"{path} is not the HIP library ({self.lib.jss_backend()!r})")
+        self._scalars = {}
 
     # -- memory ----------------------------------------------------------------------------
     def zeros(self, shape, dtype):
@@ -76,11 +77,20 @@ class HipBackend:
             src = self.torch.from_numpy(np.ascontiguousarray(src))
         dst.copy_(src)
 
-    def select_into(self, out, flags, a, b, scratch):
-        """out[...] = where(flags != 0, a (scalar), b) without allocating: `scratch` is a preallocated bool tensor."""
-        scratch.copy_(flags)                      # uint8 -> bool conversion in place
-        out.copy_(b)
-        out.masked_fill_(scratch, a)
+    def select_into(self, out, flags, a, b):
+        """out[...] = where(flags != 0, a (scalar), b): one elementwise kernel, nothing allocated (`flags` is a uint8
+        tensor holding 0 / 1, reinterpreted as bool)."""
+        self.torch.where(flags.view(self.torch.bool), self.scalar(a, out.dtype), b, out=out)
+
+    def scalar(self, value, dtype):
+        """Cached 0-dim device tensor (created outside any stream capture: BatchedJssEnv makes the ones it needs
+        when it is constructed)."""
+        key = (int(value), str(dtype))
+        if key not in self._scalars:
+            dt = getattr(self.torch, dtype) if isinstance(dtype, str) else dtype
+            self._scalars[key] = self.torch.tensor(int(value), dtype=dt, device=self.device)
+            self._scalars[(int(value), str(dt))] = self._scalars[key]
+        return self._scalars[key]
 
     # -- execution -------------------------------------------------------------------------
     def stream(self):
@@ -187,7 +197,7 @@ class CpuBackend:
     def copy_into(self, dst, src):
         dst[...] = src
 
-    def select_into(self, out, flags, a, b, scratch):
+    def select_into(self, out, flags, a, b):
         np.copyto(out, b)
         out[flags != 0] = a
 
@@ -285,7 +295,8 @@ class BatchedJssEnv:
             self._actions_out = be.zeros((B,), "int32")
             self._hole = be.zeros((B,), "int32")
             self._act_buf = be.zeros((B,), "int32")
-            self._was_done_mask = be.zeros((B,), "bool")
+            if hasattr(be, "scalar"):
+                be.scalar(_abi.ACTION_RESET, "int32")
 
         p = be.ptr
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._rem), p(self._inst), p(self._table_of_env), None,
@@ -375,7 +386,7 @@ class BatchedJssEnv:
             if tuple(a.shape) != (self.batch,):
                 raise ValueError("actions must have shape (B,)")
             if autoreset:      # envs that reported done last time get JSS_ACTION_RESET: reset in the same launch
-                be.select_into(self._act_buf, self.done, _abi.ACTION_RESET, a, self._was_done_mask)
+                be.select_into(self._act_buf, self.done, _abi.ACTION_RESET, a)
                 a = self._act_buf
             _abi.check(be.lib, be.lib.jss_step(d, s, be.ptr(a), o, be.stream()), "jss_step")
         return self._obs(), self.reward, self.done, False, {}

@@ -66,7 +66,7 @@ class EmuBackend:
         self._keep = [a]
         return a
 
-    def select_into(self, out, flags, a, b, scratch):
+    def select_into(self, out, flags, a, b):
         np.copyto(out, b)
         out[flags != 0] = a
 
