@@ -496,9 +496,12 @@ def main():
                                                             bucketed=True)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "shared":
-        out["cpu_baseline"] = cpu_baseline_port(args.instance, args.seed)
-        out["cpu_baseline_twin"] = cpu_baseline_twin(args.instance, args.seed)
-        out["cpu_baseline"]["host"] = out["cpu_baseline_twin"]["host"] = host_cores()
+        for name, fn in (("cpu_baseline", cpu_baseline_port), ("cpu_baseline_twin", cpu_baseline_twin)):
+            try:     # a host-side hiccup (no compiler for a stale checker build, ...) must not cost the GPU measurement
+                out[name] = fn(args.instance, args.seed)
+                out[name]["host"] = host_cores()
+            except Exception as exc:
+                out[name] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
     elif rank == 0:
         out["cpu_baseline"] = None
 
