@@ -483,17 +483,25 @@ def main():
             env.close()
         del env
         env = None
-        out["batch_x4"] = side_run("shared", 4 * B, args.policy, label_extra=" -- 4x the batch: 420 MB working set, beyond the Infinity Cache",
-                                   instance=args.instance, modes=("eager", "sub2", "sub3"))
-        out["synthetic15x15_per_env_tables"] = side_run("synthetic15x15", B, args.policy)
-        out["config2_ta01_batch4096_random"] = side_run("shared", 4096, "random", modes=("eager", "graph"))
-        out["config3_ta41_spt_batch16384"] = side_run("shared", 16384, "SPT", instance="ta41")
-        out["config4_synthetic50x20_batch8192"] = side_run("synthetic50x20", 8192, "random")
-        out["config4_synthetic50x20_batch65536_one_gpu"] = side_run("synthetic50x20", 65536, "random",
-                                                                    label_extra=" -- all of config 4 on one GPU")
-        out["config5_mixed_padded_batch32768"] = side_run("mixed", 32768, "random", label_extra=", padded 100x20")
-        out["config5_mixed_bucketed_batch32768"] = side_run("mixed", 32768, "random", label_extra=", shape-bucketed (no padding)",
-                                                            bucketed=True)
+        extras = [
+            ("batch_x4", dict(workload="shared", batch=4 * B, policy=args.policy, instance=args.instance, modes=("eager", "sub2", "sub3"),
+                              label_extra=" -- 4x the batch: 420 MB working set, beyond the Infinity Cache")),
+            ("synthetic15x15_per_env_tables", dict(workload="synthetic15x15", batch=B, policy=args.policy)),
+            ("config2_ta01_batch4096_random", dict(workload="shared", batch=4096, policy="random", modes=("eager", "graph"))),
+            ("config3_ta41_spt_batch16384", dict(workload="shared", batch=16384, policy="SPT", instance="ta41")),
+            ("config4_synthetic50x20_batch8192", dict(workload="synthetic50x20", batch=8192, policy="random")),
+            ("config4_synthetic50x20_batch65536_one_gpu", dict(workload="synthetic50x20", batch=65536, policy="random",
+                                                               label_extra=" -- all of config 4 on one GPU")),
+            ("config5_mixed_padded_batch32768", dict(workload="mixed", batch=32768, policy="random", label_extra=", padded 100x20")),
+            ("config5_mixed_bucketed_batch32768", dict(workload="mixed", batch=32768, policy="random", bucketed=True,
+                                                       label_extra=", shape-bucketed (no padding)")),
+        ]
+        for name, kw in extras:
+            try:     # an extra that fails (memory on a busy box, ...) is reported, it does not cost the headline
+                out[name] = side_run(kw.pop("workload"), kw.pop("batch"), kw.pop("policy"), **kw)
+            except Exception as exc:
+                out[name] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+                torch.cuda.synchronize()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "shared":
         for name, fn in (("cpu_baseline", cpu_baseline_port), ("cpu_baseline_twin", cpu_baseline_twin)):
