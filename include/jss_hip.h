@@ -23,6 +23,11 @@
  *   jss_rollout  <- DispatchingRule.run_episode's loop    dispatching.py:55-75
  *                   (policy + step fused, n iterations per launch, optional
  *                    auto-restart of finished episodes)
+ *   jss_trajectory <- the same loop with EVERY step's transition written out, step-major:
+ *                   what the policy saw (observation, mask), the action it took, the
+ *                   reward and done flag it got -- the (s, a, r, d) stream a behaviour
+ *                   policy (random, a dispatching rule) collects for a learner, K steps
+ *                   per launch with the env state held in registers in between
  *   jss_rollout_steps <- the same loop issued as n_sub independent sub-batches on
  *                   n_sub streams, so that consecutive steps of different sub-batches
  *                   overlap on the device (env instances are independent)
@@ -46,7 +51,8 @@
  *                                                float32 reciprocals
  *   job state     int32 [B][jmax][JSS_NF]        one 32-byte record per job (JSS_F_* words below):
  *                                                a lane moves its job with two dwordx4 accesses
- *   env header    int32 [B][4]                   JSS_H_*: clock, episode, step, status
+ *   env header    int32 [B][JSS_NH]              JSS_H_*: clock, episode, step, status + the instance constants
+ *                                                of the env (copied in by reset): one 64-byte line per env
  *   machine state int32 [B][mmax]                time_until_available_machine
  *   action_mask   uint8 [B][jmax + 1]            legal_actions (output; rebuilt from the flag bits
  *                                                every call); NOPE flag at index J(env), zeros after it
@@ -62,7 +68,7 @@
 extern "C" {
 #endif
 
-#define JSS_ABI_VERSION 5
+#define JSS_ABI_VERSION 6
 
 #define JSS_MAX_JOBS 128
 #define JSS_MAX_MACHINES 64
@@ -90,11 +96,25 @@ extern "C" {
 #define JSS_FLAG_BLOCKED 512
 #define JSS_NEXT2_SHIFT 10
 
-/* words of the per-env header */
+/* words of the per-env header: 64 bytes, one cache line per env.  Words 4-13 are a copy of the env's instance
+ * record (and its index) written by every reset of the env: a step-type call gets everything it needs to know about
+ * its env from this one line, in the same memory round trip as the state -- no env -> instance -> J/M chain of
+ * dependent loads in front of the job records, no second fetch of the observation's normalisers behind them. */
 #define JSS_H_CLOCK 0    /* current_time_step                                     */
 #define JSS_H_EPISODE 1  /* episodes started (RNG key)                            */
 #define JSS_H_STEP 2     /* env steps since reset (RNG key)                       */
 #define JSS_H_STATUS 3   /* bits 0-7 JSS_ERR_*, bit 8 legal_actions[J] (NOPE)     */
+#define JSS_H_JOBS 4           /* J of the env's instance (0 = the env was never reset: step-type calls leave it alone) */
+#define JSS_H_MACHINES 5       /* M                                               */
+#define JSS_H_MAX_TIME_OP 6    /* jss_env.py:86                                   */
+#define JSS_H_TABLE 7          /* index of the env's instance in ops / rem / inst */
+#define JSS_H_MAX_TIME_JOBS 8  /* jss_env.py:89                                   */
+#define JSS_H_SUM_OP 9         /* jss_env.py:88                                   */
+#define JSS_H_RCP_MAX_TIME_OP 10   /* float32 bits, as JSS_I_RCP_*                */
+#define JSS_H_RCP_MAX_TIME_JOBS 11
+#define JSS_H_RCP_SUM_OP 12
+#define JSS_H_RCP_MACHINES 13
+#define JSS_NH 16              /* header stride in ints (words 14, 15 are 0)      */
 #define JSS_STATUS_NOOP 256
 
 /* words of the per-instance record */
@@ -165,7 +185,7 @@ typedef struct JssDesc {
 } JssDesc;
 
 typedef struct JssState {
-    int32_t *env;      /* [B][4]  JSS_H_*                                              */
+    int32_t *env;      /* [B][JSS_NH]  JSS_H_*                                         */
     int32_t *job;      /* [B][jmax][JSS_NF]                                            */
     int32_t *machine;  /* [B][mmax]                                                    */
     int32_t *solution; /* [B][jmax][mmax]                                              */
@@ -180,6 +200,18 @@ typedef struct JssOut {
     uint8_t *done;        /* [B] nb_legal_actions == 0 (jss_env.py:639-653)               */
     int32_t *makespan;    /* [B] clock at the last done transition (last_time_step, :650) */
 } JssOut;
+
+/* Per-step record of jss_trajectory, step-major (slot k of env i at [k][i]).  Any pointer may be NULL: that stream
+ * is not recorded. */
+typedef struct JssTraj {
+    float *real_obs;      /* [K][B][jmax][7]  the observation the policy saw in slot k.  Rows J(env)..jmax-1 are never
+                             written: allocate the buffer zero-filled                                                */
+    uint8_t *action_mask; /* [K][B][jmax+1]   the mask the policy saw (whole row written, zeros behind the NOPE flag) */
+    int32_t *action;      /* [K][B]  the action taken: job, J = NOPE; JSS_ACTION_RESET = the env was found done and was
+                             reset instead of stepped (JSS_ROLLOUT_AUTORESET); JSS_ACTION_SKIP = found done, left frozen */
+    float *reward;        /* [K][B]  reward of that step (0 in RESET / SKIP slots)   */
+    uint8_t *done;        /* [K][B]  done after that step                            */
+} JssTraj;
 
 int jss_abi_version(void);
 const char *jss_error_string(int code);
@@ -204,6 +236,18 @@ int jss_policy(const JssDesc *desc, const JssState *state, int kind, uint64_t se
 /* n_iter x (policy + step) per env inside one launch, state held in registers */
 int jss_rollout(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
                 uint32_t explore_q16, int32_t n_iter, int32_t flags, void *stream);
+
+/* jss_rollout(n_iter = n_steps) that also records every iteration in `traj` (slot k = iteration k): state, `out`
+ * and the counters end up exactly as after jss_rollout with the same arguments; an iteration that finds its env done
+ * records JSS_ACTION_RESET (auto-reset: gymnasium.vector "next-step" semantics, the slot after it holds the fresh
+ * episode's first observation) or JSS_ACTION_SKIP, reward 0.  State is read and written once per call. */
+int jss_trajectory(const JssDesc *desc, const JssState *state, const JssOut *out, const JssTraj *traj, int kind,
+                   uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, void *stream);
+
+/* Debug aid: waits for everything queued on `stream` and returns the first asynchronous error (0 = none).  The
+ * launching calls above only report what the launch itself reports; a fault inside a kernel surfaces here.  The
+ * only call of the library that blocks. */
+int jss_sync_check(void *stream);
 
 /* n_steps x jss_rollout(n_iter = 1) over the whole batch, issued as n_sub contiguous sub-batches (boundaries at
  * multiples of 64 envs): step s of sub-batch i is launched on streams[i] and depends only on step s - 1 of the same

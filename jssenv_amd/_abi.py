@@ -9,11 +9,13 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_JOBS, MAX_MACHINES = 128, 64
 F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_NEXT, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
 TODO_MASK, FLAG_LEGAL, FLAG_BLOCKED, NEXT2_SHIFT = 255, 256, 512, 10
 H_CLOCK, H_EPISODE, H_STEP, H_STATUS = 0, 1, 2, 3
+H_JOBS, H_MACHINES, H_MAX_TIME_OP, H_TABLE = 4, 5, 6, 7
+H_MAX_TIME_JOBS, H_SUM_OP, H_RCP_MAX_TIME_OP, H_RCP_MAX_TIME_JOBS, H_RCP_SUM_OP, H_RCP_MACHINES, NH = 8, 9, 10, 11, 12, 13, 16
 STATUS_NOOP = 256
 F4_ONE = -1
 I_JOBS, I_MACHINES, I_MAX_TIME_OP, I_MAX_TIME_JOBS, I_SUM_OP = 0, 1, 2, 3, 4
@@ -27,7 +29,7 @@ E_NULL, E_SHAPE, E_KIND, E_LDS = -1, -2, -3, -4
 MAX_SUB_BATCHES = 16
 
 SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_backend", "jss_reset", "jss_step", "jss_advance", "jss_policy",
-           "jss_rollout", "jss_rollout_steps")
+           "jss_rollout", "jss_rollout_steps", "jss_trajectory", "jss_sync_check")
 
 _p = C.c_void_p
 
@@ -45,6 +47,10 @@ class JssState(C.Structure):
 
 class JssOut(C.Structure):
     _fields_ = [("real_obs", _p), ("action_mask", _p), ("reward", _p), ("done", _p), ("makespan", _p)]
+
+
+class JssTraj(C.Structure):
+    _fields_ = [("real_obs", _p), ("action_mask", _p), ("action", _p), ("reward", _p), ("done", _p)]
 
 
 def library_path(name: str = "libjss_hip.so") -> str:
@@ -72,6 +78,9 @@ def bind(lib):
     lib.jss_rollout_steps.restype = C.c_int
     lib.jss_rollout_steps.argtypes = [D, S, O, C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(_p)]
+    lib.jss_trajectory.restype = C.c_int
+    lib.jss_trajectory.argtypes = [D, S, O, C.POINTER(JssTraj), C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, _p]
+    lib.jss_sync_check.restype, lib.jss_sync_check.argtypes = C.c_int, [_p]
     if lib.jss_abi_version() != ABI_VERSION:
         raise RuntimeError(f"library ABI {lib.jss_abi_version()} != expected {ABI_VERSION}")
     return lib

@@ -6,6 +6,9 @@
 //   * wave flavour (jss_wave_env.hpp): one 64-lane wavefront simulates one env; job j sits on
 //     lane j%64 (slot j/64, JPL = 1 or 2 slots), machine m on lane m.  Packed flavour
 //     (jss_packed_env.hpp): 64/G envs per wavefront, G = 16 or 32 lanes per env.
+//   * everything a step needs to know about its env sits in the env's 64-byte header (clock, J, M, the
+//     observation's normalisers, the op table index: written by reset): no env -> instance -> shape chain
+//     of dependent loads in front of the state, no second fetch behind it.
 //   * the env's whole state lives in registers for the duration of the call: 8 int32 per job,
 //     which include the job's next THREE ops (current, next, and the one after it in the spare
 //     bits of word 0), so that a step touches the op table only when a job moves on to a new op
@@ -46,7 +49,8 @@ constexpr int kDurMask = 0xffff;
 
 // kRollout1 = kRollout with n_iter == 1 compiled loop-free (fewer live registers: the benchmarked
 // one-launch-per-env-step path)
-enum Mode { kReset = 0, kStep = 1, kAdvance = 2, kPolicy = 3, kRollout = 4, kRollout1 = 5 };
+// kTraj = kRollout that also records every iteration's transition (JssTraj)
+enum Mode { kReset = 0, kStep = 1, kAdvance = 2, kPolicy = 3, kRollout = 4, kRollout1 = 5, kTraj = 6 };
 // where the op table lives: LDS (one instance shared by the batch) or global memory
 enum Tab { kTabLds = 0, kTabGlobal = 1 };
 
@@ -54,6 +58,7 @@ struct Params {
     JssDesc d;
     JssState s;
     JssOut o;
+    JssTraj t;               // kTraj
     const int32_t *actions;  // kStep
     int32_t *actions_out;    // kPolicy
     const uint8_t *which;    // kReset / kAdvance
@@ -67,6 +72,7 @@ struct Params {
     int32_t table_lds_ints;  // LDS ints reserved for the shared op table (0 with kTabGlobal), multiple of 4
     int32_t obs_wave_floats; // floats of one wave's observation image in LDS (multiple of 4)
     int32_t mv_off_ints;     // packed kernel: LDS offset (ints) of the per-lane max_horizon_machine table
+    int32_t norm_off_ints;   // packed kernel, kTabGlobal: LDS offset (ints) of the per-group observation normalisers
     int32_t ablate;          // JSS_PROFILING builds: JSS_PROF_ABLATE mask; 0 otherwise
 };
 
@@ -96,6 +102,11 @@ __device__ __forceinline__ float as_float(int bits) {
     union { int i; float f; } u;
     u.i = bits;
     return u.f;
+}
+__device__ __forceinline__ int as_int(float x) {
+    union { int i; float f; } u;
+    u.f = x;
+    return u.i;
 }
 
 #define JSS_DPP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xF, 0xF, false)

@@ -30,6 +30,7 @@ struct Call {   // one ABI call
     int32_t *actions_out = nullptr;
     const uint8_t *which = nullptr;
     int32_t *hole = nullptr;
+    JssTraj t = JssTraj();
     uint64_t seed = 0;
     uint32_t explore_q16 = 0;
     int kind = 0;
@@ -39,11 +40,11 @@ struct Call {   // one ABI call
 
 // One env: pointers into the batch tensors + its instance.
 struct Env {
-    int J, M, max_time_op;
-    const int32_t *inst;        // JSS_I_* record
+    int J, M, max_time_op, tid;
+    const int32_t *norm;        // the six observation normalisers: max_time_jobs, sum_op, four float32 reciprocals
     const int32_t *ops, *rem;   // [jmax][mmax] tables of my instance (rem may be null)
-    int stride;
-    int32_t *hdr;               // [4]
+    int stride, jmax, mmax;
+    int32_t *hdr;               // [JSS_NH]
     int32_t *job;               // [jmax][JSS_NF]
     int32_t *tm;                // [mmax]
     int32_t *sol;               // [jmax][mmax]
@@ -68,19 +69,32 @@ struct Env {
     void flag(int err) const { hdr[JSS_H_STATUS] |= err; }
 };
 
-Env env_of(const Call &c, int b) {
+// The env's view of the batch.  from_instance: a reset -- its shape and normalisers come from its instance record
+// (env -> table_of_env -> record) and are copied into its header; every other call reads them back from the header.
+Env env_of(const Call &c, int b, bool from_instance) {
     const JssDesc &d = c.d;
-    const int tid = d.table_of_env ? d.table_of_env[b] : (d.n_tables == 1 ? 0 : b);
     const size_t region = (size_t)d.jmax * d.mmax;
     Env e;
-    e.inst = d.inst + (size_t)tid * JSS_NI;
-    e.J = e.inst[JSS_I_JOBS];
-    e.M = e.inst[JSS_I_MACHINES];
-    e.max_time_op = e.inst[JSS_I_MAX_TIME_OP];
-    e.ops = d.ops + tid * region;
-    e.rem = d.rem ? d.rem + tid * region : nullptr;
+    e.hdr = c.s.env + (size_t)b * JSS_NH;
+    if (from_instance) {
+        e.tid = d.table_of_env ? d.table_of_env[b] : (d.n_tables == 1 ? 0 : b);
+        const int32_t *inst = d.inst + (size_t)e.tid * JSS_NI;
+        e.J = inst[JSS_I_JOBS];
+        e.M = inst[JSS_I_MACHINES];
+        e.max_time_op = inst[JSS_I_MAX_TIME_OP];
+        e.norm = inst + JSS_I_MAX_TIME_JOBS;
+    } else {
+        e.J = e.hdr[JSS_H_JOBS];
+        e.M = e.hdr[JSS_H_MACHINES];
+        e.max_time_op = e.hdr[JSS_H_MAX_TIME_OP];
+        e.tid = e.hdr[JSS_H_TABLE];
+        e.norm = e.hdr + JSS_H_MAX_TIME_JOBS;
+    }
+    e.ops = d.ops + e.tid * region;
+    e.rem = d.rem ? d.rem + e.tid * region : nullptr;
     e.stride = d.mmax;
-    e.hdr = c.s.env + (size_t)b * 4;
+    e.jmax = d.jmax;
+    e.mmax = d.mmax;
     e.job = c.s.job + (size_t)b * d.jmax * JSS_NF;
     e.tm = c.s.machine + (size_t)b * d.mmax;
     e.sol = c.s.solution + b * region;
@@ -103,16 +117,25 @@ bool any_busy(const Env &e) {
 void reset_env(const Env &e) {
     e.t() = 0;                                                            // :154
     e.hdr[JSS_H_STATUS] = 0;                                              // NOPE illegal (:161), error bits cleared
-    for (int m = 0; m < e.M; ++m) e.tm[m] = 0;                            // :164
-    for (int j = 0; j < e.J; ++j) {
-        e.w(j, JSS_F_TODO) = JSS_FLAG_LEGAL;                              // todo 0 (:166), legal (:160), not blocked (:171)
-        e.w(j, JSS_F_CUR) = e.ops[j * e.stride];                          // :174-176 needed machine = op 0
-        e.w(j, JSS_F_NEXT) = 1 < e.M ? e.ops[j * e.stride + 1] : -1;
-        e.set_next2(j, 2 < e.M ? e.ops[j * e.stride + 2] : -1);
+    // the instance constants travel with the env from here on (include/jss_hip.h JSS_H_*)
+    e.hdr[JSS_H_JOBS] = e.J;
+    e.hdr[JSS_H_MACHINES] = e.M;
+    e.hdr[JSS_H_MAX_TIME_OP] = e.max_time_op;
+    e.hdr[JSS_H_TABLE] = e.tid;
+    if (e.norm != e.hdr + JSS_H_MAX_TIME_JOBS)
+        for (int i = 0; i < 6; ++i) e.hdr[JSS_H_MAX_TIME_JOBS + i] = e.norm[i];
+    e.hdr[14] = e.hdr[15] = 0;
+    for (int m = 0; m < e.mmax; ++m) e.tm[m] = 0;                         // :164
+    for (int j = 0; j < e.jmax; ++j) {                                    // rows behind J: "no job" (todo 0, no op)
+        const bool v = j < e.J;
+        e.w(j, JSS_F_TODO) = v ? JSS_FLAG_LEGAL : 0;                      // todo 0 (:166), legal (:160), not blocked (:171)
+        e.w(j, JSS_F_CUR) = v ? e.ops[j * e.stride] : -1;                 // :174-176 needed machine = op 0
+        e.w(j, JSS_F_NEXT) = (v && 1 < e.M) ? e.ops[j * e.stride + 1] : -1;
+        e.set_next2(j, (v && 2 < e.M) ? e.ops[j * e.stride + 2] : -1);
         e.w(j, JSS_F_LEFT) = e.w(j, JSS_F_PERF) = e.w(j, JSS_F_IDLE) = e.w(j, JSS_F_IDLE_LAST) = 0;   // :165-170
         e.w(j, JSS_F_F4) = 0;                                             // :180
     }
-    for (int i = 0; i < e.J * e.stride; ++i) e.sol[i] = -1;               // :163
+    for (int i = 0; i < e.jmax * e.stride; ++i) e.sol[i] = -1;            // :163, the whole padded block
 }
 
 // ---- increase_time_step(): jss_env.py:495-637; caller guarantees a busy machine ------------------------------
@@ -361,28 +384,36 @@ float div_by(float a, float b, float rb) {
     return std::fmaf(std::fmaf(-q, b, a), rb, q);
 }
 
+// observation rows < J and the mask row of one env (padding: obs rows behind J are zeroed when `pad`)
+void write_obs_mask(const Env &e, int jm, float *obs, uint8_t *mk, bool pad) {
+    const float f_op = (float)e.max_time_op, f_jobs = (float)e.norm[0], f_sum = (float)e.norm[1];
+    const float f_m = (float)e.M;
+    const float r_op = as_float(e.norm[2]), r_jobs = as_float(e.norm[3]);
+    const float r_sum = as_float(e.norm[4]), r_m = as_float(e.norm[5]);
+    if (obs) {
+        for (int j = 0; j < e.J; ++j) {                                   // jss_env.py:102-111
+            float *row = obs + j * 7;
+            row[0] = e.legal(j) ? 1.f : 0.f;                              // :130
+            row[1] = div_by((float)e.w(j, JSS_F_LEFT), f_op, r_op);       // :448, :539
+            row[2] = div_by((float)e.todo(j), f_m, r_m);                  // :559
+            row[3] = div_by((float)e.w(j, JSS_F_PERF), f_jobs, r_jobs);   // :545
+            row[4] = e.w(j, JSS_F_F4) == JSS_F4_ONE ? 1.f : div_by((float)e.w(j, JSS_F_F4), f_op, r_op);   // :569-586
+            row[5] = div_by((float)e.w(j, JSS_F_IDLE_LAST), f_sum, r_sum);    // :555, :600
+            row[6] = div_by((float)e.w(j, JSS_F_IDLE), f_sum, r_sum);     // :553, :601
+        }
+        if (pad)
+            for (int i = e.J * 7; i < jm * 7; ++i) obs[i] = 0.f;          // padding rows
+    }
+    if (mk) {
+        for (int j = 0; j < e.J; ++j) mk[j] = e.legal(j) ? 1 : 0;
+        mk[e.J] = (uint8_t)e.noop();
+        for (int j = e.J + 1; j <= jm; ++j) mk[j] = 0;
+    }
+}
+
 void write_outputs(const Env &e, const Call &c, int b) {
     const int jm = c.d.jmax;
-    float *obs = c.o.real_obs + (size_t)b * jm * 7;
-    uint8_t *mk = c.o.action_mask + (size_t)b * (jm + 1);
-    const float f_op = (float)e.max_time_op, f_jobs = (float)e.inst[JSS_I_MAX_TIME_JOBS], f_sum = (float)e.inst[JSS_I_SUM_OP];
-    const float f_m = (float)e.M;
-    const float r_op = as_float(e.inst[JSS_I_RCP_MAX_TIME_OP]), r_jobs = as_float(e.inst[JSS_I_RCP_MAX_TIME_JOBS]);
-    const float r_sum = as_float(e.inst[JSS_I_RCP_SUM_OP]), r_m = as_float(e.inst[JSS_I_RCP_MACHINES]);
-    for (int j = 0; j < e.J; ++j) {                                       // jss_env.py:102-111
-        float *row = obs + j * 7;
-        row[0] = e.legal(j) ? 1.f : 0.f;                                  // :130
-        row[1] = div_by((float)e.w(j, JSS_F_LEFT), f_op, r_op);           // :448, :539
-        row[2] = div_by((float)e.todo(j), f_m, r_m);                      // :559
-        row[3] = div_by((float)e.w(j, JSS_F_PERF), f_jobs, r_jobs);       // :545
-        row[4] = e.w(j, JSS_F_F4) == JSS_F4_ONE ? 1.f : div_by((float)e.w(j, JSS_F_F4), f_op, r_op);   // :569-586
-        row[5] = div_by((float)e.w(j, JSS_F_IDLE_LAST), f_sum, r_sum);    // :555, :600
-        row[6] = div_by((float)e.w(j, JSS_F_IDLE), f_sum, r_sum);         // :553, :601
-        mk[j] = e.legal(j) ? 1 : 0;
-    }
-    for (int i = e.J * 7; i < jm * 7; ++i) obs[i] = 0.f;                  // padding rows
-    mk[e.J] = (uint8_t)e.noop();
-    for (int j = e.J + 1; j <= jm; ++j) mk[j] = 0;
+    write_obs_mask(e, jm, c.o.real_obs + (size_t)b * jm * 7, c.o.action_mask + (size_t)b * (jm + 1), true);
 }
 
 void add_counters(const Call &c, int b, int steps, int episodes, long long makespans, long long reward_num) {
@@ -396,32 +427,34 @@ void add_counters(const Call &c, int b, int steps, int episodes, long long makes
 
 uint64_t env_id_of(const Call &c, int b) { return (uint64_t)(c.d.env_ids ? c.d.env_ids[b] : c.d.env_id_base + b); }
 
-enum Mode { kReset, kStep, kAdvance, kPolicy, kRollout };
+enum Mode { kReset, kStep, kAdvance, kPolicy, kRollout, kTraj };
+
+void restart(const Env &e, const Call &c, int b) {                       // reset() + the bookkeeping around it
+    const int episode = e.hdr[JSS_H_EPISODE];
+    reset_env(e);
+    e.hdr[JSS_H_EPISODE] = episode + 1;
+    e.hdr[JSS_H_STEP] = 0;
+    c.o.reward[b] = 0.f;
+    c.o.done[b] = 0;
+}
 
 void run_env(const Call &c, int mode, int b) {
-    const Env e = env_of(c, b);
+    if (mode == kReset) {
+        if (c.which && !c.which[b]) return;
+        const Env e = env_of(c, b, true);
+        restart(e, c, b);
+        write_outputs(e, c, b);
+        return;
+    }
+    Env e = env_of(c, b, false);
+    if (e.J == 0) return;                                                 // never reset: nothing to step
     switch (mode) {
-    case kReset:
-        if (c.which && !c.which[b]) break;
-        {
-            const int episode = e.hdr[JSS_H_EPISODE];
-            reset_env(e);
-            e.hdr[JSS_H_EPISODE] = episode + 1;
-            e.hdr[JSS_H_STEP] = 0;
-            c.o.reward[b] = 0.f;
-            c.o.done[b] = 0;
-        }
-        break;
     case kStep: {
         const int a = c.actions[b];
         if (a == JSS_ACTION_SKIP) break;                                  // untouched: reward / done / makespan stay
-        if (a == JSS_ACTION_RESET) {                                      // reset() instead of a step
-            const int episode = e.hdr[JSS_H_EPISODE];
-            reset_env(e);
-            e.hdr[JSS_H_EPISODE] = episode + 1;
-            e.hdr[JSS_H_STEP] = 0;
-            c.o.reward[b] = 0.f;
-            c.o.done[b] = 0;
+        if (a == JSS_ACTION_RESET) {                                      // reset() instead of a step; the env may have been
+            e = env_of(c, b, true);                                       // given another instance since (table_of_env)
+            restart(e, c, b);
             break;
         }
         const int rn = step_env(e, a);
@@ -434,7 +467,7 @@ void run_env(const Call &c, int mode, int b) {
         break;
     }
     case kAdvance:
-        if (c.which && !c.which[b]) break;
+        if (c.which && !c.which[b]) return;
         {
             int hole = 0;
             if (!any_busy(e)) e.flag(JSS_ERR_NOPE_IDLE);                  // reference: IndexError (:517)
@@ -446,26 +479,47 @@ void run_env(const Call &c, int mode, int b) {
         c.actions_out[b] = select_action(e, c, env_id_of(c, b));
         return;                                                           // no outputs rewritten
     default: {                                                            // n_iter x (policy + step), dispatching.py:55-75
-        const uint64_t env_id = env_id_of(c, b);
+        const uint64_t env_id = env_id_of(c, b);                          // kTraj: every iteration recorded (JssTraj)
+        const int jm = c.d.jmax;
+        const bool autoreset = (c.flags & JSS_ROLLOUT_AUTORESET) != 0;
         int n_steps = 0, n_done = 0, last_rn = 0, last_makespan = -1;
         long long sum_makespan = 0, sum_rn = 0;
         for (int it = 0; it < c.n_iter; ++it) {
+            const size_t slot = (size_t)it * c.d.batch + b;
+            if (mode == kTraj)                                            // what the policy sees in this slot
+                write_obs_mask(e, jm, c.t.real_obs ? c.t.real_obs + slot * jm * 7 : nullptr,
+                               c.t.action_mask ? c.t.action_mask + slot * (jm + 1) : nullptr, false);
             if (n_legal(e) == 0) {                                        // done
-                if (!(c.flags & JSS_ROLLOUT_AUTORESET)) break;            // frozen
+                if (mode == kTraj) {
+                    if (c.t.action) c.t.action[slot] = autoreset ? JSS_ACTION_RESET : JSS_ACTION_SKIP;
+                    if (c.t.reward) c.t.reward[slot] = 0.f;
+                    if (c.t.done) c.t.done[slot] = autoreset ? 0 : 1;
+                }
+                if (!autoreset) {
+                    if (mode == kTraj) continue;                          // frozen: every remaining slot says so
+                    break;
+                }
                 const int episode = e.hdr[JSS_H_EPISODE];
                 reset_env(e);
                 e.hdr[JSS_H_EPISODE] = episode + 1;
                 e.hdr[JSS_H_STEP] = 0;
                 continue;
             }
-            last_rn = step_env(e, select_action(e, c, env_id));
+            const int a = select_action(e, c, env_id);
+            last_rn = step_env(e, a);
             e.hdr[JSS_H_STEP] += 1;
             n_steps += 1;
             sum_rn += last_rn;
-            if (n_legal(e) == 0) {
+            const bool done = n_legal(e) == 0;
+            if (done) {
                 n_done += 1;
                 sum_makespan += e.t();
                 last_makespan = e.t();
+            }
+            if (mode == kTraj) {
+                if (c.t.action) c.t.action[slot] = a;
+                if (c.t.reward) c.t.reward[slot] = (float)last_rn / (float)e.max_time_op;
+                if (c.t.done) c.t.done[slot] = done ? 1 : 0;
             }
         }
         if (n_steps) c.o.reward[b] = (float)last_rn / (float)e.max_time_op;
@@ -585,6 +639,21 @@ int jss_rollout(const JssDesc *desc, const JssState *state, const JssOut *out, i
     c.n_iter = n_iter; c.flags = flags;
     return run(c, kRollout);
 }
+
+int jss_trajectory(const JssDesc *desc, const JssState *state, const JssOut *out, const JssTraj *traj, int kind,
+                   uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, void *) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if (!traj) return JSS_E_NULL;
+    if ((rc = check_kind(desc, kind))) return rc;
+    if (n_steps < 0) return JSS_E_SHAPE;
+    Call c;
+    c.d = *desc; c.s = *state; c.o = *out; c.t = *traj; c.kind = kind; c.seed = seed; c.explore_q16 = explore_q16;
+    c.n_iter = n_steps; c.flags = flags;
+    return run(c, kTraj);
+}
+
+int jss_sync_check(void *) { return 0; }                                  // every call of this library is synchronous
 
 // envs are independent and the call is synchronous: n_steps one-step rollouts of every env ARE one n_steps-iteration
 // rollout per env; sub-batches and streams have nothing to overlap here

@@ -78,11 +78,13 @@ int plan(Params &p, LaunchPlan &lp) {
         lp.envs_per_block = (kWave / G) * kWavesPerBlock;
         p.obs_wave_floats = ((kWave / G) * p.d.jmax * 7 + 3) & ~3;
         p.mv_off_ints = p.table_lds_ints + kWavesPerBlock * p.obs_wave_floats;
-        lp.shmem = sizeof(int32_t) * ((size_t)p.mv_off_ints + kBlock);
+        p.norm_off_ints = p.mv_off_ints + kBlock;                       // one int per lane (six used per group), kTabGlobal
+        lp.shmem = sizeof(int32_t) * ((size_t)p.norm_off_ints + (shared ? 0 : kBlock));
     } else {
         lp.envs_per_block = kWavesPerBlock;
-        p.obs_wave_floats = (p.d.jmax * 7 + 3) & ~3;
+        p.obs_wave_floats = (p.d.jmax * 7 + 3 + 3) & ~3;               // + up to 3 floats of alignment shift (store_obs)
         p.mv_off_ints = 0;
+        p.norm_off_ints = 0;
         lp.shmem = sizeof(int32_t) * ((size_t)p.table_lds_ints + kWavesPerBlock * p.obs_wave_floats);
     }
 #ifdef JSS_PROFILING
@@ -108,21 +110,17 @@ int launch(Params &p, void *stream) {
     return rc ? rc : fire(p, lp, stream);
 }
 
-// The description of envs [start, start + count) of the batch `p` describes: every per-env pointer moves,
-// and so do the instance tables when the batch has one table per env (tid = local env index).
+// The description of envs [start, start + count) of the batch `p` describes, for the step-type modes: every per-env
+// pointer moves; the instance tables stay (an env's header names its table by its index in the WHOLE batch's
+// tables, so n_tables keeps describing those).  Not a description a reset may be launched with.
 Params sub_batch(const Params &p, int start, int count) {
     Params q = p;
     const size_t s0 = (size_t)start, jm = (size_t)p.d.jmax, mm = (size_t)p.d.mmax;
     q.d.batch = count;
     if (p.d.table_of_env) q.d.table_of_env = p.d.table_of_env + s0;
-    else if (p.d.n_tables != 1) {
-        q.d.ops = p.d.ops + s0 * jm * mm;
-        if (p.d.rem) q.d.rem = p.d.rem + s0 * jm * mm;
-        q.d.inst = p.d.inst + s0 * JSS_NI;
-    }
     if (p.d.env_ids) q.d.env_ids = p.d.env_ids + s0;
     q.d.env_id_base = p.d.env_id_base + start;
-    q.s.env = p.s.env + s0 * 4;
+    q.s.env = p.s.env + s0 * JSS_NH;
     q.s.job = p.s.job + s0 * jm * JSS_NF;
     q.s.machine = p.s.machine + s0 * mm;
     q.s.solution = p.s.solution + s0 * jm * mm;
@@ -215,6 +213,25 @@ int jss_rollout(const JssDesc *desc, const JssState *state, const JssOut *out, i
     p.d = *desc; p.s = *state; p.o = *out; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
     p.n_iter = n_iter; p.flags = flags;
     return n_iter == 1 ? launch<kRollout1>(p, stream) : launch<kRollout>(p, stream);
+}
+
+int jss_trajectory(const JssDesc *desc, const JssState *state, const JssOut *out, const JssTraj *traj, int kind,
+                   uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, void *stream) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if (!traj) return JSS_E_NULL;
+    if ((rc = check_kind(desc, kind))) return rc;
+    if (n_steps < 0) return JSS_E_SHAPE;
+    Params p = {};
+    p.d = *desc; p.s = *state; p.o = *out; p.t = *traj; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
+    p.n_iter = n_steps; p.flags = flags;
+    return launch<kTraj>(p, stream);
+}
+
+int jss_sync_check(void *stream) {
+    const hipError_t rc = hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));
+    const hipError_t sticky = hipGetLastError();
+    return (int)(rc != hipSuccess ? rc : sticky);
 }
 
 int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,

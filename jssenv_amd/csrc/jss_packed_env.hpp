@@ -47,6 +47,11 @@ struct PCtx {                 // per-lane view of "my env"
     bool jvalid, mvalid;      // gl < J, gl < M
     int tid;                  // instance of my env
     int J, M, max_time_op;
+    // the observation's normalisers: wave-uniform registers with kTabLds (one instance for the whole batch); with
+    // kTabGlobal they differ per group and wait in LDS (`norm`: 6 ints per group, written when the kernel starts)
+    int max_time_jobs, sum_op;
+    float r_op, r_jobs, r_sum, r_m;
+    int32_t *norm;
     const int32_t *lds_row;   // kTabLds: op table row of my job in LDS
     // op table row of my job.  With kTabGlobal the 64-bit address is rebuilt from `tid` at each of its (few) uses
     // rather than carried in two VGPRs through the whole kernel (these kernels are the register-hungry ones).
@@ -122,9 +127,9 @@ __device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G, TAB> &c, const
         e.f4 = 0;                                                        // :180
         e.legal = c.jvalid;                                              // :160
         e.blocked = false;                                               // :171-172
-        if (c.alive) {                                                   // solution = -1 (:163)
+        if (c.alive) {                                                   // solution = -1 (:163), the whole padded block
             int32_t *sol = p.s.solution + ((size_t)c.first_env + c.rel) * p.d.jmax * p.d.mmax;
-            const int n = c.J * p.d.mmax;
+            const int n = p.d.jmax * p.d.mmax;
             for (int i = c.gl; i < n; i += G) sol[i] = -1;
         }
     }
@@ -356,28 +361,28 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G, TAB> &c,
     const bool caseB = c.jvalid && !e.legal && !caseA && !e.blocked && e.todo < c.M; // :366-369
     int k = caseA ? e.todo + 1 : e.todo;                                              // :332 / :370
     int tn = caseA ? e.t + e.left : e.t + tm_need;                                    // :334-337 / :374-377
-    int u = 0;                                                                        // machine_next as a bit mask
+    uint32_t u = 0;                                                                   // machine_next as a bit mask
     const int last = c.M - 1;
     const int32_t *tab = mvtab + c.gbase;
     // the loop of :340-363 / :380-401, its first iterations on the ops the record carries
     bool go = gate && (caseA || caseB) && k < last && mh > tn;
     if (go && caseB) {                                                                // op k == todo: the current op
         const int m = e.cur >> 16;
-        if (tab[m] > tn) u |= 1 << m;                                                 // :346-351
+        if (tab[m] > tn) u |= 1u << m;                                                // :346-351
         tn += e.cur & kDurMask;                                                       // :362
         ++k;
         go = k < last && mh > tn;
     }
     if (go) {                                                                         // op k == todo + 1: the next op
         const int m = e.nxt >> 16;
-        if (tab[m] > tn) u |= 1 << m;
+        if (tab[m] > tn) u |= 1u << m;
         tn += e.nxt & kDurMask;
         ++k;
         go = k < last && mh > tn;
     }
     if (go) {                                                                         // op k == todo + 2: the one after it
         const int m = e.nxt2 >> 16;
-        if (tab[m] > tn) u |= 1 << m;
+        if (tab[m] > tn) u |= 1u << m;
         tn += e.nxt2 & kDurMask;
         ++k;
         go = k < last && mh > tn;
@@ -387,18 +392,18 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G, TAB> &c,
             const int32_t *row = c.row(p);
             const int op0 = row[k], op1 = row[k + 1];                             // k + 1 <= M - 1: inside the row
             int m = op0 >> 16;
-            if (tab[m] > tn) u |= 1 << m;
+            if (tab[m] > tn) u |= 1u << m;
             tn += op0 & kDurMask;
             ++k;
             if (k < last && mh > tn) {
                 m = op1 >> 16;
-                if (tab[m] > tn) u |= 1 << m;
+                if (tab[m] > tn) u |= 1u << m;
                 tn += op1 & kDurMask;
                 ++k;
             }
         } while (k < last && mh > tn);
     }
-    int covered = row_or(u);                                                          // union over the group
+    int covered = row_or((int)u);                                                     // union over the group
     if (G == 32) covered |= __builtin_amdgcn_ds_swizzle(covered, 0x401F);
     if (gate && (uint32_t)covered == legal_machines) e.noop = 1;                      // :357-359 / :395-397
     wave_lds_sync();                                                                  // mvtab is reused by the next call
@@ -517,7 +522,7 @@ __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G, TAB> &c, const Pa
     const unsigned jc = (unsigned)c.gl < jm ? c.gl : 0;
     const unsigned mc = (unsigned)c.gl < mm ? c.gl : 0;
     const size_t fe = (size_t)c.first_env;
-    r.h = ld_off<int4>(p.s.env + fe * 4, c.rel * 16u);
+    r.h = ld_off<int4>(p.s.env + fe * JSS_NH, c.rel * (JSS_NH * 4u));
     const int32_t *jb = p.s.job + fe * jm * JSS_NF;
     const unsigned jo = (c.rel * jm + jc) * 32u;
     r.lo = ld_off<int4>(jb, jo);
@@ -550,48 +555,81 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, c
     return hd;
 }
 
+// action mask rows of jmax + 1 bytes at `mk` (first env of the wave): legal jobs, the NOPE flag at index J, zeros behind it
 template <int G, int TAB>
-__device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, const PHeader &hd,
-                                        const PRaw<G> &raw) {
+__device__ __forceinline__ void p_store_mask(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, uint8_t *mk) {
     if (!c.alive) return;
-    const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
-    const size_t fe = (size_t)c.first_env;
-    if (c.gl == 0)
-        st_off(p.s.env + fe * 4, c.rel * 16u,
-                     make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0)));
-    if (c.mvalid && e.tm != raw.tm) st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);   // idle machines stay 0
-    if (c.jvalid) {
-        int32_t *jb = p.s.job + fe * jm * JSS_NF;
-        const unsigned jo = (c.rel * jm + c.gl) * 32u;
-        const int4 lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0) |
-                                      (e.nxt2 >= 0 ? (int)((unsigned)e.nxt2 << JSS_NEXT2_SHIFT) : 0), e.cur, e.left, e.perf);
-        const int4 hi = make_int4(e.idle, e.idle_last, e.f4, e.nxt);
-        // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
-        if (lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
-        if (hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) st_off(jb, jo + 16u, hi);
-    }
-    // action mask row of jmax + 1 bytes: legal jobs, the NOPE flag at index J, zeros behind it
-    uint8_t *mk = p.o.action_mask + fe * (jm + 1);
+    const unsigned jm = (unsigned)p.d.jmax;
     const unsigned mo = c.rel * (jm + 1);
     if ((unsigned)c.gl <= jm)
         st_off<uint8_t>(mk, mo + c.gl, (uint8_t)(c.jvalid ? (e.legal ? 1 : 0) : (c.gl == c.J ? e.noop : 0)));
     if (jm == (unsigned)G && c.gl == 0) st_off<uint8_t>(mk, mo + jm, (uint8_t)(c.J == G ? e.noop : 0));
 }
 
+// the observation's normalisers of my env (see PCtx)
+struct PNorm {
+    int max_time_jobs, sum_op;
+    float r_op, r_jobs, r_sum, r_m;
+};
+template <int G, int TAB>
+__device__ __forceinline__ PNorm p_norm(const PCtx<G, TAB> &c) {
+    PNorm n;
+    if (TAB == kTabLds) {
+        n.max_time_jobs = c.max_time_jobs; n.sum_op = c.sum_op;
+        n.r_op = c.r_op; n.r_jobs = c.r_jobs; n.r_sum = c.r_sum; n.r_m = c.r_m;
+    } else {
+        n.max_time_jobs = c.norm[0]; n.sum_op = c.norm[1];
+        n.r_op = as_float(c.norm[2]); n.r_jobs = as_float(c.norm[3]); n.r_sum = as_float(c.norm[4]); n.r_m = as_float(c.norm[5]);
+    }
+    return n;
+}
+
+// State back to HBM.  fresh = my env was (re)initialised by this call: every row of its padded block is written (rows
+// behind J(env) as "no job") together with the instance constants in its header; otherwise rows < J(env), and of
+// those only the halves that changed.
+template <int G, int TAB>
+__device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, const PHeader &hd,
+                                        const PRaw<G> &raw, bool fresh) {
+    if (!c.alive) return;
+    const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
+    const size_t fe = (size_t)c.first_env;
+    if (c.gl == 0) {
+        int32_t *hp = p.s.env + fe * JSS_NH;
+        const unsigned ho = c.rel * (JSS_NH * 4u);
+        st_off(hp, ho, make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0)));
+        if (fresh) {   // the instance constants of the env travel with it from here on (include/jss_hip.h JSS_H_*)
+            const PNorm n = p_norm(c);
+            st_off(hp, ho + 16u, make_int4(c.J, c.M, c.max_time_op, c.tid));
+            st_off(hp, ho + 32u, make_int4(n.max_time_jobs, n.sum_op, as_int(n.r_op), as_int(n.r_jobs)));
+            st_off(hp, ho + 48u, make_int4(as_int(n.r_sum), as_int(n.r_m), 0, 0));
+        }
+    }
+    if (fresh ? (unsigned)c.gl < mm : (c.mvalid && e.tm != raw.tm))      // idle machines stay 0
+        st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
+    if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
+        int32_t *jb = p.s.job + fe * jm * JSS_NF;
+        const unsigned jo = (c.rel * jm + c.gl) * 32u;
+        const int4 lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0) |
+                                      (e.nxt2 >= 0 ? (int)((unsigned)e.nxt2 << JSS_NEXT2_SHIFT) : 0), e.cur, e.left, e.perf);
+        const int4 hi = make_int4(e.idle, e.idle_last, e.f4, e.nxt);
+        // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
+        if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
+        if (fresh || hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) st_off(jb, jo + 16u, hi);
+    }
+}
+
 // (J,7) float32 observation (jss_env.py:102-111).  Each lane writes its job's row into an LDS
 // image of the wave's E consecutive envs ([E][jmax][7], padding rows zero), which then goes out as
 // one linear copy -- dwordx4 per lane when the wave's block is whole and 16-byte sized.
 template <int G, int TAB>
-__device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, float *scratch,
-                                            bool wave_whole) {
+__device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, float *dst,
+                                            float *scratch, bool wave_whole) {   // dst: block of the wave's first env
     constexpr int E = kWave / G;
     const int row_floats = p.d.jmax * 7;
-    // the normalisers and their reciprocals (instance record words 2..8)
-    const int32_t *ir = p.d.inst + (TAB == kTabLds ? 0 : (size_t)c.tid * JSS_NI);
-    const float f_op = (float)c.max_time_op, f_jobs = (float)ir[JSS_I_MAX_TIME_JOBS], f_sum = (float)ir[JSS_I_SUM_OP];
+    const PNorm nr = p_norm(c);
+    const float f_op = (float)c.max_time_op, f_jobs = (float)nr.max_time_jobs, f_sum = (float)nr.sum_op;
     const float f_m = (float)c.M;
-    const float r_op = as_float(ir[JSS_I_RCP_MAX_TIME_OP]), r_jobs = as_float(ir[JSS_I_RCP_MAX_TIME_JOBS]);
-    const float r_sum = as_float(ir[JSS_I_RCP_SUM_OP]), r_m = as_float(ir[JSS_I_RCP_MACHINES]);
+    const float r_op = nr.r_op, r_jobs = nr.r_jobs, r_sum = nr.r_sum, r_m = nr.r_m;
     float *mine = scratch + (c.gbase / G) * row_floats;   // image slot = physical group (dead groups share c.rel with a live one)
     if (c.gl < p.d.jmax) {
         float *row = mine + c.gl * 7;
@@ -605,8 +643,7 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G, TAB>
     }
     wave_lds_sync();
     const int n = E * row_floats;
-    float *dst = p.o.real_obs + (size_t)c.first_env * row_floats;
-    if (wave_whole && (n & 3) == 0) {
+    if (wave_whole && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
         for (int i = c.lane; i < (n >> 2); i += kWave)
             st_nt(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
     } else if (c.alive) {
@@ -616,16 +653,41 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G, TAB>
 }
 
 // ---------------------------------------------------------------------------------------
-// mode bodies: everything between "state unpacked into registers" and "state stored"
+// mode bodies: everything between "state unpacked into registers" and "state stored".  Returns "my env was
+// (re)initialised by this call".
 // ---------------------------------------------------------------------------------------
-template <int G, int MODE, int TAB>
-__device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G, TAB> &c, const Params &p, int a_in, bool selected,
-                                       int32_t *mvtab) {
+// my env is being reset and may have been given another instance since (table_of_env): take its constants from the
+// instance record (kTabGlobal; with kTabLds the whole batch shares one instance and nothing changes)
+template <int G, int TAB>
+__device__ __forceinline__ void p_reload_instance(PCtx<G, TAB> &c, const Params &p, bool on) {
+    if (TAB == kTabLds) return;
+    if (__ballot(on) == 0) return;
     const size_t fe = (size_t)c.first_env;
+    int tid = c.tid;
+    if (on && p.d.table_of_env) tid = ld_off<int>(p.d.table_of_env + fe, c.rel * 4u);
+    const int32_t *ir = p.d.inst + (size_t)tid * JSS_NI;
+    if (on) {
+        c.tid = tid;
+        c.J = ir[JSS_I_JOBS];
+        c.M = ir[JSS_I_MACHINES];
+        c.max_time_op = ir[JSS_I_MAX_TIME_OP];
+        c.jvalid = c.gl < c.J;
+        c.mvalid = c.gl < c.M;
+        if (c.gl < 6) c.norm[c.gl] = ir[JSS_I_MAX_TIME_JOBS + c.gl];      // record words 3..8 = the six normalisers
+    }
+    wave_lds_sync();
+}
+
+template <int G, int MODE, int TAB>
+__device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c, const Params &p, int a_in, bool selected,
+                                       int32_t *mvtab, float *scratch, bool wave_whole) {
+    const size_t fe = (size_t)c.first_env;
+    bool fresh = false;
     if (MODE == kReset) {
         const bool on = c.alive && selected;          // untouched groups are written back unchanged
         p_reset(e, c, p, on);
         if (on) {
+            fresh = true;
             hd.episode += 1;
             hd.step = 0;
             if (c.gl == 0) {
@@ -635,8 +697,10 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G, TA
         }
     } else if (MODE == kStep) {
         const bool restart = c.alive && a_in == JSS_ACTION_RESET;       // reset() this env instead of stepping it
+        p_reload_instance(c, p, restart);
         p_reset(e, c, p, restart);
         if (restart) {
+            fresh = true;
             hd.episode += 1;
             hd.step = 0;
             if (c.gl == 0) {
@@ -666,17 +730,22 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G, TA
                                                        : p.d.env_id_base + (int64_t)(fe + c.rel));
         const int a = p_select(e, c, p, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
         if (c.alive && c.gl == 0) st_off<int>(p.actions_out + fe, c.rel * 4u, a);
-    } else {  // kRollout / kRollout1
+    } else {  // kRollout / kRollout1 / kTraj
         const uint64_t env_id = (uint64_t)(p.d.env_ids ? ld_off<int64_t>(p.d.env_ids + fe, c.rel * 8u)
                                                        : p.d.env_id_base + (int64_t)(fe + c.rel));
         int n_steps = 0, n_done = 0, last_rn = 0, last_makespan = -1, sum_makespan = 0, sum_rn = 0;
         const bool autoreset = (p.flags & JSS_ROLLOUT_AUTORESET) != 0;
         const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;
         for (int it = 0; it < n_iter; ++it) {
+            const size_t slot0 = (size_t)it * p.d.batch + fe;            // kTraj: slot [it][first env of the wave]
+            if (MODE == kTraj) {                                         // what the policy sees in this slot
+                if (p.t.real_obs) p_store_obs<G, TAB>(e, c, p, p.t.real_obs + slot0 * p.d.jmax * 7, scratch, wave_whole);
+                if (p.t.action_mask) p_store_mask<G, TAB>(e, c, p, p.t.action_mask + slot0 * (p.d.jmax + 1));
+            }
             const bool done0 = !grp_any<G>(e.legal, c.gbase);            // :639-653
             const bool do_reset = c.alive && done0 && autoreset;
             const bool do_step = c.alive && !done0;
-            if (MODE != kRollout1 && __ballot(do_reset || do_step) == 0) break;  // every env frozen
+            if (MODE != kRollout1 && MODE != kTraj && __ballot(do_reset || do_step) == 0) break;  // every env frozen
             p_reset(e, c, p, do_reset);
             if (do_reset) {
                 hd.episode += 1;
@@ -698,6 +767,12 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G, TA
                     last_makespan = e.t;
                 }
             }
+            if (MODE == kTraj && c.alive && c.gl == 0) {
+                const size_t slot = slot0 + c.rel;
+                if (p.t.action) p.t.action[slot] = do_step ? a : (do_reset ? JSS_ACTION_RESET : JSS_ACTION_SKIP);
+                if (p.t.reward) p.t.reward[slot] = do_step ? (float)rn / (float)c.max_time_op : 0.f;
+                if (p.t.done) p.t.done[slot] = do_step ? (done1 ? 1 : 0) : (do_reset ? 0 : 1);
+            }
         }
         const bool done = !grp_any<G>(e.legal, c.gbase);
         if (c.alive && c.gl == 0) {
@@ -707,6 +782,7 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G, TA
             if (p.s.counters) add_counters(p.s.counters + (fe + c.rel) * 4, n_steps, n_done, sum_makespan, sum_rn);
         }
     }
+    return fresh;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -720,8 +796,9 @@ __device__ __forceinline__ void p_body(PEnv<G> &e, PHeader &hd, const PCtx<G, TA
 #define JSS_PACKED_GLOBAL_MIN_BLOCKS 7
 #endif
 template <int G, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, MODE == kRollout ? (TAB == kTabGlobal ? 4 : 5)
-                                                    : ((TAB == kTabGlobal && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
+__global__ __launch_bounds__(kBlock, MODE == kTraj ? (TAB == kTabGlobal ? 3 : 4)
+                                     : MODE == kRollout ? (TAB == kTabGlobal ? 4 : 5)
+                                     : ((TAB == kTabGlobal && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
 void jss_packed_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     constexpr int E = kWave / G;                      // envs per wave
@@ -736,6 +813,7 @@ void jss_packed_kernel(Params p) {
     c.lane = lane;
     c.gl = lane & (G - 1);
     c.gbase = lane & ~(G - 1);
+    c.norm = lds + p.norm_off_ints + wave * kWave + c.gbase;             // kTabGlobal: my group's six normalisers
     c.first_env = blockIdx.x * EB + wave * E;                            // wave-uniform
     const bool wave_dead = c.first_env >= p.d.batch;                     // only in the last workgroup
     const int e_in_wave = lane / G;
@@ -743,17 +821,27 @@ void jss_packed_kernel(Params p) {
     c.rel = (unsigned)(c.alive ? e_in_wave : (wave_dead ? 0 : p.d.batch - 1 - c.first_env));
     const bool wave_whole = c.first_env + E <= p.d.batch;
     const size_t fe = (size_t)c.first_env;
-    // 1. state loads first: they depend on nothing but the env index
+    // 1. state loads first: they depend on nothing but the env index.  With kTabGlobal the env's shape and op table
+    //    index come from its header (words 4-7: the same 64-byte line as the clock) and its six observation
+    //    normalisers (words 8-13) are parked in LDS, one word per lane, until the observation is written; a reset
+    //    call takes both from the instance record instead (env -> instance -> record).
     PRaw<G> raw;
     int a_in = JSS_ACTION_SKIP;
     bool selected = true;
+    int4 hx = make_int4(0, 0, 0, 0);
     c.tid = 0;
     if (!wave_dead) {
         raw = p_issue_loads<G, TAB>(c, p);
         if (MODE == kStep) a_in = ld_off<int>(p.actions + fe, c.rel * 4u);
         if ((MODE == kReset || MODE == kAdvance) && p.which) selected = ld_off<uint8_t>(p.which + fe, c.rel) != 0;
-        if (TAB == kTabGlobal)
-            c.tid = p.d.table_of_env ? ld_off<int>(p.d.table_of_env + fe, c.rel * 4u) : (int)(fe + c.rel);
+        if (TAB == kTabGlobal) {
+            if (MODE == kReset) {
+                c.tid = p.d.table_of_env ? ld_off<int>(p.d.table_of_env + fe, c.rel * 4u) : (int)(fe + c.rel);
+            } else {
+                hx = ld_off<int4>(p.s.env + fe * JSS_NH, c.rel * (JSS_NH * 4u) + 16u);
+                if (c.gl < 6) c.norm[c.gl] = ld_off<int>(p.s.env + fe * JSS_NH, c.rel * (JSS_NH * 4u) + 32u + (unsigned)c.gl * 4u);
+            }
+        }
     }
     // 2. instance constants; the shared op table -> LDS
     if (TAB == kTabLds) {
@@ -761,20 +849,43 @@ void jss_packed_kernel(Params p) {
         __syncthreads();
     }
     if (wave_dead) return;
-    const int32_t *ir = p.d.inst + (TAB == kTabLds ? 0 : (size_t)c.tid * JSS_NI);
-    c.J = ir[JSS_I_JOBS];
-    c.M = ir[JSS_I_MACHINES];
-    c.max_time_op = ir[JSS_I_MAX_TIME_OP];
+    if (TAB == kTabLds) {                             // one instance for the whole batch: scalar loads, issued up here
+        const int32_t *ir = p.d.inst;
+        c.J = ir[JSS_I_JOBS];
+        c.M = ir[JSS_I_MACHINES];
+        c.max_time_op = ir[JSS_I_MAX_TIME_OP];
+        c.max_time_jobs = ir[JSS_I_MAX_TIME_JOBS];
+        c.sum_op = ir[JSS_I_SUM_OP];
+        c.r_op = as_float(ir[JSS_I_RCP_MAX_TIME_OP]);
+        c.r_jobs = as_float(ir[JSS_I_RCP_MAX_TIME_JOBS]);
+        c.r_sum = as_float(ir[JSS_I_RCP_SUM_OP]);
+        c.r_m = as_float(ir[JSS_I_RCP_MACHINES]);
+    } else if (MODE == kReset) {
+        const int32_t *ir = p.d.inst + (size_t)c.tid * JSS_NI;
+        c.J = ir[JSS_I_JOBS];
+        c.M = ir[JSS_I_MACHINES];
+        c.max_time_op = ir[JSS_I_MAX_TIME_OP];
+        if (c.gl < 6) c.norm[c.gl] = ir[JSS_I_MAX_TIME_JOBS + c.gl];
+        wave_lds_sync();
+    } else {
+        c.J = hx.x;
+        c.M = hx.y;
+        c.max_time_op = hx.z;
+        c.tid = hx.w;
+        wave_lds_sync();
+    }
     c.jvalid = c.gl < c.J;
     c.mvalid = c.gl < c.M;
     c.lds_row = lds + (c.gl < p.d.jmax ? c.gl : 0) * p.d.mmax;
 
     PEnv<G> e;
     PHeader hd = p_unpack(e, c, raw);
-    p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab);
+    const bool fresh = p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab, scratch, wave_whole);
     if (MODE == kPolicy) return;
-    p_store(e, c, p, hd, raw);
-    if (!JSS_ABLATED(p, JSS_ABLATE_OBS)) p_store_obs<G, TAB>(e, c, p, scratch, wave_whole);
+    p_store(e, c, p, hd, raw, fresh);
+    p_store_mask<G, TAB>(e, c, p, p.o.action_mask + fe * (p.d.jmax + 1));
+    if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
+        p_store_obs<G, TAB>(e, c, p, p.o.real_obs + fe * p.d.jmax * 7, scratch, wave_whole);
 }
 
 }  // namespace jss

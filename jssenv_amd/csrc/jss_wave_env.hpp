@@ -3,8 +3,15 @@
 // Job j on lane j % 64, slot j / 64 (JPL = 1 or 2 slots); machine m on lane m.  The legal / blocked
 // job sets are wave-uniform 64-bit masks (SGPR pairs): nb_legal_actions is one s_bcnt1, "any legal"
 // one s_cmp, and the data-dependent while-loops of step() are scalar branches.
+//
+// Memory round trips of a step-type call (the wave is latency-bound at the batch sizes this flavour
+// serves -- profiles/README.md): ONE mandatory trip -- the env's 64-byte header (scalar load: clock,
+// J, M, the observation's normalisers, the op table index) together with the job records and machine
+// clocks, none of whose addresses depends on another load (ragged batches: header first, then the rows
+// < J(env)) -- plus, when a job moves on to a new op, the 4-byte op table entry that refills its record,
+// which is issued inside jump() and not waited for before the state is packed for the store (kPending).
 #include "jss_common.hpp"
-#include "jss_packed_env.hpp"   // ld_off / st_off
+#include "jss_packed_env.hpp"   // ld_off / st_off / st_nt
 
 namespace jss {
 
@@ -17,12 +24,20 @@ struct Ctx {
     const int32_t *tab;  // op table of my env (LDS with kTabLds, global with kTabGlobal), row stride `stride`
     int stride;
     int lane;
+    // the observation's normalisers (jss_env.py:102-111) and their float32 reciprocals
+    int max_time_jobs, sum_op;
+    float r_op, r_jobs, r_sum, r_m;
 };
+
+// nxt2 of a job that has just moved on to a new op while the op table entry that refills it is still
+// in flight (Env::fill receives it): see jump() / settle()
+constexpr int kPending = -2;
 
 template <int JPL>
 struct Env {
     int t;                                                               // current_time_step
     int todo[JPL], cur[JPL], nxt[JPL], nxt2[JPL], left[JPL], perf[JPL], idle[JPL], idle_last[JPL], f4[JPL];
+    int fill[JPL];                                                       // the load behind a kPending nxt2
     uint64_t legal[JPL], blocked[JPL];                                   // job sets, wave-uniform
     int tm;                                                              // lane m: time_until_available_machine[m]
     int noop;                                                            // legal_actions[J]
@@ -53,6 +68,14 @@ __device__ __forceinline__ int job_value(const int (&v)[JPL], int a) {
     return __builtin_amdgcn_readlane(x, a & 63);
 }
 
+// the refill of a record's third cached op has landed: from here on nxt2 is a plain value again
+template <int JPL>
+__device__ __forceinline__ void settle(Env<JPL> &e) {
+#pragma unroll
+    for (int s = 0; s < JPL; ++s)
+        if (e.nxt2[s] == kPending) e.nxt2[s] = e.fill[s];
+}
+
 // ---------------------------------------------------------------------------------------
 // reset(): jss_env.py:145-181
 // ---------------------------------------------------------------------------------------
@@ -70,14 +93,16 @@ __device__ __forceinline__ void reset_env(Env<JPL> &e, const Ctx &c, const Param
         e.cur[s] = v ? c.tab[j * c.stride] : -1;                         // :174-176 needed machine = op 0
         e.nxt[s] = (v && 1 < c.M) ? c.tab[j * c.stride + 1] : -1;
         e.nxt2[s] = (v && 2 < c.M) ? c.tab[j * c.stride + 2] : -1;
+        e.fill[s] = -1;
         e.left[s] = e.perf[s] = e.idle[s] = e.idle_last[s] = 0;          // :165-170
         e.f4[s] = 0;                                                     // :180 state zeros
         e.legal[s] = __ballot(v);                                        // :160
         e.blocked[s] = 0;                                                // :171-172
     }
-    // solution = -1 (:163); coalesced rows of the padded [jmax][mmax] block
+    // solution = -1 (:163): the whole padded [jmax][mmax] block of the env, coalesced (rows behind J(env) too, so
+    // that nothing of a previous, larger instance of this env survives a reset)
     int32_t *sol = p.s.solution + (size_t)c.b * p.d.jmax * p.d.mmax;
-    const int n = c.J * p.d.mmax;
+    const int n = p.d.jmax * p.d.mmax;
     for (int i = c.lane; i < n; i += kWave) st_off<int>(sol, (unsigned)i * 4u, -1);
 }
 
@@ -140,6 +165,9 @@ __device__ __forceinline__ int advance(Env<JPL> &e, const Ctx &c) {
 // ---------------------------------------------------------------------------------------
 // `while nb_legal_actions == 0 (and a machine is busy): increase_time_step()` in one jump to the first time T at which
 // a job becomes legal (derivation and the two rare cases: p_jump in jss_packed_env.hpp).  Caller guarantees no legal job.
+// A job that finishes inside the jump moves on (cur <- nxt <- nxt2) and the op table entry that refills nxt2 is
+// requested here but NOT waited for: nxt2 = kPending until settle() (end of step(); earlier only if a look-ahead
+// walk of _check_no_op needs that very entry), so the request's latency hides behind the rest of the step.
 // ---------------------------------------------------------------------------------------
 template <int JPL>
 __device__ __forceinline__ void jump(Env<JPL> &e, const Ctx &c, bool is_nope, int &rn) {
@@ -192,7 +220,12 @@ __device__ __forceinline__ void jump(Env<JPL> &e, const Ctx &c, bool is_nope, in
                 e.todo[s] += 1;
                 e.cur[s] = e.nxt[s];
                 e.nxt[s] = e.nxt2[s];
-                e.nxt2[s] = (e.todo[s] + 2 < c.M) ? c.tab[j * c.stride + e.todo[s] + 2] : -1;
+                if (e.todo[s] + 2 < c.M) {
+                    e.fill[s] = c.tab[j * c.stride + e.todo[s] + 2];     // in flight until settle()
+                    e.nxt2[s] = kPending;
+                } else {
+                    e.nxt2[s] = -1;
+                }
                 const bool more = e.cur[s] >= 0;
                 e.idle[s] += more ? T - f : 0;
                 e.idle_last[s] = more ? T - f : 0;
@@ -352,6 +385,7 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
             ++k;
             go = k < last && hz.mh > tn;
         }
+        if (__ballot(go && e.nxt2[s] == kPending) != 0) settle(e);                // rare: the walk needs the entry being refilled
         if (go) {                                                                 // op k == todo + 2: the one after it
             tn = walk_op(hz, e.nxt2[s], tn, u);
             ++k;
@@ -421,6 +455,7 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
     }
     if (!JSS_ABLATED(p, JSS_ABLATE_PRIORITIZE)) prioritize(e, c);        // :432 / :471
     if (!JSS_ABLATED(p, JSS_ABLATE_CHECK_NO_OP)) check_no_op(e, c);      // :433 / :472
+    settle(e);                                                           // the refill jump() requested has had the rest of the step to land
     return rn;
 }
 
@@ -511,7 +546,7 @@ __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, co
 }
 
 // ---------------------------------------------------------------------------------------
-// HBM <-> registers.  One 32-byte record per job (two dwordx4 per lane), one int4 header per env.
+// HBM <-> registers.  One 32-byte record per job (two dwordx4 per lane), one 64-byte header per env.
 // The env index is wave-uniform, so every base is an SGPR pair and the lane offset 32 bits.
 // ---------------------------------------------------------------------------------------
 struct Header {
@@ -519,24 +554,25 @@ struct Header {
 };
 
 template <int JPL>
-struct RawEnv {  // loads issued first; unpacked once the instance record is known
-    int4 h;
+struct RawEnv {  // what the state loads returned: unchanged halves of a record are not stored back
     int4 lo[JPL], hi[JPL];
     int tm;
 };
 
+// Rows j < jlimit of the env's job records + its machine clocks.  Lanes behind the limit issue no request and hold
+// the record of a job that does not exist (todo 0, no op, nothing running) -- which is also what reset() leaves in
+// the rows between J(env) and jmax, so nothing has to be masked after the load.
 template <int JPL>
-__device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params &p, int jlimit) {   // rows j < jlimit
+__device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params &p, int jlimit) {
     RawEnv<JPL> r;
-    const int jm = jlimit;
-    r.h = *reinterpret_cast<const int4 *>(p.s.env + (size_t)b * 4);
     const int32_t *jb = p.s.job + (size_t)b * p.d.jmax * JSS_NF;
     r.tm = ld_off<int>(p.s.machine + (size_t)b * p.d.mmax, (unsigned)(lane < p.d.mmax ? lane : 0) * 4u);
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + lane;
-        r.lo[s] = r.hi[s] = make_int4(0, -1, 0, 0);
-        if (j < jm) {                                                    // lanes behind the limit issue no request
+        r.lo[s] = make_int4(0, -1, 0, 0);
+        r.hi[s] = make_int4(0, 0, 0, -1);
+        if (j < jlimit) {
             r.lo[s] = ld_off<int4>(jb, (unsigned)j * 32u);
             r.hi[s] = ld_off<int4>(jb, (unsigned)j * 32u + 16u);
         }
@@ -545,173 +581,244 @@ __device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params
 }
 
 template <int JPL>
-__device__ __forceinline__ Header unpack_env(Env<JPL> &e, const Ctx &c, const RawEnv<JPL> &r) {
-    Header hd;
-    const int status = __builtin_amdgcn_readfirstlane(r.h.w);
-    hd.episode = __builtin_amdgcn_readfirstlane(r.h.y);
-    hd.step = __builtin_amdgcn_readfirstlane(r.h.z);
-    e.t = __builtin_amdgcn_readfirstlane(r.h.x);
+__device__ __forceinline__ RawEnv<JPL> blank_raw() {                      // reset: nothing is read, everything is written
+    RawEnv<JPL> r;
+    r.tm = 0;
+#pragma unroll
+    for (int s = 0; s < JPL; ++s) {
+        r.lo[s] = make_int4(0, -1, 0, 0);
+        r.hi[s] = make_int4(0, 0, 0, -1);
+    }
+    return r;
+}
+
+template <int JPL>
+__device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawEnv<JPL> &r, int clock, int status) {
+    e.t = clock;
     e.err = status & 0xFF;
     e.noop = (status & JSS_STATUS_NOOP) ? 1 : 0;
     e.tm = c.lane < c.M ? r.tm : 0;
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
-        const int j = s * kWave + c.lane;
-        const bool v = j < c.J;
         const int4 lo = r.lo[s], hi = r.hi[s];
-        e.todo[s] = v ? (lo.x & JSS_TODO_MASK) : 0;
-        e.cur[s] = v ? lo.y : -1;
-        e.left[s] = v ? lo.z : 0;
-        e.perf[s] = v ? lo.w : 0;
-        e.idle[s] = v ? hi.x : 0;
-        e.idle_last[s] = v ? hi.y : 0;
-        e.f4[s] = v ? hi.z : 0;
-        e.nxt[s] = v ? hi.w : -1;
-        e.nxt2[s] = (v && ((unsigned)lo.x >> JSS_NEXT2_SHIFT)) ? (int)((unsigned)lo.x >> JSS_NEXT2_SHIFT) : -1;
-        e.legal[s] = __ballot(v && (lo.x & JSS_FLAG_LEGAL));
-        e.blocked[s] = __ballot(v && (lo.x & JSS_FLAG_BLOCKED));
+        e.todo[s] = lo.x & JSS_TODO_MASK;
+        e.cur[s] = lo.y;
+        e.left[s] = lo.z;
+        e.perf[s] = lo.w;
+        e.idle[s] = hi.x;
+        e.idle_last[s] = hi.y;
+        e.f4[s] = hi.z;
+        e.nxt[s] = hi.w;
+        const int n2 = (int)((unsigned)lo.x >> JSS_NEXT2_SHIFT);
+        e.nxt2[s] = n2 ? n2 : -1;
+        e.fill[s] = -1;
+        e.legal[s] = __ballot((lo.x & JSS_FLAG_LEGAL) != 0);
+        e.blocked[s] = __ballot((lo.x & JSS_FLAG_BLOCKED) != 0);
     }
-    return hd;
 }
 
+// action mask row: legal jobs, the NOPE flag at index J, zeros behind it
 template <int JPL>
-__device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p, const Header &hd,
-                                          const RawEnv<JPL> &raw) {
-    const int jm = p.d.jmax;
-    int32_t *jb = p.s.job + (size_t)c.b * jm * JSS_NF;
-    uint8_t *mk = p.o.action_mask + (size_t)c.b * (jm + 1);
-    if (c.lane == 0) {
-        *reinterpret_cast<int4 *>(p.s.env + (size_t)c.b * 4) =
-            make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
-        mk[jm] = (uint8_t)(c.J == jm ? e.noop : 0);                      // last byte of the row (lanes cover 0..jmax-1)
-    }
-    if (c.lane < c.M && e.tm != raw.tm) st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);   // idle machines stay 0
+__device__ __forceinline__ void store_mask(const Env<JPL> &e, const Ctx &c, uint8_t *mk, int jm) {
+    if (c.lane == 0) st_off<uint8_t>(mk, (unsigned)jm, (uint8_t)(c.J == jm ? e.noop : 0));   // last byte of the row
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
-        const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = (int)((e.blocked[s] >> c.lane) & 1);
-        if (j < c.J) {   // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
-            const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0) |
-                                          (e.nxt2[s] >= 0 ? (int)((unsigned)e.nxt2[s] << JSS_NEXT2_SHIFT) : 0), e.cur[s], e.left[s], e.perf[s]);
-            const int4 hi = make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]);
-            const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
-            if (lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w) st_off<int4>(jb, (unsigned)j * 32u, lo);
-            if (hi.x != hi0.x || hi.y != hi0.y || hi.z != hi0.z || hi.w != hi0.w) st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
-        }
-        // action mask: legal jobs, the NOPE flag at index J, zeros behind it
+        const int lg = (int)((e.legal[s] >> c.lane) & 1);
         if (j < jm) st_off<uint8_t>(mk, (unsigned)j, (uint8_t)(j < c.J ? lg : (j == c.J ? e.noop : 0)));
     }
 }
 
-// The (J,7) observation of jss_env.py:102-111, float32.  Every column is a function of the
-// integer state (column 4 of its own stored numerator: the reference writes it only when an
-// op finishes).  Transposed through LDS so the HBM write is jmax*7 contiguous floats.
+// State back to HBM.  all_rows = the env was (re)initialised: every row of the padded block is written (rows behind
+// J(env) as "no job"); otherwise rows < J(env), and of those only the halves that changed.
 template <int JPL>
-__device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, const Params &p, float *scratch, int rows) {
+__device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p, const Header &hd,
+                                          const RawEnv<JPL> &raw, bool all_rows) {
+    const int jm = p.d.jmax;
+    int32_t *jb = p.s.job + (size_t)c.b * jm * JSS_NF;
+    int32_t *hp = p.s.env + (size_t)c.b * JSS_NH;
+    if (c.lane == 0) {
+        *reinterpret_cast<int4 *>(hp) = make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
+        if (all_rows) {   // the instance constants of the env travel with it from here on (include/jss_hip.h JSS_H_*)
+            *reinterpret_cast<int4 *>(hp + 4) = make_int4(c.J, c.M, c.max_time_op, c.tid);
+            *reinterpret_cast<int4 *>(hp + 8) = make_int4(c.max_time_jobs, c.sum_op, as_int(c.r_op), as_int(c.r_jobs));
+            *reinterpret_cast<int4 *>(hp + 12) = make_int4(as_int(c.r_sum), as_int(c.r_m), 0, 0);
+        }
+    }
+    if (all_rows) {
+        if (c.lane < p.d.mmax) st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
+    } else if (c.lane < c.M && e.tm != raw.tm) {                         // idle machines stay 0
+        st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
+    }
+#pragma unroll
+    for (int s = 0; s < JPL; ++s) {
+        const int j = s * kWave + c.lane;
+        const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = (int)((e.blocked[s] >> c.lane) & 1);
+        const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0) |
+                                      (e.nxt2[s] >= 0 ? (int)((unsigned)e.nxt2[s] << JSS_NEXT2_SHIFT) : 0), e.cur[s], e.left[s], e.perf[s]);
+        const int4 hi = make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]);
+        if (all_rows) {
+            if (j < jm) {
+                st_off<int4>(jb, (unsigned)j * 32u, lo);
+                st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
+            }
+        } else if (j < c.J) {   // steps without a time advance touch few jobs
+            const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
+            if (lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w) st_off<int4>(jb, (unsigned)j * 32u, lo);
+            if (hi.x != hi0.x || hi.y != hi0.y || hi.z != hi0.z || hi.w != hi0.w) st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
+        }
+    }
+}
+
+// The (J,7) observation of jss_env.py:102-111, float32, to `dst` (first float of the env's [jmax][7] block).  Every
+// column is a function of the integer state (column 4 of its own stored numerator: the reference writes it only
+// when an op finishes).  Transposed through LDS so the HBM write is rows*7 contiguous floats; the LDS image is
+// shifted by the block's misalignment so that 16-byte lines of the image are 16-byte lines of the destination
+// (a 50-job block is 1400 bytes: every other env starts 8 bytes past a line) and everything but the first and
+// last line leaves as streaming dwordx4 stores.
+template <int JPL>
+__device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, float *dst, float *scratch, int rows) {
     // rows = jmax when the env is (re)initialised by a reset call, J(env) otherwise: the rows behind J are zeros
     // from that reset on and nothing ever changes them, so a step does not rewrite them (ragged, padded batches)
-    const int32_t *ir = p.d.inst + (size_t)c.tid * JSS_NI;
-    const float f_op = (float)c.max_time_op, f_jobs = (float)ir[JSS_I_MAX_TIME_JOBS], f_sum = (float)ir[JSS_I_SUM_OP];
-    const float f_m = (float)c.M;
-    const float r_op = as_float(ir[JSS_I_RCP_MAX_TIME_OP]), r_jobs = as_float(ir[JSS_I_RCP_MAX_TIME_JOBS]);
-    const float r_sum = as_float(ir[JSS_I_RCP_SUM_OP]), r_m = as_float(ir[JSS_I_RCP_MACHINES]);
+    const float f_op = (float)c.max_time_op, f_m = (float)c.M, f_jobs = (float)c.max_time_jobs, f_sum = (float)c.sum_op;
+    const int sh = (int)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3);   // floats past a 16-byte boundary (wave-uniform)
+    float *img = scratch + sh;
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         if (j < rows) {
             const bool v = j < c.J;  // padding rows are written as zeros
-            float *row = scratch + j * 7;
+            float *row = img + j * 7;
             row[0] = v ? (float)((e.legal[s] >> c.lane) & 1) : 0.f;                       // :130
-            row[1] = div_by((float)e.left[s], f_op, r_op);                               // :448, :539
-            row[2] = div_by((float)e.todo[s], f_m, r_m);                                 // :559
-            row[3] = div_by((float)e.perf[s], f_jobs, r_jobs);                           // :545
-            row[4] = e.f4[s] == JSS_F4_ONE ? 1.0f : div_by((float)e.f4[s], f_op, r_op);  // :569-586
-            row[5] = div_by((float)e.idle_last[s], f_sum, r_sum);                        // :555, :600
-            row[6] = div_by((float)e.idle[s], f_sum, r_sum);                             // :553, :601
+            row[1] = div_by((float)e.left[s], f_op, c.r_op);                             // :448, :539
+            row[2] = div_by((float)e.todo[s], f_m, c.r_m);                               // :559
+            row[3] = div_by((float)e.perf[s], f_jobs, c.r_jobs);                       // :545
+            row[4] = e.f4[s] == JSS_F4_ONE ? 1.0f : div_by((float)e.f4[s], f_op, c.r_op);  // :569-586
+            row[5] = div_by((float)e.idle_last[s], f_sum, c.r_sum);                    // :555, :600
+            row[6] = div_by((float)e.idle[s], f_sum, c.r_sum);                         // :553, :601
         }
     }
     wave_lds_sync();
-    float *dst = p.o.real_obs + (size_t)c.b * p.d.jmax * 7;
-    const int n = rows * 7;
-    int done = 0;
-    if ((((size_t)c.b * p.d.jmax * 7) & 3) == 0) {                       // 16-byte aligned row block: whole float4s first
-        for (int i = c.lane; i < (n >> 2); i += kWave)     // streaming store: whole lines, never read back (see st_nt)
-            st_nt(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
-        done = n & ~3;
+    float *dst0 = dst - sh;                                              // 16-byte aligned
+    const int end = sh + rows * 7;                                       // image floats [sh, end) are the block
+    for (int i = c.lane; i < ((end + 3) >> 2); i += kWave) {
+        const int lo = i << 2;
+        if (lo >= sh && lo + 4 <= end) {                                 // streaming store: whole lines, never read back (see st_nt)
+            st_nt(dst0, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lo + k >= sh && lo + k < end) st_off<float>(dst0, (unsigned)(lo + k) * 4u, scratch[lo + k]);
+        }
     }
-    for (int i = done + c.lane; i < n; i += kWave) st_off<float>(dst, (unsigned)i * 4u, scratch[i]);
     wave_lds_sync();
 }
 
-// ---------------------------------------------------------------------------------------
-// the kernel: one mode per instantiation
-// ---------------------------------------------------------------------------------------
-// Occupancy bound: 8 waves per SIMD keeps 8 192 envs (BASELINE config 4's share of one GPU) in ONE round of resident
-// waves; the price is an SGPR budget of 80, which the step/rollout modes overrun by 30-60 values that live in spare
-// VGPR lanes (v_writelane / v_readlane, no scratch).  JSS_WAVE_MIN_BLOCKS = 7 lifts the budget to 102 (A/B builds).
-// Two jobs per lane (J > 64) runs at 7 (5 for the multi-iteration rollout): more would spill VGPRs to scratch.
-#ifndef JSS_WAVE_MIN_BLOCKS
-#define JSS_WAVE_MIN_BLOCKS 8
-#endif
-template <int JPL, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE == kRollout1)
-                                         ? (JPL == 2 ? (MODE == kRollout ? 5 : 7) : JSS_WAVE_MIN_BLOCKS)
-                                         : 8) void jss_kernel(Params p) {
-    HIP_DYNAMIC_SHARED(int32_t, lds)
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // obs image of this wave, 16-byte aligned (table_lds_ints and obs_wave_floats are multiples of 4)
-    float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;
-
-    const int b_raw = blockIdx.x * kWavesPerBlock + wave;                 // one env per wave
-    const bool alive = b_raw < p.d.batch;
-    const int b = alive ? b_raw : p.d.batch - 1;
-    // 1. state loads first: they depend on nothing but the env index -- unless the batch is ragged (jmin < jmax):
-    //    then the instance record goes first (two scalar loads) and the rows behind J(env) are never requested
-    const bool ragged = p.d.jmin > 0 && p.d.jmin < p.d.jmax;
-    RawEnv<JPL> raw;
-    if (!ragged) raw = issue_loads<JPL>(b, lane, p, p.d.jmax);
-    int a_in = JSS_ACTION_SKIP;
-    if (MODE == kStep) a_in = __builtin_amdgcn_readfirstlane(p.actions[b]);
-    bool selected = true;
-    if ((MODE == kReset || MODE == kAdvance) && p.which) selected = __builtin_amdgcn_readfirstlane((int)p.which[b]) != 0;
-    // 2. instance record; the shared op table -> LDS
-    Ctx c;
-    c.b = b;
-    c.lane = lane;
-    c.tid = TAB == kTabLds ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : b);
-    const int32_t *ir = p.d.inst + (size_t)c.tid * JSS_NI;
+// The env's instance constants from the instance record (reset paths; step-type calls take them from the header)
+__device__ __forceinline__ void ctx_from_instance(Ctx &c, const Params &p, int tid) {
+    const int32_t *ir = p.d.inst + (size_t)tid * JSS_NI;
+    c.tid = tid;
     c.J = __builtin_amdgcn_readfirstlane(ir[JSS_I_JOBS]);
     c.M = __builtin_amdgcn_readfirstlane(ir[JSS_I_MACHINES]);
     c.max_time_op = __builtin_amdgcn_readfirstlane(ir[JSS_I_MAX_TIME_OP]);
-    c.stride = p.d.mmax;
-    if (ragged) raw = issue_loads<JPL>(b, lane, p, c.J);
-    if (TAB == kTabLds) {
-        stage_shared_table(lds, p.d.ops, c.J * p.d.mmax, (int)threadIdx.x);
-        __syncthreads();
-        c.tab = lds;
-    } else {
-        c.tab = p.d.ops + (size_t)c.tid * p.region_ints;
-    }
-    if (!alive) return;
+    c.max_time_jobs = __builtin_amdgcn_readfirstlane(ir[JSS_I_MAX_TIME_JOBS]);
+    c.sum_op = __builtin_amdgcn_readfirstlane(ir[JSS_I_SUM_OP]);
+    c.r_op = as_float(__builtin_amdgcn_readfirstlane(ir[JSS_I_RCP_MAX_TIME_OP]));
+    c.r_jobs = as_float(__builtin_amdgcn_readfirstlane(ir[JSS_I_RCP_MAX_TIME_JOBS]));
+    c.r_sum = as_float(__builtin_amdgcn_readfirstlane(ir[JSS_I_RCP_SUM_OP]));
+    c.r_m = as_float(__builtin_amdgcn_readfirstlane(ir[JSS_I_RCP_MACHINES]));
+}
 
+template <int TAB>
+__device__ __forceinline__ void ctx_table(Ctx &c, const Params &p, const int32_t *lds) {
+    c.stride = p.d.mmax;
+    c.tab = TAB == kTabLds ? lds : p.d.ops + (size_t)c.tid * p.region_ints;
+}
+
+// The 16 header words of env b as wave-uniform values (scalar loads: nothing in this kernel has written them yet)
+struct HeaderWords {
+    int clock, episode, step, status, J, M, max_time_op, tid;
+    int max_time_jobs, sum_op, r_op, r_jobs, r_sum, r_m;
+};
+__device__ __forceinline__ HeaderWords load_header(const Params &p, int b) {
+    const int32_t *hp = p.s.env + (size_t)b * JSS_NH;
+    HeaderWords h;
+    h.clock = hp[JSS_H_CLOCK];
+    h.episode = hp[JSS_H_EPISODE];
+    h.step = hp[JSS_H_STEP];
+    h.status = hp[JSS_H_STATUS];
+    h.J = hp[JSS_H_JOBS];
+    h.M = hp[JSS_H_MACHINES];
+    h.max_time_op = hp[JSS_H_MAX_TIME_OP];
+    h.tid = hp[JSS_H_TABLE];
+    h.max_time_jobs = hp[JSS_H_MAX_TIME_JOBS];
+    h.sum_op = hp[JSS_H_SUM_OP];
+    h.r_op = hp[JSS_H_RCP_MAX_TIME_OP];
+    h.r_jobs = hp[JSS_H_RCP_MAX_TIME_JOBS];
+    h.r_sum = hp[JSS_H_RCP_SUM_OP];
+    h.r_m = hp[JSS_H_RCP_MACHINES];
+    return h;
+}
+__device__ __forceinline__ void ctx_from_header(Ctx &c, const HeaderWords &h) {
+    c.J = __builtin_amdgcn_readfirstlane(h.J);
+    c.M = __builtin_amdgcn_readfirstlane(h.M);
+    c.max_time_op = __builtin_amdgcn_readfirstlane(h.max_time_op);
+    c.tid = __builtin_amdgcn_readfirstlane(h.tid);
+    c.max_time_jobs = __builtin_amdgcn_readfirstlane(h.max_time_jobs);
+    c.sum_op = __builtin_amdgcn_readfirstlane(h.sum_op);
+    c.r_op = as_float(__builtin_amdgcn_readfirstlane(h.r_op));
+    c.r_jobs = as_float(__builtin_amdgcn_readfirstlane(h.r_jobs));
+    c.r_sum = as_float(__builtin_amdgcn_readfirstlane(h.r_sum));
+    c.r_m = as_float(__builtin_amdgcn_readfirstlane(h.r_m));
+}
+
+// ---------------------------------------------------------------------------------------
+// one env, one mode: everything behind "the header words are on their way"
+// ---------------------------------------------------------------------------------------
+template <int JPL, int MODE, int TAB>
+__device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderWords &h, bool ragged, int a_in,
+                                          const int32_t *lds, float *scratch) {
+    const int b = c.b, lane = c.lane;
+    Header hd;
     Env<JPL> e;
-    Header hd = unpack_env(e, c, raw);
+    RawEnv<JPL> raw;
+    bool fresh = false;                                                  // the env was (re)initialised by this call
     if (MODE == kReset) {
-        if (!selected) return;
-        hd.episode += 1;
+        // nothing of the old state is needed but the episode counter
+        raw = blank_raw<JPL>();
+        hd.episode = __builtin_amdgcn_readfirstlane(h.episode) + 1;
         hd.step = 0;
+        ctx_table<TAB>(c, p, lds);
         reset_env(e, c, p);
+        fresh = true;
         if (lane == 0) {
             p.o.reward[b] = 0.f;
             p.o.done[b] = 0;
         }
-    } else if (MODE == kStep) {
+    } else {
+        // 1. state loads: their addresses depend on nothing but the env index -- unless the batch is ragged
+        //    (jmin < jmax): then the rows behind J(env), known from the header, are never requested
+        if (!ragged) raw = issue_loads<JPL>(b, lane, p, p.d.jmax);
+        ctx_from_header(c, h);
+        if (ragged) raw = issue_loads<JPL>(b, lane, p, c.J);
+        if (c.J == 0) return;                                            // never reset: nothing to step
+        ctx_table<TAB>(c, p, lds);
+        hd.episode = __builtin_amdgcn_readfirstlane(h.episode);
+        hd.step = __builtin_amdgcn_readfirstlane(h.step);
+        unpack_env(e, c, raw, __builtin_amdgcn_readfirstlane(h.clock), __builtin_amdgcn_readfirstlane(h.status));
+    }
+
+    if (MODE == kStep) {
         const bool restart = a_in == JSS_ACTION_RESET;                   // reset() this env instead of stepping it
         if (restart) {
+            // the env may have been given another instance since its last reset (table_of_env)
+            const int tid = TAB == kTabLds ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : c.tid);
+            ctx_from_instance(c, p, tid);
+            ctx_table<TAB>(c, p, lds);
             hd.episode += 1;
             hd.step = 0;
             reset_env(e, c, p);
+            fresh = true;
             if (lane == 0) {
                 p.o.reward[b] = 0.f;
                 p.o.done[b] = 0;
@@ -728,7 +835,6 @@ __global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE 
             if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
         }
     } else if (MODE == kAdvance) {
-        if (!selected) return;
         int hole = 0;
         if (__ballot(e.tm > 0) == 0) e.err |= JSS_ERR_NOPE_IDLE;        // reference: IndexError (:517)
         else hole = advance(e, c);
@@ -738,14 +844,29 @@ __global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE 
                                     (uint32_t)hd.episode, (uint32_t)hd.step);
         if (lane == 0) p.actions_out[b] = a;
         return;
-    } else {  // kRollout / kRollout1: n_iter x (policy + step), state stays in registers
+    } else if (MODE == kRollout || MODE == kRollout1 || MODE == kTraj) {
+        // n_iter x (policy + step), state stays in registers; kTraj also records every iteration (JssTraj)
         const uint64_t env_id = (uint64_t)(p.d.env_ids ? p.d.env_ids[b] : p.d.env_id_base + b);
         int n_steps = 0, n_done = 0, sum_makespan = 0, sum_rn = 0;
         int last_rn = 0, last_makespan = -1;
         const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;
         for (int it = 0; it < n_iter; ++it) {
+            const size_t slot = (size_t)it * p.d.batch + b;              // kTraj: [it][b]
+            if (MODE == kTraj) {                                         // what the policy sees in this slot
+                if (p.t.real_obs) store_obs(e, c, p.t.real_obs + slot * p.d.jmax * 7, scratch, c.J);
+                if (p.t.action_mask) store_mask(e, c, p.t.action_mask + slot * (p.d.jmax + 1), p.d.jmax);
+            }
             if (!any_legal(e)) {                                         // done (:639-653)
-                if (!(p.flags & JSS_ROLLOUT_AUTORESET)) break;           // frozen
+                const bool autoreset = (p.flags & JSS_ROLLOUT_AUTORESET) != 0;
+                if (MODE == kTraj && lane == 0) {
+                    if (p.t.action) p.t.action[slot] = autoreset ? JSS_ACTION_RESET : JSS_ACTION_SKIP;
+                    if (p.t.reward) p.t.reward[slot] = 0.f;
+                    if (p.t.done) p.t.done[slot] = autoreset ? 0 : 1;
+                }
+                if (!autoreset) {
+                    if (MODE == kTraj) continue;                         // frozen: every remaining slot says so
+                    break;
+                }
                 reset_env(e, c, p);
                 hd.episode += 1;
                 hd.step = 0;
@@ -756,10 +877,16 @@ __global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE 
             hd.step += 1;
             n_steps += 1;
             sum_rn += last_rn;
-            if (!any_legal(e)) {
+            const bool done = !any_legal(e);
+            if (done) {
                 n_done += 1;
                 sum_makespan += e.t;
                 last_makespan = e.t;
+            }
+            if (MODE == kTraj && lane == 0) {
+                if (p.t.action) p.t.action[slot] = a;
+                if (p.t.reward) p.t.reward[slot] = (float)last_rn / (float)c.max_time_op;
+                if (p.t.done) p.t.done[slot] = done ? 1 : 0;
             }
         }
         if (lane == 0) {
@@ -769,8 +896,64 @@ __global__ __launch_bounds__(kBlock, (MODE == kStep || MODE == kRollout || MODE 
             if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, n_steps, n_done, sum_makespan, sum_rn);
         }
     }
-    store_env(e, c, p, hd, raw);
-    if (!JSS_ABLATED(p, JSS_ABLATE_OBS)) store_obs(e, c, p, scratch, MODE == kReset ? p.d.jmax : c.J);
+    store_env(e, c, p, hd, raw, fresh);
+    store_mask(e, c, p.o.action_mask + (size_t)b * (p.d.jmax + 1), p.d.jmax);
+    if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
+        store_obs(e, c, p.o.real_obs + (size_t)b * p.d.jmax * 7, scratch, fresh ? p.d.jmax : c.J);
+}
+
+// ---------------------------------------------------------------------------------------
+// the kernel: one mode per instantiation
+// ---------------------------------------------------------------------------------------
+// Occupancy bound: 8 waves per SIMD keeps 8 192 envs (BASELINE config 4's share of one GPU) in ONE round of resident
+// waves; the price is an SGPR budget of 80, which the step/rollout modes overrun by values that live in spare
+// VGPR lanes (v_writelane / v_readlane, no scratch).  JSS_WAVE_MIN_BLOCKS = 7 lifts the budget to 102 (A/B builds).
+// Two jobs per lane (J > 64) runs at 7 (5 for the multi-iteration rollout): more would spill VGPRs to scratch.
+// A batch padded to more than 64 jobs is compiled with two jobs per lane, but every wave whose own env has
+// J <= 64 (70 of 80 Taillard instances in the mixed ta01-ta80 batch) runs the one-job-per-lane body.
+#ifndef JSS_WAVE_MIN_BLOCKS
+#define JSS_WAVE_MIN_BLOCKS 8
+#endif
+template <int JPL, int MODE, int TAB>
+__global__ __launch_bounds__(kBlock, MODE == kTraj ? (JPL == 2 ? 4 : 6)
+                                     : (MODE == kStep || MODE == kRollout || MODE == kRollout1)
+                                         ? (JPL == 2 ? (MODE == kRollout ? 5 : 7) : JSS_WAVE_MIN_BLOCKS)
+                                         : 8) void jss_kernel(Params p) {
+    HIP_DYNAMIC_SHARED(int32_t, lds)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // obs image of this wave, 16-byte aligned (table_lds_ints and obs_wave_floats are multiples of 4)
+    float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;
+
+    const int b_raw = blockIdx.x * kWavesPerBlock + wave;                 // one env per wave
+    const bool alive = b_raw < p.d.batch;
+    const int b = alive ? b_raw : p.d.batch - 1;
+    Ctx c;
+    c.b = b;
+    c.lane = lane;
+    const HeaderWords h = load_header(p, b);
+    int a_in = JSS_ACTION_SKIP;
+    if (MODE == kStep) a_in = __builtin_amdgcn_readfirstlane(p.actions[b]);
+    bool selected = true;
+    if ((MODE == kReset || MODE == kAdvance) && p.which) selected = __builtin_amdgcn_readfirstlane((int)p.which[b]) != 0;
+    if (TAB == kTabLds) {                                                // one instance for the whole batch: its op table -> LDS
+        stage_shared_table(lds, p.d.ops, p.d.inst[JSS_I_JOBS] * p.d.mmax, (int)threadIdx.x);
+        __syncthreads();
+    }
+    if (!alive || !selected) return;
+    const bool ragged = p.d.jmin > 0 && p.d.jmin < p.d.jmax;
+    if (MODE == kReset) {
+        const int tid = TAB == kTabLds ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : b);
+        ctx_from_instance(c, p, tid);
+        if (JPL == 2 && c.J <= kWave) wave_main<1, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
+        else wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
+    } else {
+        // (a restart may hand the env a wider instance: it takes the full-width body)
+        if (JPL == 2 && ragged && !(MODE == kStep && a_in == JSS_ACTION_RESET) && __builtin_amdgcn_readfirstlane(h.J) <= kWave)
+            wave_main<1, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
+        else
+            wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
+    }
 }
 
 }  // namespace jss

@@ -280,7 +280,8 @@ class BatchedJssEnv:
             self._env_ids = None
             # state (include/jss_hip.h JssState)
             J, M = self.jmax, self.mmax
-            self.env_header = be.zeros((B, 4), "int32")          # clock, episode, step_in_episode, status
+            # clock, episode, step_in_episode, status + the env's instance constants (written by reset): 64 bytes
+            self.env_header = be.zeros((B, _abi.NH), "int32")
             self.job_state = be.zeros((B, J, _abi.NF), "int32")  # one 32-byte record per job
             self.machine_state = be.zeros((B, M), "int32")
             self.solution = be.zeros((B, J, M), "int32")
@@ -394,6 +395,8 @@ class BatchedJssEnv:
     def increase_time_step(self, which=None):
         """increase_time_step() of jss_env.py:495-637 per env; returns hole_planning (B,) int32 (the env's own
         buffer, overwritten by the next call)."""
+        if not self._is_reset:
+            raise RuntimeError("call reset() before increase_time_step()")
         be = self.backend
         d, s, o = self._refs()
         with be.on_device():
@@ -404,6 +407,8 @@ class BatchedJssEnv:
     def policy(self, kind: Union[str, int] = "random", seed: Optional[int] = None, explore: float = 0.0):
         """Per-env action from the on-device selectors (random masked, FIFO, SPT, MWR, LWR, MOR, LOR, CR).
         Returns the env's own (B,) int32 action buffer (overwritten by the next policy() call)."""
+        if not self._is_reset:
+            raise RuntimeError("call reset() before policy()")
         be = self.backend
         k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
         d, s, _ = self._refs()
@@ -449,11 +454,51 @@ class BatchedJssEnv:
         _abi.check(be.lib, rc, "jss_rollout_steps")
         return self._obs(), self.reward, self.done, False, {}
 
+    def trajectory(self, kind: Union[str, int] = "random", steps: int = 1, seed: Optional[int] = None,
+                   autoreset: bool = True, explore: float = 0.0, buffers: Optional[dict] = None,
+                   record=("real_obs", "action_mask", "action", "reward", "done")):
+        """``steps`` x (policy + step) per env in ONE launch, like ``rollout(n_iter=steps)``, with every iteration's
+        transition written out step-major: ``real_obs`` (K, B, J, 7) and ``action_mask`` (K, B, J + 1) = what the
+        policy saw in slot k, ``action`` (K, B) what it did (``-2``: the env was found done and was reset instead --
+        gymnasium.vector next-step auto-reset; ``-1``: found done with autoreset off), ``reward`` / ``done`` (K, B)
+        what it got.  State is read and written once per call: the (s, a, r, d) stream of a scripted / random
+        behaviour policy without K launch boundaries and K - 1 state round trips.
+
+        ``buffers`` (the dict a previous call returned) is reused when its shapes fit; otherwise zero-filled
+        tensors are allocated here (outside the hot loop: allocate once, pass them back in)."""
+        if not self._is_reset:
+            raise RuntimeError("call reset() before trajectory()")
+        be = self.backend
+        K, B, J = int(steps), self.batch, self.jmax
+        shapes = {"real_obs": ((K, B, J, 7), "float32"), "action_mask": ((K, B, J + 1), "uint8"),
+                  "action": ((K, B), "int32"), "reward": ((K, B), "float32"), "done": ((K, B), "uint8")}
+        out = {}
+        with be.on_device():
+            for name in record:
+                shape, dtype = shapes[name]
+                t = None if buffers is None else buffers.get(name)
+                out[name] = t if t is not None and tuple(t.shape) == shape else be.zeros(shape, dtype)
+        k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
+        flags = _abi.ROLLOUT_AUTORESET if autoreset else 0
+        traj = _abi.JssTraj(*[be.ptr(out.get(n)) for n in ("real_obs", "action_mask", "action", "reward", "done")])
+        d, s, o = self._refs()
+        with be.on_device():
+            _abi.check(be.lib, be.lib.jss_trajectory(d, s, o, C.byref(traj), k, self.seed if seed is None else int(seed),
+                                                     int(round(explore * 65536)), K, flags, be.stream()),
+                       "jss_trajectory")
+        return out
+
+    def sync_check(self):
+        """Wait for the env's stream and raise if a kernel faulted (the launching calls only report launch errors)."""
+        be = self.backend
+        with be.on_device():
+            _abi.check(be.lib, be.lib.jss_sync_check(be.stream()), "jss_sync_check")
+
     def synchronize(self):
         self.backend.sync()
 
     def close(self):
-        """Wait for outstanding work and drop the side streams this env's own backend created."""
+        """Wait for outstanding work (the side streams of rollout_steps are process-wide and stay)."""
         self.synchronize()
         if self._owns_backend:
             self.backend.close()

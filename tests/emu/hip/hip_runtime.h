@@ -42,6 +42,7 @@ typedef void *hipStream_t;
 #define hipSuccess 0
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipPeekAtLastError() { return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 #define hipDeviceAttributeMultiprocessorCount 0
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }

@@ -545,6 +545,14 @@ def case_instance_resampling(backend):
     orcs[4].episode = 3
     row = env.backend.numpy(env.action_mask)[4]
     assert row[:15].all() and not row[15:].any(), row
+    # ... and so must the rows behind the new J of every state tensor: nothing of the larger instance survives a reset
+    js = env.backend.numpy(env.job_state)[4]
+    assert (js[15:, _abi.F_CUR] == -1).all() and (js[15:, _abi.F_NEXT] == -1).all(), js[15:]
+    assert not js[15:, [_abi.F_TODO, _abi.F_LEFT, _abi.F_PERF, _abi.F_IDLE, _abi.F_IDLE_LAST, _abi.F_F4]].any(), js[15:]
+    assert (env.backend.numpy(env.solution)[4] == -1).all()
+    assert not env.backend.numpy(env.machine_state)[4].any()
+    hdr = env.backend.numpy(env.env_header)[4]
+    assert hdr[_abi.H_JOBS] == 15 and hdr[_abi.H_MACHINES] == 15 and hdr[_abi.H_TABLE] == 0, hdr
     step_all(10)
     for i, o in enumerate(orcs):
         assert_matches_oracle(env.host_state(i), o, f"after larger->smaller reassignment, env {i}")
@@ -584,6 +592,61 @@ def case_rollout_steps(backend, batch=150, steps=6, n_sub=3, seed=31):
         raise AssertionError("n_sub > 16 must be rejected")
     except ValueError:
         pass
+
+
+def case_trajectory(backend, instances="ta01", batch=9, steps=40, kind="random", seed=17, explore=0.0, autoreset=True,
+                    warm=0, table_of_env=None):
+    """jss_trajectory (K steps per launch, every transition recorded) against K x (jss_policy, jss_step with next-step
+    auto-reset) on a twin env: slot by slot the observation and mask the policy saw, the action it took (-2 where
+    the env was found done and reset), reward and done; afterwards every state tensor and counter bit-identical to
+    both that env and one advanced by jss_rollout(n_iter = K), the call jss_trajectory is defined as.
+    (The step-by-step path itself is held to the oracle by case_batch_lockstep.)"""
+    kw = dict(batch=batch, seed=seed, env_id_base=5, _backend=backend, table_of_env=table_of_env)
+    a = BatchedJssEnv(instances, **kw)
+    b = BatchedJssEnv(instances, **kw)
+    a.reset()
+    b.reset()
+    if warm:
+        a.rollout(kind, n_iter=warm, explore=explore, autoreset=autoreset)
+        b.rollout(kind, n_iter=warm, explore=explore, autoreset=autoreset)
+    n = a.backend.numpy
+    tr = a.trajectory(kind, steps=steps, explore=explore, autoreset=autoreset)
+    tr = {k: n(v) for k, v in tr.items()}
+    J = a.jobs_per_env
+    n_real = 0
+    for k in range(steps):
+        obs, mask, done_before = n(b.real_obs), n(b.action_mask), n(b.done).astype(bool)
+        for i in range(batch):
+            assert np.array_equal(tr["real_obs"][k, i, :J[i]], obs[i, :J[i]]), f"slot {k} env {i}: observation"
+            assert not tr["real_obs"][k, i, J[i]:].any()
+            assert np.array_equal(tr["action_mask"][k, i], mask[i]), f"slot {k} env {i}: mask"
+        act = n(b.policy(kind, explore=explore)).astype(np.int32)
+        if autoreset:
+            want_a = np.where(done_before, _abi.ACTION_RESET, act)
+            b.step(act, autoreset=True)
+        else:
+            want_a = np.where(done_before, _abi.ACTION_SKIP, act)
+            b.step(want_a)
+        assert np.array_equal(tr["action"][k], want_a), f"slot {k}: actions {tr['action'][k]} vs {want_a}"
+        rew, done = n(b.reward), n(b.done)
+        stepped = want_a >= 0
+        n_real += int(stepped.sum())
+        assert np.array_equal(tr["reward"][k][stepped], rew[stepped]), f"slot {k}: reward"
+        assert not tr["reward"][k][~stepped].any()
+        want_done = np.where(stepped, done, 0 if autoreset else 1)
+        assert np.array_equal(tr["done"][k], want_done), f"slot {k}: done"
+    c = BatchedJssEnv(instances, **kw)            # ... and the call it is defined as: jss_rollout(n_iter = steps)
+    c.reset()
+    if warm:
+        c.rollout(kind, n_iter=warm, explore=explore, autoreset=autoreset)
+    c.rollout(kind, n_iter=steps, explore=explore, autoreset=autoreset)
+    for name in BatchedJssEnv._STATE_TENSORS:
+        x, y, z = n(getattr(a, name)), n(getattr(b, name)), n(getattr(c, name))
+        assert np.array_equal(x, z), f"trajectory differs from rollout(n_iter={steps}) in {name}"
+        if name != "reward":                       # (a reset slot leaves the last real step's reward in `out`, jss_step writes 0)
+            assert np.array_equal(x, y), f"trajectory differs from policy + step x {steps} in {name}"
+    assert a.stats()["steps"] == b.stats()["steps"] and n_real > 0
+    return a
 
 
 # -----------------------------------------------------------------------------------------

@@ -85,6 +85,12 @@ def test_bucketed_and_rollout_steps(cpu):
     P.case_rollout_steps(cpu, batch=150, steps=30, n_sub=3)
 
 
+def test_trajectory(cpu):
+    P.case_trajectory(cpu, "ta01", batch=9, steps=60, kind="random", warm=200)
+    P.case_trajectory(cpu, ["ta01", "ta31", "ta71"], batch=7, steps=40, kind="SPT", explore=0.2)
+    P.case_trajectory(cpu, "ta01", batch=4, steps=12, kind="FIFO", warm=220, autoreset=False)
+
+
 def test_config1_ta01_fifo_on_cpu(cpu):
     """BASELINE config 1: ta01 single env on CPU, FIFO dispatching rule to completion -- through the reference's own
     call shape (make + rule(env) + step), no GPU anywhere.  225 steps, makespan 1486 (golden G3)."""

@@ -51,6 +51,14 @@ def test_rollout_ragged(hip):
     P.case_rollout(hip, ["ta02", "ta72"], batch=4, n_iter=0, chunks=(400,), kind="SPT", autoreset=False)
 
 
+def test_trajectory_equals_policy_plus_step(hip):
+    """jss_trajectory: K steps per launch, every transition recorded, == K x (jss_policy, jss_step)."""
+    P.case_trajectory(hip, "ta01", batch=130, steps=300, kind="random", warm=150)       # shared table, crosses episode ends
+    P.case_trajectory(hip, ["ta01", "ta31", "ta51", "ta71"], batch=11, steps=120, kind="SPT", explore=0.2)   # ragged
+    P.case_trajectory(hip, ["ta02", "ta03", "ta04"], batch=9, steps=260, kind="random")  # env -> instance map, global tables
+    P.case_trajectory(hip, "ta41", batch=6, steps=40, kind="FIFO", warm=590, autoreset=False)
+
+
 def test_rule_makespans(hip):
     """G3: ta01 FIFO 1486 / SPT 1462, ta41 SPT 2499 ... as captured from the live reference."""
     P.case_rule_makespans(hip, insts=("ta01", "ta41", "ta80"))

@@ -108,3 +108,12 @@ def test_rollout_steps_equals_rollout(emu):
 
 def test_nope_fuzz_tiny_instances(emu):
     P.case_nope_fuzz(emu, batch=8, steps=30)
+
+
+def test_trajectory_equals_policy_plus_step(emu):
+    P.case_trajectory(emu, "ta01", batch=9, steps=40, kind="random", warm=200)          # crosses episode ends
+    P.case_trajectory(emu, ["ta01", "ta31", "ta71"], batch=5, steps=25, kind="SPT", explore=0.2)   # ragged, two jobs per lane
+
+
+def test_trajectory_frozen_without_autoreset(emu):
+    P.case_trajectory(emu, "ta01", batch=4, steps=12, kind="FIFO", warm=220, autoreset=False)
