@@ -13,25 +13,40 @@ an env step).  A pass is ONE launch over the batch, or -- whichever a short prob
 over n_sub contiguous sub-batches on n_sub HIP streams (jss_rollout_steps): step s of a sub-batch depends only on
 its own step s-1, so one sub-batch's drain overlaps another's fill; results are identical either way.
 
-Timing: W untimed warm-up steps, then >= 5 windows of EXACTLY K steps, each bracketed by barrier +
+Timing: W untimed warm-up steps, then windows of EXACTLY K steps, each bracketed by barrier +
 torch.cuda.synchronize() on both sides; per window the wall time is the MAX over ranks and the env steps the SUM
-over ranks (one RCCL all-reduce each, outside the timed region).  value = median window; min/max are printed too.
+over ranks (one RCCL all-reduce each, outside the timed region).  As many windows as it takes for the timed total to
+reach 50 ms (at least 5, at most 400): the driver's K = 20 makes a window 0.4 ms, and five of those are noise.
+value = median window; n / min / max are printed too.  roofline.frac is value x algorithmic bytes / peak -- the
+wall-clock number anybody can recompute from the line; the HIP-event figure is kept as roofline.frac_gpu_time.
 
 Workload: BASELINE.json configs[1] shape (ta01, 15x15, one shared instance, random masked policy) at the
 north_star's target batch of 65 536 envs per GPU (weak scaling: every rank owns its own 65 536 envs, no data-path
-collective).  Extras on the same line (N = 1): the plain one-launch-per-step figure, 4x the batch (beyond the
-256 MB Infinity Cache), per-env synthetic 15x15 tables, BASELINE configs 2-5, the fused 64-step rollout.
+collective).  Extras on the same line (N = 1): the plain one-launch-per-step figure, jss_step alone with resident
+actions (step_only), the K-steps-per-launch trajectory mode, the B = 1 facade's microseconds per step(), 4x the batch
+(beyond the 256 MB Infinity Cache), per-env synthetic 15x15 tables, BASELINE configs 2-5, the fused 64-step rollout.
 
-Extra objects: roofline (HBM; algorithmic bytes per step / HIP-event time per step), cpu_baseline (the C oracle
-of oracle/, kind "port") and cpu_baseline_twin (libjss_cpu.so, 1 core and all cores), timed on this box's host cores,
-rank 0, N = 1.
+With N > 1 the same line also carries config4_sharded: BASELINE config 4 as it is defined -- synthetic 50x20, 65 536
+envs split over the N ranks by shard_bounds (strong scaling) -- measured after the weak-scaling headline.
+
+Extra objects: roofline (HBM), cpu_baseline = the Python / NumPy restatement of the reference's step() on one host
+core (kind "restatement": the stand-in for the reference's own speed, which cannot travel to this box),
+cpu_baseline_port (the C oracle, one env per thread) and cpu_baseline_twin (libjss_cpu.so, 1 core and all cores),
+all timed on this box's host cores in this run, rank 0, N = 1.
 """
 import argparse
+import hashlib
 import json
+import math
 import os
 import socket
 import sys
 import time
+
+# Completion signals are polled instead of waited for through interrupts: a 20-step window is 0.25-0.4 ms of GPU
+# work, and the interrupt path adds tens of microseconds to every synchronize().  Process-wide HSA runtime setting,
+# must be in the environment before the runtime starts; reported in the JSON line (host.hsa_enable_interrupt).
+os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -39,7 +54,18 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED_PEAK_GBS = 6290.0  # measured copy bandwidth, same guide (SURVEY.md 8(d) asks for both)
-N_WINDOWS = 5
+MIN_WINDOWS, MAX_WINDOWS, MIN_TIMED_SECONDS = 5, 400, 0.05
+
+
+def csrc_hash():
+    """sha256 over the kernel sources + ABI header: ties the static counter numbers in profiles/hbm_traffic.json to
+    the binary they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "jssenv_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/jss_hip.h"]:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def b_alg(J, M):
@@ -74,6 +100,27 @@ def usable_threads():
         return max(1, int(h["cgroup_quota_cores"] + 0.5))
     return h["affinity"] or h["logical"] or 1
 
+
+
+def cpu_baseline_restatement(inst_name, seed, target_seconds=10.0):
+    """The reference's own way of doing a step -- Python loops over NumPy arrays, one env, one core
+    (oracle/np_restatement.py: attribute-for-attribute restatement of jss_env.py:121-653, pinned bit-exactly to the
+    reference's golden traces; in the build container it runs at the live reference's speed) -- driven by the
+    README's random masked loop."""
+    import numpy as np
+    from jssenv_amd import builtin_instance
+    from oracle.np_restatement import NumpyJssEnv, random_masked_episode
+    env = NumpyJssEnv(builtin_instance(inst_name))
+    rng = np.random.default_rng(seed)
+    random_masked_episode(env, rng)                      # warm
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < target_seconds:
+        steps += random_masked_episode(env, rng)
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env steps/s", "cores": 1, "kind": "restatement",
+            "sample": f"{inst_name}, random masked policy (README.md:53-64) + step() to completion, whole episodes for "
+                      f"{dt:.1f} s ({steps} env steps), single env, one core, Python {sys.version_info[0]}.{sys.version_info[1]} + NumPy",
+            "implementation": "oracle/np_restatement.py (Python loops over NumPy arrays, like JSSEnv/envs/jss_env.py)"}
 
 
 def cpu_baseline_port(inst_name, seed, target_seconds=8.0):
@@ -275,14 +322,18 @@ def main():
         return e
 
     # ---- timing ---------------------------------------------------------------------------------------------
-    def window(env, policy, n_launch, n_iter, mode, graph=None):
+    def window(env, policy, n_launch, n_iter, mode, graph=None, run=None, prep=None):
         """Time n_launch steps.  Returns (wall seconds, GPU ms per step from HIP events on the launch stream)."""
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if prep is not None:
+            prep()                             # untimed: e.g. put the state back where a recorded action trace starts
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record()
-        if graph is not None:
+        if run is not None:
+            run(n_launch)
+        elif graph is not None:
             graph.replay()
         elif hasattr(env, "rollout_steps") and mode.startswith("sub"):
             env.rollout_steps(policy, steps=n_launch, n_sub=int(mode[3:]), autoreset=True)
@@ -327,14 +378,19 @@ def main():
             print(f"launch-mode probe (s per {n_probe} steps): " + ", ".join(f"{m} {t:.6f}" for m, t in zip(candidates, probe)), file=sys.stderr)
         return candidates[probe.index(min(probe))]
 
-    def measure(env, policy, steps, mode, n_iter=1, windows=N_WINDOWS):
-        """`windows` windows of `steps` steps each.  Returns the per-window lists, already reduced over ranks."""
+    def measure(env, policy, steps, mode, n_iter=1, windows=None, run=None, prep=None):
+        """Windows of `steps` steps each -- as many as it takes for the timed total to reach MIN_TIMED_SECONDS (between
+        MIN_WINDOWS and MAX_WINDOWS; every rank takes the same number).  Returns the median window and all windows,
+        already reduced over ranks.  `run(n)` overrides what a window executes (extras)."""
         graph = capture(env, policy, steps) if mode == "graph" else None
-        window(env, policy, steps, n_iter, mode, graph)     # untimed: side streams / graph exist before the first window
+        first = window(env, policy, steps, n_iter, mode, graph, run, prep)   # untimed: side streams / graph exist before the first window
+        if windows is None:
+            t_win = agree_max([first[0]])[0]
+            windows = int(min(MAX_WINDOWS, max(MIN_WINDOWS, math.ceil(MIN_TIMED_SECONDS / max(t_win, 1e-6)))))
         rows = []
         for _ in range(windows):
             env.zero_counters()
-            dt, ms = window(env, policy, steps, n_iter, mode, graph)
+            dt, ms = window(env, policy, steps, n_iter, mode, graph, run, prep)
             tot = reduce_counters(env.counter_totals().cpu() if on_host else env.counter_totals(), dt)
             ms = agree_max([ms])[0]
             rows.append({"steps": tot["steps"], "seconds": tot["seconds"], "rate": tot["steps"] / tot["seconds"],
@@ -344,6 +400,10 @@ def main():
         rows.sort(key=lambda r: r["rate"])
         med = rows[len(rows) // 2]
         return med, rows
+
+    def window_stats(rows, steps):
+        return {"n": len(rows), "steps_each": steps, "statistic": "median", "min": rows[0]["rate"], "max": rows[-1]["rate"],
+                "timed_seconds_total": sum(r["seconds"] for r in rows)}
 
     def launch_label(mode):
         if mode.startswith("sub"):
@@ -367,35 +427,49 @@ def main():
         try:
             with open(prof) as fh:
                 ent = json.load(fh).get(f"{key}_b{batch}")
-            return (ent["bytes_per_launch"], f"profiles/{ent['source']} (static: rocprofv3 PMC passes, not re-measured in this run)") if ent else (None, None)
+            if not ent:
+                return None, None
+            stale = ent.get("csrc_sha16") != csrc_hash()
+            return ent["bytes_per_launch"], (f"profiles/{ent['source']} (static: rocprofv3 PMC passes of round {ent.get('round')}, not re-measured in "
+                                             f"this run; kernel sources {'CHANGED since' if stale else 'unchanged since'} -- csrc_sha16 {ent.get('csrc_sha16')})")
         except Exception:
             return None, None
 
     def roofline(med, alg_per_step, steps, env, key, batch):
+        """frac = whole-job env steps per second x algorithmic bytes per env step / (N x peak): the wall-clock figure,
+        reproducible from `value` alone.  frac_gpu_time = the same bytes over the HIP-event time of the timed region
+        (what the kernels achieve once launched; the difference is launch ramp-up, drain and the synchronisation)."""
         stepped = med["steps"] / world / steps
-        achieved = stepped * alg_per_step / (med["kernel_ms"] * 1e-3) / 1e9
+        achieved = med["rate"] / world * alg_per_step / 1e9
+        gpu_time = stepped * alg_per_step / (med["kernel_ms"] * 1e-3) / 1e9
         traffic, src = static_traffic(key, batch)
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_PEAK_GBS,
+                "frac_gpu_time": gpu_time / HBM_PEAK_GBS, "achieved_gpu_time": gpu_time,
                 "measured_peak": HBM_MEASURED_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                 "kernel": kernel_name(env), "kernel_ms": med["kernel_ms"],
                 "alg_bytes_per_env_step": alg_per_step, "env_steps_per_launch": stepped}
 
-    def side_run(workload, batch, policy, label_extra="", instance="ta01", bucketed=False, modes=("eager", "graph", "sub2", "sub3")):
-        """One extra workload on this GPU: median of N_WINDOWS windows, same timing discipline as the headline."""
+    def side_run(workload, batch, policy, label_extra="", instance="ta01", bucketed=False, modes=("eager", "graph", "sub2", "sub3"),
+                 first_env=None, keep=False):
+        """One extra workload on this GPU, same timing discipline as the headline."""
         alg, label, key = describe(workload, instance)
-        env = make_env(workload, batch, rank * batch, policy, instance=instance, bucketed=bucketed)
+        env = make_env(workload, batch, first_env if first_env is not None else rank * batch, policy, instance=instance,
+                       bucketed=bucketed)
         for _ in range(args.warmup):
             env.rollout(policy, n_iter=1, autoreset=True)
         mode = pick_mode(env, policy, list(modes))
         med, rows = measure(env, policy, args.steps, mode)
         rf = roofline(med, alg, args.steps, env, None if bucketed else key, batch)
         out = {"workload": label + label_extra, "batch": batch, "policy": policy, "value": med["rate"],
-               "min": rows[0]["rate"], "max": rows[-1]["rate"], "unit": "env steps/s", "ms_per_step": med["seconds"] / args.steps * 1e3,
+               "min": rows[0]["rate"], "max": rows[-1]["rate"], "windows": len(rows), "unit": "env steps/s",
+               "ms_per_step": med["seconds"] / args.steps * 1e3, "roofline_frac_gpu_time": rf["frac_gpu_time"],
                "launch": ("one launch per shape bucket per step, every bucket on its own HIP stream" if bucketed else launch_label(mode)),
                "kernel": rf["kernel"], "roofline_frac": rf["frac"],
                "roofline_frac_of_measured_peak": rf["frac_of_measured_peak"], "alg_bytes_per_env_step": alg,
                "traffic": rf["traffic"], "mean_makespan": med["makespan_sum"] / med["episodes"] if med["episodes"] else None}
+        if keep:
+            return out, env
         if hasattr(env, "close"):
             env.close()
         del env
@@ -423,8 +497,7 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int32",
         "data": ("ta01 (the reference's Taillard instance; no dataset involved)" if args.workload == "shared" and args.instance == "ta01"
                  else "synthetic" if args.workload.startswith("synthetic") else "reference instances (ta01-ta80)"),
-        "windows": {"n": len(rows), "steps_each": args.steps, "statistic": "median", "min": rows[0]["rate"], "max": rows[-1]["rate"],
-                    "all": [r["rate"] for r in rows]},
+        "windows": window_stats(rows, args.steps),
         "launch": ("one launch per shape bucket per step, every bucket on its own HIP stream (C launch loop per bucket)"
                    if hasattr(env, "buckets") else launch_label(mode)),
         "config": {"workload": f"{wl_label}{bucket_note}, {args.policy} masked policy fused with step(), "
@@ -445,39 +518,132 @@ def main():
             med1, rows1 = measure(env, args.policy, args.steps, m1)
             out["single_launch_per_step"] = {"value": med1["rate"], "min": rows1[0]["rate"], "max": rows1[-1]["rate"],
                                              "kernel_ms": med1["kernel_ms"], "launch": launch_label(m1),
-                                             "roofline_frac": roofline(med1, alg_per_step, args.steps, env, key, B)["frac"]}
+                                             "roofline_frac": roofline(med1, alg_per_step, args.steps, env, key, B)["frac"],
+                                             "roofline_frac_gpu_time": roofline(med1, alg_per_step, args.steps, env, key, B)["frac_gpu_time"]}
         # fused multi-step rollout: 64 iterations per launch, state in registers, outputs once per launch
         n_l = max(4, args.steps // 16)
         medf, _ = measure(env, args.policy, n_l, "eager", n_iter=64, windows=3)
         out["fused_rollout"] = {"value": medf["rate"], "unit": "env steps/s", "iterations_per_launch": 64, "launches": n_l,
                                 "note": "policy+step x64 per launch, observation written once per launch"}
     if not args.no_extras and world == 1 and not hasattr(env, "buckets"):
-        # the path an RL trainer with its own policy network uses: jss_policy (stand-in for the network) then
-        # jss_step(actions) with next-step auto-reset -- two launches + the action select per env step, hipGraph replay
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        g2 = torch.cuda.CUDAGraph()
-        n2 = max(20, min(100, args.steps))
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(g2, stream=side):
-                for _ in range(n2):
-                    env.step(env.policy(args.policy), autoreset=True)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        g2.replay()
-        torch.cuda.synchronize()
-        rates = []
-        for _ in range(3):
-            env.zero_counters()
+        try:
+            # ---- the boundary entry point itself: jss_step with the actions already resident in HBM, ONE launch per env
+            # step, next-step auto-reset folded into the action codes.  The actions are a recorded behaviour trajectory
+            # (jss_trajectory from a snapshot of the state, restored afterwards), so every launch executes real, legal steps.
+            n2 = max(20, min(100, args.steps))
+            env.zero_counters()                          # (the counters live in the arena: the snapshot holds zeros)
+            snap = env._arena.clone(), env.solution.clone()
+            acts = env.trajectory(args.policy, steps=n2, record=("action",))["action"]
+
+            def restore():
+                env._arena.copy_(snap[0])
+                env.solution.copy_(snap[1])
+
+            def replay_steps(n):
+                for k in range(n):
+                    env.step(acts[k])
+            meds, rowss = measure(env, args.policy, n2, "eager", run=replay_steps, prep=restore)
+            restore()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            gs = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(gs, stream=side):
+                    replay_steps(n2)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            medg, rowsg = measure(env, args.policy, n2, "eager", run=lambda n: gs.replay(), prep=restore)
+            del gs
+            best, rws, how = (medg, rowsg, "hipGraph replay") if medg["rate"] > meds["rate"] else (meds, rowss, "eager ctypes launches")
+            rfs = roofline(best, alg_per_step, n2, env, None, B)
+            out["step_only"] = {"value": best["rate"], "unit": "env steps/s", "ms_per_step": best["seconds"] / n2 * 1e3,
+                                "launch": f"jss_step(actions resident in HBM), one launch per env step, {how}",
+                                "roofline_frac": rfs["frac"], "roofline_frac_gpu_time": rfs["frac_gpu_time"],
+                                "windows": window_stats(rws, n2), "eager": meds["rate"], "graph": medg["rate"],
+                                "note": "the entry point an RL trainer with its own policy network calls; the policy's cost is not in it"}
+            restore()
+            del snap
+        except Exception as exc:
+            out["step_only"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.synchronize()
+        try:
+            # ---- trajectory mode: K steps per launch, every transition recorded (what a scripted / random behaviour
+            # policy collecting rollouts wants): no state reload, no K - 1 launch boundaries
+            KT = 32
+            Jm = env.jmax
+            bufs = env.trajectory(args.policy, steps=KT)
+            n_l = max(2, args.steps // KT)
+
+            def traj_run(n):
+                for _ in range(n):
+                    env.trajectory(args.policy, steps=KT, buffers=bufs)
+            medt, rowst = measure(env, args.policy, n_l, "eager", run=traj_run)
+            inst_j, inst_m = (inst0.jobs, inst0.machines) if args.workload == "shared" else (Jm, env.mmax)
+            rec_bytes = 28 * inst_j + (Jm + 1) + 4 + 4 + 1                      # obs rows + mask row + action + reward + done
+            state_bytes = 2 * (32 * inst_j + 4 * inst_m + 16)                    # state read + written once per launch
+            out["trajectory"] = {"value": medt["rate"], "unit": "env steps/s", "steps_per_launch": KT, "launches_per_window": n_l,
+                                 "windows": window_stats(rowst, n_l * KT),
+                                 "roofline_frac": medt["rate"] * alg_per_step / 1e9 / HBM_PEAK_GBS,
+                                 "bytes_written_per_env_step": rec_bytes + state_bytes / KT,
+                                 "achieved_GBs_of_its_own_bytes": medt["rate"] * (rec_bytes + state_bytes / KT) / 1e9,
+                                 "note": "jss_trajectory: policy + step x K per launch with the observation, mask, action, reward and "
+                                         "done of EVERY step written out ([K][B] buffers); roofline_frac uses the same algorithmic "
+                                         "bytes per env step as the headline (SURVEY 8(d)), the next two fields its own byte count"}
+            del bufs
+        except Exception as exc:
+            out["trajectory"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.synchronize()
+        # the un-fused path: jss_policy (stand-in for a policy network) then jss_step(actions) with next-step auto-reset --
+        # two launches + the action select per env step, hipGraph replay
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            g2 = torch.cuda.CUDAGraph()
+            n2 = max(20, min(100, args.steps))
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g2, stream=side):
+                    for _ in range(n2):
+                        env.step(env.policy(args.policy), autoreset=True)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            med2, rows2 = measure(env, args.policy, n2, "eager", run=lambda n: g2.replay())
+            del g2
+            out["policy_then_step_two_launches"] = {"value": med2["rate"], "unit": "env steps/s", "iterations": n2,
+                                                    "windows": window_stats(rows2, n2),
+                                                    "roofline_frac": roofline(med2, alg_per_step, n2, env, None, B)["frac"],
+                                                    "note": "jss_policy + action select + jss_step(autoreset) per env step (three "
+                                                            "launches, actions through HBM), hipGraph replay"}
+        except Exception as exc:
+            out["policy_then_step_two_launches"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.synchronize()
+        try:
+            # ---- the B = 1 drop-in facade (make('jss-v1')): what a user who only swaps the package gets per step()
+            from jssenv_amd import make
+            from jssenv_amd.dispatching import get_rule
+            f = make("jss-v1", env_config={"instance_path": args.instance}, device=dev)
+            f.reset()
+            rule = get_rule("FIFO")
+            done, n_f = False, 0
+            acts_f = []
+            while not done:                              # a FIFO episode, recorded ...
+                a = rule(f)
+                acts_f.append(a)
+                _, _, done, _, _ = f.step(a)
+            f.reset()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            g2.replay()
+            for a in acts_f:                             # ... and replayed: step() alone, host -> device -> host every call
+                f.step(a)
+            dt_f = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            tot_r, mk_f = rule.run_episode(f, device_rng=True, seed=1)
+            dt_fused = time.perf_counter() - t0
+            out["facade_b1"] = {"us_per_step": dt_f / len(acts_f) * 1e6, "steps": len(acts_f), "instance": args.instance,
+                                "reference_us_per_step_build_container": 79.0,
+                                "fused_rule_episode_ms": dt_fused * 1e3, "fused_rule_makespan": mk_f,
+                                "note": "JssEnv.step(a) on the GPU: action in, one launch, ONE device->host copy of the env's "
+                                        "arena, sync; fused = DispatchingRule.run_episode(env, device_rng=True), whole episode on the device"}
+        except Exception as exc:
+            out["facade_b1"] = {"us_per_step": None, "error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t0
-            rates.append(float(env.counter_totals()[0].item()) / dt2)
-        del g2
-        out["policy_then_step_two_launches"] = {"value": sorted(rates)[1], "unit": "env steps/s", "iterations": n2,
-                                                "note": "jss_policy + jss_step(autoreset) per env step (separate launches, "
-                                                        "actions through HBM), hipGraph replay; median of 3"}
     if not args.no_extras and world == 1 and args.workload == "shared" and args.scaling == "weak":
         if hasattr(env, "close"):
             env.close()
@@ -503,8 +669,28 @@ def main():
                 out[name] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
                 torch.cuda.synchronize()
 
+    if world > 1 and not args.no_extras and args.workload == "shared" and args.scaling == "weak":
+        # BASELINE config 4 as it is defined: synthetic 50x20, 65 536 envs sharded over the N GPUs (strong scaling)
+        if env is not None and hasattr(env, "close"):
+            env.close()
+        del env
+        env = None
+        try:
+            lo4, hi4 = shard_bounds(65536, world, rank)
+            c4 = side_run("synthetic50x20", hi4 - lo4, "random", first_env=lo4,
+                          label_extra=f" -- BASELINE config 4: 65536 envs sharded over {world} GPUs ({hi4 - lo4} on rank {rank})")
+            c4["global_batch"], c4["scaling"], c4["n_gpus"] = 65536, "strong", world
+            c4["roofline_frac"] = c4["value"] / world * b_alg(50, 20) / 1e9 / HBM_PEAK_GBS
+            out["config4_sharded"] = c4
+        except Exception as exc:
+            out["config4_sharded"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.synchronize()
+
+    out["host"] = {"hsa_enable_interrupt": os.environ.get("HSA_ENABLE_INTERRUPT"), **host_cores()}
+    out["csrc_sha16"] = csrc_hash()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "shared":
-        for name, fn in (("cpu_baseline", cpu_baseline_port), ("cpu_baseline_twin", cpu_baseline_twin)):
+        for name, fn in (("cpu_baseline", cpu_baseline_restatement), ("cpu_baseline_port", cpu_baseline_port),
+                         ("cpu_baseline_twin", cpu_baseline_twin)):
             try:     # a host-side hiccup (no compiler for a stale checker build, ...) must not cost the GPU measurement
                 out[name] = fn(args.instance, args.seed)
                 out[name]["host"] = host_cores()

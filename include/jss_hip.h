@@ -51,8 +51,8 @@
  *                                                float32 reciprocals
  *   job state     int32 [B][jmax][JSS_NF]        one 32-byte record per job (JSS_F_* words below):
  *                                                a lane moves its job with two dwordx4 accesses
- *   env header    int32 [B][JSS_NH]              JSS_H_*: clock, episode, step, status + the instance constants
- *                                                of the env (copied in by reset): one 64-byte line per env
+ *   env header    int32 [B][JSS_NH]              JSS_H_*: clock, episode, step, status
+ *   env constants int32 [B][JSS_NC]              JSS_C_*: the env's instance constants (copied in by reset)
  *   machine state int32 [B][mmax]                time_until_available_machine
  *   action_mask   uint8 [B][jmax + 1]            legal_actions (output; rebuilt from the flag bits
  *                                                every call); NOPE flag at index J(env), zeros after it
@@ -96,26 +96,31 @@ extern "C" {
 #define JSS_FLAG_BLOCKED 512
 #define JSS_NEXT2_SHIFT 10
 
-/* words of the per-env header: 64 bytes, one cache line per env.  Words 4-13 are a copy of the env's instance
- * record (and its index) written by every reset of the env: a step-type call gets everything it needs to know about
- * its env from this one line, in the same memory round trip as the state -- no env -> instance -> J/M chain of
- * dependent loads in front of the job records, no second fetch of the observation's normalisers behind them. */
+/* words of the per-env header (16 bytes: read and rewritten by every call) */
 #define JSS_H_CLOCK 0    /* current_time_step                                     */
 #define JSS_H_EPISODE 1  /* episodes started (RNG key)                            */
 #define JSS_H_STEP 2     /* env steps since reset (RNG key)                       */
 #define JSS_H_STATUS 3   /* bits 0-7 JSS_ERR_*, bit 8 legal_actions[J] (NOPE)     */
-#define JSS_H_JOBS 4           /* J of the env's instance (0 = the env was never reset: step-type calls leave it alone) */
-#define JSS_H_MACHINES 5       /* M                                               */
-#define JSS_H_MAX_TIME_OP 6    /* jss_env.py:86                                   */
-#define JSS_H_TABLE 7          /* index of the env's instance in ops / rem / inst */
-#define JSS_H_MAX_TIME_JOBS 8  /* jss_env.py:89                                   */
-#define JSS_H_SUM_OP 9         /* jss_env.py:88                                   */
-#define JSS_H_RCP_MAX_TIME_OP 10   /* float32 bits, as JSS_I_RCP_*                */
-#define JSS_H_RCP_MAX_TIME_JOBS 11
-#define JSS_H_RCP_SUM_OP 12
-#define JSS_H_RCP_MACHINES 13
-#define JSS_NH 16              /* header stride in ints (words 14, 15 are 0)      */
+#define JSS_NH 4
 #define JSS_STATUS_NOOP 256
+
+/* words of the per-env constants record (JssState.env_const, 48 bytes): a copy of the env's instance record and
+ * its index, written by every reset of the env and read-only in between.  A step-type call of a batch whose envs
+ * differ in instance gets everything it needs to know about its env from here, in the same memory round trip as the
+ * state -- no env -> instance -> J/M chain of dependent loads in front of the job records, no second fetch of the
+ * observation's normalisers behind them.  (A batch that shares ONE instance reads the instance record itself, a
+ * wave-uniform scalar load, and never touches this tensor outside reset.) */
+#define JSS_C_JOBS 0           /* J of the env's instance (0 = the env was never reset: step-type calls leave it alone) */
+#define JSS_C_MACHINES 1       /* M                                               */
+#define JSS_C_MAX_TIME_OP 2    /* jss_env.py:86                                   */
+#define JSS_C_TABLE 3          /* index of the env's instance in ops / rem / inst */
+#define JSS_C_MAX_TIME_JOBS 4  /* jss_env.py:89                                   */
+#define JSS_C_SUM_OP 5         /* jss_env.py:88                                   */
+#define JSS_C_RCP_MAX_TIME_OP 6    /* float32 bits, as JSS_I_RCP_*                */
+#define JSS_C_RCP_MAX_TIME_JOBS 7
+#define JSS_C_RCP_SUM_OP 8
+#define JSS_C_RCP_MACHINES 9
+#define JSS_NC 12              /* record stride in ints (words 10, 11 are 0)      */
 
 /* words of the per-instance record */
 #define JSS_I_JOBS 0
@@ -186,6 +191,7 @@ typedef struct JssDesc {
 
 typedef struct JssState {
     int32_t *env;      /* [B][JSS_NH]  JSS_H_*                                         */
+    int32_t *env_const;/* [B][JSS_NC]  JSS_C_*: written by reset, read by the step-type calls */
     int32_t *job;      /* [B][jmax][JSS_NF]                                            */
     int32_t *machine;  /* [B][mmax]                                                    */
     int32_t *solution; /* [B][jmax][mmax]                                              */

@@ -14,8 +14,9 @@ MAX_JOBS, MAX_MACHINES = 128, 64
 F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_NEXT, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
 TODO_MASK, FLAG_LEGAL, FLAG_BLOCKED, NEXT2_SHIFT = 255, 256, 512, 10
 H_CLOCK, H_EPISODE, H_STEP, H_STATUS = 0, 1, 2, 3
-H_JOBS, H_MACHINES, H_MAX_TIME_OP, H_TABLE = 4, 5, 6, 7
-H_MAX_TIME_JOBS, H_SUM_OP, H_RCP_MAX_TIME_OP, H_RCP_MAX_TIME_JOBS, H_RCP_SUM_OP, H_RCP_MACHINES, NH = 8, 9, 10, 11, 12, 13, 16
+NH = 4
+C_JOBS, C_MACHINES, C_MAX_TIME_OP, C_TABLE, C_MAX_TIME_JOBS, C_SUM_OP = 0, 1, 2, 3, 4, 5
+C_RCP_MAX_TIME_OP, C_RCP_MAX_TIME_JOBS, C_RCP_SUM_OP, C_RCP_MACHINES, NC = 6, 7, 8, 9, 12
 STATUS_NOOP = 256
 F4_ONE = -1
 I_JOBS, I_MACHINES, I_MAX_TIME_OP, I_MAX_TIME_JOBS, I_SUM_OP = 0, 1, 2, 3, 4
@@ -42,7 +43,7 @@ class JssDesc(C.Structure):
 
 
 class JssState(C.Structure):
-    _fields_ = [("env", _p), ("job", _p), ("machine", _p), ("solution", _p), ("counters", _p)]
+    _fields_ = [("env", _p), ("env_const", _p), ("job", _p), ("machine", _p), ("solution", _p), ("counters", _p)]
 
 
 class JssOut(C.Structure):

@@ -78,8 +78,10 @@ class BucketedJssEnv:
             # lets late-created ones alias the caller's hardware queue
             pool = _backend.side_pool(len(self._each()))
             self._streams = {k: pool["streams"][i] for i, (k, _) in enumerate(self._each())}
-            self._fork_event = pool["fork"]
-            self._join_events = {k: pool["join"][i] for i, (k, _) in enumerate(self._each())}
+            # the fork / join events are this object's own (two env objects driven from two host threads must not
+            # re-record each other's fork event); the streams are shared, which only serialises such envs
+            self._fork_event = self._torch.cuda.Event()
+            self._join_events = {k: self._torch.cuda.Event() for k, _ in self._each()}
 
     def close(self):
         """Wait for outstanding work and stop using the (process-wide) side streams."""

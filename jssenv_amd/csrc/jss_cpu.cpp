@@ -45,6 +45,7 @@ struct Env {
     const int32_t *ops, *rem;   // [jmax][mmax] tables of my instance (rem may be null)
     int stride, jmax, mmax;
     int32_t *hdr;               // [JSS_NH]
+    int32_t *cst;               // [JSS_NC] the env's constants record
     int32_t *job;               // [jmax][JSS_NF]
     int32_t *tm;                // [mmax]
     int32_t *sol;               // [jmax][mmax]
@@ -76,6 +77,7 @@ Env env_of(const Call &c, int b, bool from_instance) {
     const size_t region = (size_t)d.jmax * d.mmax;
     Env e;
     e.hdr = c.s.env + (size_t)b * JSS_NH;
+    e.cst = c.s.env_const + (size_t)b * JSS_NC;
     if (from_instance) {
         e.tid = d.table_of_env ? d.table_of_env[b] : (d.n_tables == 1 ? 0 : b);
         const int32_t *inst = d.inst + (size_t)e.tid * JSS_NI;
@@ -84,11 +86,11 @@ Env env_of(const Call &c, int b, bool from_instance) {
         e.max_time_op = inst[JSS_I_MAX_TIME_OP];
         e.norm = inst + JSS_I_MAX_TIME_JOBS;
     } else {
-        e.J = e.hdr[JSS_H_JOBS];
-        e.M = e.hdr[JSS_H_MACHINES];
-        e.max_time_op = e.hdr[JSS_H_MAX_TIME_OP];
-        e.tid = e.hdr[JSS_H_TABLE];
-        e.norm = e.hdr + JSS_H_MAX_TIME_JOBS;
+        e.J = e.cst[JSS_C_JOBS];
+        e.M = e.cst[JSS_C_MACHINES];
+        e.max_time_op = e.cst[JSS_C_MAX_TIME_OP];
+        e.tid = e.cst[JSS_C_TABLE];
+        e.norm = e.cst + JSS_C_MAX_TIME_JOBS;
     }
     e.ops = d.ops + e.tid * region;
     e.rem = d.rem ? d.rem + e.tid * region : nullptr;
@@ -117,14 +119,14 @@ bool any_busy(const Env &e) {
 void reset_env(const Env &e) {
     e.t() = 0;                                                            // :154
     e.hdr[JSS_H_STATUS] = 0;                                              // NOPE illegal (:161), error bits cleared
-    // the instance constants travel with the env from here on (include/jss_hip.h JSS_H_*)
-    e.hdr[JSS_H_JOBS] = e.J;
-    e.hdr[JSS_H_MACHINES] = e.M;
-    e.hdr[JSS_H_MAX_TIME_OP] = e.max_time_op;
-    e.hdr[JSS_H_TABLE] = e.tid;
-    if (e.norm != e.hdr + JSS_H_MAX_TIME_JOBS)
-        for (int i = 0; i < 6; ++i) e.hdr[JSS_H_MAX_TIME_JOBS + i] = e.norm[i];
-    e.hdr[14] = e.hdr[15] = 0;
+    // the instance constants travel with the env from here on (include/jss_hip.h JSS_C_*)
+    e.cst[JSS_C_JOBS] = e.J;
+    e.cst[JSS_C_MACHINES] = e.M;
+    e.cst[JSS_C_MAX_TIME_OP] = e.max_time_op;
+    e.cst[JSS_C_TABLE] = e.tid;
+    if (e.norm != e.cst + JSS_C_MAX_TIME_JOBS)
+        for (int i = 0; i < 6; ++i) e.cst[JSS_C_MAX_TIME_JOBS + i] = e.norm[i];
+    e.cst[10] = e.cst[11] = 0;
     for (int m = 0; m < e.mmax; ++m) e.tm[m] = 0;                         // :164
     for (int j = 0; j < e.jmax; ++j) {                                    // rows behind J: "no job" (todo 0, no op)
         const bool v = j < e.J;
@@ -551,7 +553,7 @@ int run(const Call &c, int mode) {
 int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_out) {
     if (!d || !s) return JSS_E_NULL;
     if (!d->ops || !d->inst) return JSS_E_NULL;
-    if (!s->env || !s->job || !s->machine || !s->solution) return JSS_E_NULL;
+    if (!s->env || !s->env_const || !s->job || !s->machine || !s->solution) return JSS_E_NULL;
     if (need_out && (!o || !o->real_obs || !o->action_mask || !o->reward || !o->done || !o->makespan)) return JSS_E_NULL;
     if (d->batch < 0 || d->jmax < 1 || d->jmax > JSS_MAX_JOBS || d->mmax < 2 || d->mmax > JSS_MAX_MACHINES ||
         d->n_tables < 1)

@@ -19,7 +19,7 @@ using namespace jss;
 int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_out) {
     if (!d || !s) return JSS_E_NULL;
     if (!d->ops || !d->inst) return JSS_E_NULL;
-    if (!s->env || !s->job || !s->machine || !s->solution) return JSS_E_NULL;
+    if (!s->env || !s->env_const || !s->job || !s->machine || !s->solution) return JSS_E_NULL;
     if (need_out && (!o || !o->real_obs || !o->action_mask || !o->reward || !o->done || !o->makespan)) return JSS_E_NULL;
     if (d->batch < 0 || d->jmax < 1 || d->jmax > JSS_MAX_JOBS || d->mmax < 2 || d->mmax > JSS_MAX_MACHINES ||
         d->n_tables < 1)
@@ -121,6 +121,7 @@ Params sub_batch(const Params &p, int start, int count) {
     if (p.d.env_ids) q.d.env_ids = p.d.env_ids + s0;
     q.d.env_id_base = p.d.env_id_base + start;
     q.s.env = p.s.env + s0 * JSS_NH;
+    q.s.env_const = p.s.env_const + s0 * JSS_NC;
     q.s.job = p.s.job + s0 * jm * JSS_NF;
     q.s.machine = p.s.machine + s0 * mm;
     q.s.solution = p.s.solution + s0 * jm * mm;

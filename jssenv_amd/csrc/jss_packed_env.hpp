@@ -594,14 +594,15 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
     const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
     const size_t fe = (size_t)c.first_env;
     if (c.gl == 0) {
-        int32_t *hp = p.s.env + fe * JSS_NH;
-        const unsigned ho = c.rel * (JSS_NH * 4u);
-        st_off(hp, ho, make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0)));
-        if (fresh) {   // the instance constants of the env travel with it from here on (include/jss_hip.h JSS_H_*)
+        st_off(p.s.env + fe * JSS_NH, c.rel * (JSS_NH * 4u),
+               make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0)));
+        if (fresh) {   // the instance constants of the env travel with it from here on (include/jss_hip.h JSS_C_*)
             const PNorm n = p_norm(c);
-            st_off(hp, ho + 16u, make_int4(c.J, c.M, c.max_time_op, c.tid));
-            st_off(hp, ho + 32u, make_int4(n.max_time_jobs, n.sum_op, as_int(n.r_op), as_int(n.r_jobs)));
-            st_off(hp, ho + 48u, make_int4(as_int(n.r_sum), as_int(n.r_m), 0, 0));
+            int32_t *cp = p.s.env_const + fe * JSS_NC;
+            const unsigned co = c.rel * (JSS_NC * 4u);
+            st_off(cp, co, make_int4(c.J, c.M, c.max_time_op, c.tid));
+            st_off(cp, co + 16u, make_int4(n.max_time_jobs, n.sum_op, as_int(n.r_op), as_int(n.r_jobs)));
+            st_off(cp, co + 32u, make_int4(as_int(n.r_sum), as_int(n.r_m), 0, 0));
         }
     }
     if (fresh ? (unsigned)c.gl < mm : (c.mvalid && e.tm != raw.tm))      // idle machines stay 0
@@ -822,9 +823,9 @@ void jss_packed_kernel(Params p) {
     const bool wave_whole = c.first_env + E <= p.d.batch;
     const size_t fe = (size_t)c.first_env;
     // 1. state loads first: they depend on nothing but the env index.  With kTabGlobal the env's shape and op table
-    //    index come from its header (words 4-7: the same 64-byte line as the clock) and its six observation
-    //    normalisers (words 8-13) are parked in LDS, one word per lane, until the observation is written; a reset
-    //    call takes both from the instance record instead (env -> instance -> record).
+    //    index come from its constants record (JssState.env_const, written by reset) and its six observation
+    //    normalisers (words 4-9 of that record) are parked in LDS, one word per lane, until the observation is
+    //    written; a reset call takes both from the instance record instead (env -> instance -> record).
     PRaw<G> raw;
     int a_in = JSS_ACTION_SKIP;
     bool selected = true;
@@ -838,8 +839,8 @@ void jss_packed_kernel(Params p) {
             if (MODE == kReset) {
                 c.tid = p.d.table_of_env ? ld_off<int>(p.d.table_of_env + fe, c.rel * 4u) : (int)(fe + c.rel);
             } else {
-                hx = ld_off<int4>(p.s.env + fe * JSS_NH, c.rel * (JSS_NH * 4u) + 16u);
-                if (c.gl < 6) c.norm[c.gl] = ld_off<int>(p.s.env + fe * JSS_NH, c.rel * (JSS_NH * 4u) + 32u + (unsigned)c.gl * 4u);
+                hx = ld_off<int4>(p.s.env_const + fe * JSS_NC, c.rel * (JSS_NC * 4u));
+                if (c.gl < 6) c.norm[c.gl] = ld_off<int>(p.s.env_const + fe * JSS_NC, c.rel * (JSS_NC * 4u) + 16u + (unsigned)c.gl * 4u);
             }
         }
     }

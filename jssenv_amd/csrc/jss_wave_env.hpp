@@ -5,7 +5,7 @@
 // one s_cmp, and the data-dependent while-loops of step() are scalar branches.
 //
 // Memory round trips of a step-type call (the wave is latency-bound at the batch sizes this flavour
-// serves -- profiles/README.md): ONE mandatory trip -- the env's 64-byte header (scalar load: clock,
+// serves -- profiles/README.md): ONE mandatory trip -- the env's header and constants record (scalar loads: clock,
 // J, M, the observation's normalisers, the op table index) together with the job records and machine
 // clocks, none of whose addresses depends on another load (ragged batches: header first, then the rows
 // < J(env)) -- plus, when a job moves on to a new op, the 4-byte op table entry that refills its record,
@@ -546,7 +546,7 @@ __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, co
 }
 
 // ---------------------------------------------------------------------------------------
-// HBM <-> registers.  One 32-byte record per job (two dwordx4 per lane), one 64-byte header per env.
+// HBM <-> registers.  One 32-byte record per job (two dwordx4 per lane), a 16-byte header + 48 bytes of constants per env.
 // The env index is wave-uniform, so every base is an SGPR pair and the lane offset 32 bits.
 // ---------------------------------------------------------------------------------------
 struct Header {
@@ -636,13 +636,14 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
                                           const RawEnv<JPL> &raw, bool all_rows) {
     const int jm = p.d.jmax;
     int32_t *jb = p.s.job + (size_t)c.b * jm * JSS_NF;
-    int32_t *hp = p.s.env + (size_t)c.b * JSS_NH;
     if (c.lane == 0) {
-        *reinterpret_cast<int4 *>(hp) = make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
-        if (all_rows) {   // the instance constants of the env travel with it from here on (include/jss_hip.h JSS_H_*)
-            *reinterpret_cast<int4 *>(hp + 4) = make_int4(c.J, c.M, c.max_time_op, c.tid);
-            *reinterpret_cast<int4 *>(hp + 8) = make_int4(c.max_time_jobs, c.sum_op, as_int(c.r_op), as_int(c.r_jobs));
-            *reinterpret_cast<int4 *>(hp + 12) = make_int4(as_int(c.r_sum), as_int(c.r_m), 0, 0);
+        *reinterpret_cast<int4 *>(p.s.env + (size_t)c.b * JSS_NH) =
+            make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
+        if (all_rows) {   // the instance constants of the env travel with it from here on (include/jss_hip.h JSS_C_*)
+            int32_t *cp = p.s.env_const + (size_t)c.b * JSS_NC;
+            *reinterpret_cast<int4 *>(cp) = make_int4(c.J, c.M, c.max_time_op, c.tid);
+            *reinterpret_cast<int4 *>(cp + 4) = make_int4(c.max_time_jobs, c.sum_op, as_int(c.r_op), as_int(c.r_jobs));
+            *reinterpret_cast<int4 *>(cp + 8) = make_int4(as_int(c.r_sum), as_int(c.r_m), 0, 0);
         }
     }
     if (all_rows) {
@@ -735,28 +736,29 @@ __device__ __forceinline__ void ctx_table(Ctx &c, const Params &p, const int32_t
     c.tab = TAB == kTabLds ? lds : p.d.ops + (size_t)c.tid * p.region_ints;
 }
 
-// The 16 header words of env b as wave-uniform values (scalar loads: nothing in this kernel has written them yet)
+// Header and constants record of env b as wave-uniform values (scalar loads: nothing in this kernel has written them yet)
 struct HeaderWords {
     int clock, episode, step, status, J, M, max_time_op, tid;
     int max_time_jobs, sum_op, r_op, r_jobs, r_sum, r_m;
 };
 __device__ __forceinline__ HeaderWords load_header(const Params &p, int b) {
     const int32_t *hp = p.s.env + (size_t)b * JSS_NH;
+    const int32_t *cp = p.s.env_const + (size_t)b * JSS_NC;
     HeaderWords h;
     h.clock = hp[JSS_H_CLOCK];
     h.episode = hp[JSS_H_EPISODE];
     h.step = hp[JSS_H_STEP];
     h.status = hp[JSS_H_STATUS];
-    h.J = hp[JSS_H_JOBS];
-    h.M = hp[JSS_H_MACHINES];
-    h.max_time_op = hp[JSS_H_MAX_TIME_OP];
-    h.tid = hp[JSS_H_TABLE];
-    h.max_time_jobs = hp[JSS_H_MAX_TIME_JOBS];
-    h.sum_op = hp[JSS_H_SUM_OP];
-    h.r_op = hp[JSS_H_RCP_MAX_TIME_OP];
-    h.r_jobs = hp[JSS_H_RCP_MAX_TIME_JOBS];
-    h.r_sum = hp[JSS_H_RCP_SUM_OP];
-    h.r_m = hp[JSS_H_RCP_MACHINES];
+    h.J = cp[JSS_C_JOBS];
+    h.M = cp[JSS_C_MACHINES];
+    h.max_time_op = cp[JSS_C_MAX_TIME_OP];
+    h.tid = cp[JSS_C_TABLE];
+    h.max_time_jobs = cp[JSS_C_MAX_TIME_JOBS];
+    h.sum_op = cp[JSS_C_SUM_OP];
+    h.r_op = cp[JSS_C_RCP_MAX_TIME_OP];
+    h.r_jobs = cp[JSS_C_RCP_MAX_TIME_JOBS];
+    h.r_sum = cp[JSS_C_RCP_SUM_OP];
+    h.r_m = cp[JSS_C_RCP_MACHINES];
     return h;
 }
 __device__ __forceinline__ void ctx_from_header(Ctx &c, const HeaderWords &h) {
@@ -945,8 +947,7 @@ __global__ __launch_bounds__(kBlock, MODE == kTraj ? (JPL == 2 ? 4 : 6)
     if (MODE == kReset) {
         const int tid = TAB == kTabLds ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : b);
         ctx_from_instance(c, p, tid);
-        if (JPL == 2 && c.J <= kWave) wave_main<1, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
-        else wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
+        wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);   // full width: a reset writes every row of the padded block
     } else {
         // (a restart may hand the env a wider instance: it takes the full-width body)
         if (JPL == 2 && ragged && !(MODE == kStep && a_in == JSS_ACTION_RESET) && __builtin_amdgcn_readfirstlane(h.J) <= kWave)

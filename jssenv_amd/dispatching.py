@@ -16,7 +16,11 @@ when ``env`` is a ``jssenv_amd.JssEnv``; any other env object exposing the refer
 attributes falls back to the attribute-reading loop of the reference rule (CriticalRatio's float
 ratios with its per-episode due-date cache, :327-408, included).
 
-For whole batches use ``BatchedJssEnv.rollout(kind)`` -- rule + step fused on the device.
+For whole batches use ``BatchedJssEnv.rollout(kind)`` -- rule + step fused on the device.  Two entry points
+of this module do that for you on a jssenv_amd env: ``rule.run_episode(env, device_rng=True)`` plays the whole
+episode in fused launches (the 10 % NOPE exploration then comes from the device's counter RNG instead of
+NumPy's global one -- same distribution, not the same stream), and ``compare_rules`` plays each rule's
+``num_episodes`` episodes as ONE batch of ``num_episodes`` envs.
 """
 from __future__ import annotations
 
@@ -68,8 +72,13 @@ class DispatchingRule:
             return env.jobs
         return job
 
-    def run_episode(self, env) -> Tuple[float, int]:
-        """dispatching.py:55-75."""
+    def run_episode(self, env, device_rng: bool = False, seed: Optional[int] = None) -> Tuple[float, int]:
+        """dispatching.py:55-75.  ``device_rng=True`` (jssenv_amd envs only): rule + step fused on the device for the
+        whole episode, exploration drawn from the counter RNG keyed by ``seed``."""
+        if device_rng:
+            if self.kind is None or not hasattr(env, "_b") or not _device_rule_ok(self):
+                raise ValueError("device_rng=True needs a jssenv_amd.JssEnv and a rule with an on-device selector")
+            return env._run_rule(self.kind, explore=EXPLORATION_PROBABILITY, seed=seed)
         env.reset()
         done = False
         total_reward = 0.0
@@ -78,6 +87,11 @@ class DispatchingRule:
             _, reward, done, _, _ = env.step(action)
             total_reward += reward
         return total_reward, env.current_time_step
+
+
+def _device_rule_ok(rule) -> bool:
+    """CriticalRatio's device selector is the default due-date factor only."""
+    return getattr(rule, "due_date_factor", 1.5) == 1.5
 
 
 def _remaining_work(env, job: int) -> int:                                # dispatching.py:187-189
@@ -208,11 +222,40 @@ def get_rule(rule_name: str) -> DispatchingRule:                          # disp
         raise ValueError(f"Rule '{rule_name}' not found. Available rules: {list(DISPATCHING_RULES)}") from None
 
 
-def compare_rules(env, rules: Optional[List[str]] = None, num_episodes: int = 10) -> Dict[str, Dict[str, float]]:
+def compare_rules(env, rules: Optional[List[str]] = None, num_episodes: int = 10,
+                  seed: Optional[int] = None) -> Dict[str, Dict[str, float]]:
     """Mean total reward and mean makespan of each rule over ``num_episodes`` episodes on ``env``
-    (same result keys as dispatching.py:442-475)."""
+    (same result keys as dispatching.py:442-475).
+
+    On a jssenv_amd env the ``num_episodes`` episodes of a rule are one batch of ``num_episodes`` envs of the same
+    instance: rule + step fused in the rollout kernel, the rules' 10 % NOPE exploration drawn per env from the
+    counter RNG (``seed`` keys it; default: a draw from NumPy's global RNG, so ``np.random.seed`` still makes the
+    comparison reproducible).  Any other env object takes the reference's sequential loop."""
+    names = list(DISPATCHING_RULES) if rules is None else list(rules)
+    on_device = hasattr(env, "_b") and all(get_rule(n).kind is not None and _device_rule_ok(get_rule(n)) for n in names)
     results = {}
-    for name in (list(DISPATCHING_RULES) if rules is None else rules):
+    if on_device and num_episodes > 0:
+        from .env import BatchedJssEnv
+        base = int(np.random.randint(0, 2**31 - 1)) if seed is None else int(seed)
+        inst = env.instance
+        batch = BatchedJssEnv([inst], batch=int(num_episodes), seed=base, _backend=env._b.backend)
+        # an episode is J * M allocations plus its NOPEs; chunks of that size until every env reports done
+        chunk = inst.jobs * inst.machines + 16
+        for k, name in enumerate(names):
+            batch.seed = base + 7919 * k
+            batch.reset()
+            batch.zero_counters()
+            for _ in range(64):
+                batch.rollout(get_rule(name).kind, n_iter=chunk, autoreset=False, explore=EXPLORATION_PROBABILITY)
+                if bool(batch.backend.numpy(batch.done).all()):
+                    break
+            else:
+                raise RuntimeError(f"rule {name}: episodes did not finish")
+            cnt = batch.backend.numpy(batch.counters)
+            results[name] = {"avg_reward": float(cnt[:, 3].sum()) / inst.max_time_op / num_episodes,
+                             "avg_makespan": float(batch.backend.numpy(batch.makespan).sum()) / num_episodes}
+        return results
+    for name in names:
         episodes = [get_rule(name).run_episode(env) for _ in range(num_episodes)]
         results[name] = {"avg_reward": sum(r for r, _ in episodes) / num_episodes,
                          "avg_makespan": sum(m for _, m in episodes) / num_episodes}

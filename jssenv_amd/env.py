@@ -72,10 +72,43 @@ class HipBackend:
         t = self.torch.as_tensor(x, device=self.device)
         return t.to(getattr(self.torch, dtype)).contiguous()
 
+    def stage(self, buf, x):
+        """`x` (device tensor of any integer dtype, NumPy array, list) as a contiguous device tensor of buf's dtype:
+        `x` itself when it already is one, otherwise copied into the preallocated `buf` -- nothing is allocated on the
+        device (an int64 tensor, what argmax returns, is converted by the copy kernel)."""
+        t = self.torch
+        if isinstance(x, t.Tensor):
+            if x.device == buf.device and x.dtype == buf.dtype and x.is_contiguous():
+                return x
+            if tuple(x.shape) != tuple(buf.shape):
+                raise ValueError(f"expected shape {tuple(buf.shape)}, got {tuple(x.shape)}")
+            buf.copy_(x)
+            return buf
+        a = np.ascontiguousarray(np.asarray(x), dtype=np.dtype(str(buf.dtype).split(".")[-1]))
+        if a.shape != tuple(buf.shape):
+            raise ValueError(f"expected shape {tuple(buf.shape)}, got {a.shape}")
+        buf.copy_(t.from_numpy(a))
+        return buf
+
     def copy_into(self, dst, src):
         if isinstance(src, np.ndarray):
             src = self.torch.from_numpy(np.ascontiguousarray(src))
         dst.copy_(src)
+
+    def carve(self, arena, off, shape, dtype):
+        """View of `arena` (flat uint8 tensor) at byte offset `off` as `shape` / `dtype`."""
+        dt = getattr(self.torch, dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        return arena[off:off + n].view(dt).view(shape)
+
+    def snapshot(self, arena, host=None):
+        """One device -> host copy of a whole arena into a pinned staging buffer (reused); returns the NumPy view."""
+        t = self.torch
+        if host is None or host.numel() != arena.numel():
+            host = t.empty(arena.numel(), dtype=t.uint8, pin_memory=True)
+        host.copy_(arena, non_blocking=True)
+        t.cuda.current_stream(self.device).synchronize()
+        return host, host.numpy()
 
     def select_into(self, out, flags, a, b):
         """out[...] = where(flags != 0, a (scalar), b): one elementwise kernel, nothing allocated (`flags` is a uint8
@@ -106,37 +139,42 @@ class HipBackend:
             return _NULL_CTX
         return t.cuda.device(self.device)
 
-    def with_streams(self, n, fn):
+    def with_streams(self, n, fn, events=None):
         """Call fn(streams) where streams is a (void* * n) array: the current stream plus n-1 side streams that
         are forked from it before the call and joined back into it afterwards (stream-ordered for the caller,
         capturable in a hipGraph).  The side streams are created once per process and device and shared by every
         env: HIP deals streams onto a handful of hardware queues in creation order, and a side stream that lands
         on the caller's queue serialises the sub-batches it was created to overlap (seen in a long-running bench
-        process: 2 sub-batches slower than one launch until the streams were pinned like this)."""
+        process: 2 sub-batches slower than one launch until the streams were pinned like this).  The fork / join
+        EVENTS belong to the caller (`events`: a dict the env object keeps), so two envs driven from two host
+        threads order their side work against their own streams; the side streams themselves are still shared,
+        i.e. such envs' sub-batch work is serialised on them -- one host thread per device is the intended use."""
         t = self.torch
         main = t.cuda.current_stream(self.device)
         pool = self.side_pool(n - 1)
         side = pool["streams"][:n - 1]
+        ev = events if events is not None else pool.setdefault("events", {})
+        if "fork" not in ev:
+            ev["fork"], ev["join"] = t.cuda.Event(), []
+        while len(ev["join"]) < n - 1:
+            ev["join"].append(t.cuda.Event())
         if side:
-            pool["fork"].record(main)
+            ev["fork"].record(main)
             for st in side:
-                st.wait_event(pool["fork"])
+                st.wait_event(ev["fork"])
         arr = (C.c_void_p * n)(main.cuda_stream, *[st.cuda_stream for st in side])
         rc = fn(arr)
         for i, st in enumerate(side):
-            pool["join"][i].record(st)
-            main.wait_event(pool["join"][i])
+            ev["join"][i].record(st)
+            main.wait_event(ev["join"][i])
         return rc
 
     def side_pool(self, n):
-        """The process-wide side streams of this device (at least n of them) with their join events and the fork event."""
+        """The process-wide side streams of this device (at least n of them)."""
         t = self.torch
-        pool = _SIDE_STREAMS.setdefault(self.device.index, {"streams": [], "join": [], "fork": None})
+        pool = _SIDE_STREAMS.setdefault(self.device.index, {"streams": []})
         while len(pool["streams"]) < n:
             pool["streams"].append(t.cuda.Stream(device=self.device))
-            pool["join"].append(t.cuda.Event())
-        if pool["fork"] is None:
-            pool["fork"] = t.cuda.Event()
         return pool
 
     def close(self):
@@ -167,7 +205,13 @@ class CpuBackend:
 
     def __init__(self, threads: int = 0):
         from .build import build_cpu_twin
-        path = build_cpu_twin()
+        try:
+            path = build_cpu_twin()               # no-op when the in-tree library is newer than its sources
+        except Exception as exc:                  # no compiler on this host: a prebuilt library of this ABI still serves
+            path = _abi.library_path("libjss_cpu.so")
+            if not os.path.isfile(path):
+                raise RuntimeError(f"device='cpu' needs {path}: build it with `g++ -O3 -std=c++17 -fopenmp -fPIC -shared "
+                                   f"-Iinclude jssenv_amd/csrc/jss_cpu.cpp -o {path}` (automatic build failed: {exc})") from exc
         self.lib = _abi.bind(C.CDLL(path))
         if not self.lib.jss_backend().startswith(b"cpu"):
             raise RuntimeError(f"{path} is not the CPU twin ({self.lib.jss_backend()!r})")
@@ -194,8 +238,24 @@ class CpuBackend:
         self._keep = a
         return a
 
+    def stage(self, buf, x):
+        a = np.asarray(x)
+        if a.shape != buf.shape:
+            raise ValueError(f"expected shape {buf.shape}, got {a.shape}")
+        if a.dtype == buf.dtype and a.flags["C_CONTIGUOUS"]:
+            self._keep = a
+            return a
+        buf[...] = a
+        return buf
+
     def copy_into(self, dst, src):
         dst[...] = src
+
+    def carve(self, arena, off, shape, dtype):
+        return _carve_numpy(arena, off, shape, dtype)
+
+    def snapshot(self, arena, host=None):
+        return None, arena
 
     def select_into(self, out, flags, a, b):
         np.copyto(out, b)
@@ -210,11 +270,17 @@ class CpuBackend:
     def on_device(self):
         return _NULL_CTX
 
-    def with_streams(self, n, fn):
+    def with_streams(self, n, fn, events=None):
         return fn((C.c_void_p * n)())
 
     def close(self):
         pass
+
+
+def _carve_numpy(arena, off, shape, dtype):
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    return arena[off:off + n].view(dt).reshape(shape)
 
 
 def make_backend(device=None):
@@ -278,24 +344,31 @@ class BatchedJssEnv:
             self._inst = be.from_numpy(pk.inst)
             self._table_of_env = None if table_of_env is None else be.from_numpy(self.table_of_env_host)
             self._env_ids = None
-            # state (include/jss_hip.h JssState)
+            # state (include/jss_hip.h JssState), outputs (JssOut) and the per-call scratch outputs: ONE allocation,
+            # carved into 256-byte aligned views -- nothing is allocated inside the stepping calls, and a small batch
+            # (the B = 1 facade) comes back to the host in a single copy (host_state)
             J, M = self.jmax, self.mmax
-            # clock, episode, step_in_episode, status + the env's instance constants (written by reset): 64 bytes
-            self.env_header = be.zeros((B, _abi.NH), "int32")
-            self.job_state = be.zeros((B, J, _abi.NF), "int32")  # one 32-byte record per job
-            self.machine_state = be.zeros((B, M), "int32")
-            self.solution = be.zeros((B, J, M), "int32")
-            self.counters = be.zeros((B, 4), "int64")
-            # outputs (JssOut)
-            self.real_obs = be.zeros((B, J, 7), "float32")
-            self.action_mask = be.zeros((B, J + 1), "uint8")
-            self.reward = be.zeros((B,), "float32")
-            self.done = be.zeros((B,), "uint8")
-            self.makespan = be.zeros((B,), "int32")
-            # per-call outputs, allocated once (no allocation inside the stepping calls)
-            self._actions_out = be.zeros((B,), "int32")
-            self._hole = be.zeros((B,), "int32")
-            self._act_buf = be.zeros((B,), "int32")
+            specs = [("env_header", (B, _abi.NH), "int32"),     # clock, episode, step_in_episode, status
+                     ("env_const", (B, _abi.NC), "int32"),      # the env's instance constants, written by reset (JSS_C_*)
+                     ("job_state", (B, J, _abi.NF), "int32"),   # one 32-byte record per job
+                     ("machine_state", (B, M), "int32"),
+                     ("counters", (B, 4), "int64"),
+                     ("real_obs", (B, J, 7), "float32"),
+                     ("action_mask", (B, J + 1), "uint8"),
+                     ("reward", (B,), "float32"), ("done", (B,), "uint8"), ("makespan", (B,), "int32"),
+                     ("_actions_out", (B,), "int32"), ("_hole", (B,), "int32"), ("_act_buf", (B,), "int32"),
+                     ("_act_in", (B,), "int32"), ("_which_in", (B,), "uint8")]
+            self._layout, off = {}, 0
+            for name, shape, dtype in specs:
+                self._layout[name] = (off, shape, dtype)
+                off += (int(np.prod(shape)) * np.dtype(dtype).itemsize + 255) & ~255
+            self._arena = be.zeros((off,), "uint8")
+            carve = getattr(be, "carve", None) or (lambda a, o, sh, dt: _carve_numpy(a, o, sh, dt))
+            for name, (o, shape, dtype) in self._layout.items():
+                setattr(self, name, carve(self._arena, o, shape, dtype))
+            self._host_arena = None
+            self._stream_events = {}                             # fork / join events of rollout_steps, owned by this env
+            self.solution = be.zeros((B, J, M), "int32")         # the one large, rarely read tensor stays on its own
             if hasattr(be, "scalar"):
                 be.scalar(_abi.ACTION_RESET, "int32")
 
@@ -303,7 +376,7 @@ class BatchedJssEnv:
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._rem), p(self._inst), p(self._table_of_env), None,
                                   self.env_id_base, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)),
                                   int(pk.jobs.min()), 0)
-        self._state = _abi.JssState(p(self.env_header), p(self.job_state), p(self.machine_state), p(self.solution),
+        self._state = _abi.JssState(p(self.env_header), p(self.env_const), p(self.job_state), p(self.machine_state), p(self.solution),
                                     p(self.counters))
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
         self._is_reset = False
@@ -352,9 +425,15 @@ class BatchedJssEnv:
     def _mask_arg(self, which):
         if which is None:
             return None
-        w = self.backend.as_device(which, "uint8")
+        return self._stage(self._which_in, which, "uint8")
+
+    def _stage(self, buf, x, dtype):
+        be = self.backend
+        if hasattr(be, "stage"):
+            return be.stage(buf, x)
+        w = be.as_device(x, dtype)
         if tuple(w.shape) != (self.batch,):
-            raise ValueError("mask must have shape (B,)")
+            raise ValueError(f"expected shape ({self.batch},)")
         return w
 
     def _refs(self):
@@ -383,9 +462,7 @@ class BatchedJssEnv:
         be = self.backend
         d, s, o = self._refs()
         with be.on_device():
-            a = be.as_device(actions, "int32")
-            if tuple(a.shape) != (self.batch,):
-                raise ValueError("actions must have shape (B,)")
+            a = self._stage(self._act_in, actions, "int32")   # the caller's int32 tensor itself, or a copy into our buffer
             if autoreset:      # envs that reported done last time get JSS_ACTION_RESET: reset in the same launch
                 be.select_into(self._act_buf, self.done, _abi.ACTION_RESET, a)
                 a = self._act_buf
@@ -450,7 +527,7 @@ class BatchedJssEnv:
         sd = self.seed if seed is None else int(seed)
         with be.on_device():
             rc = be.with_streams(int(n_sub), lambda streams: be.lib.jss_rollout_steps(
-                d, s, o, k, sd, int(round(explore * 65536)), int(steps), flags, int(n_sub), streams))
+                d, s, o, k, sd, int(round(explore * 65536)), int(steps), flags, int(n_sub), streams), self._stream_events)
         _abi.check(be.lib, rc, "jss_rollout_steps")
         return self._obs(), self.reward, self.done, False, {}
 
@@ -575,7 +652,7 @@ class BatchedJssEnv:
         return {"steps": int(c[0]), "episodes": int(c[1]), "makespan_sum": int(c[2]), "reward_num_sum": int(c[3])}
 
     # -- checkpoint / resume: the state is a handful of tensors --------------------
-    _STATE_TENSORS = ("env_header", "job_state", "machine_state", "solution", "counters", "real_obs", "action_mask",
+    _STATE_TENSORS = ("env_header", "env_const", "job_state", "machine_state", "solution", "counters", "real_obs", "action_mask",
                       "reward", "done", "makespan")
 
     def state_dict(self):
@@ -584,7 +661,9 @@ class BatchedJssEnv:
         d = {k: n(getattr(self, k)) for k in self._STATE_TENSORS}
         d["meta"] = {"abi": _abi.ABI_VERSION, "batch": self.batch, "jmax": self.jmax, "mmax": self.mmax, "seed": self.seed,
                      "env_id_base": self.env_id_base, "table_of_env": self.table_of_env_host.copy(),
-                     "ops": self.packed.ops.copy()}
+                     "ops": self.packed.ops.copy(),
+                     # the global env ids key the per-env RNG streams: a resumed run continues them only on the same ids
+                     "env_ids": (np.zeros(0, dtype=np.int64) if self._env_ids is None else n(self._env_ids).astype(np.int64))}
         return d
 
     def load_state_dict(self, d):
@@ -594,6 +673,10 @@ class BatchedJssEnv:
         if (int(m["batch"]), int(m["jmax"]), int(m["mmax"])) != (self.batch, self.jmax, self.mmax) or \
                 not np.array_equal(m["ops"], self.packed.ops) or not np.array_equal(m["table_of_env"], self.table_of_env_host):
             raise ValueError("checkpoint belongs to a different batch (shape or instances differ)")
+        mine = np.zeros(0, dtype=np.int64) if self._env_ids is None else self.backend.numpy(self._env_ids).astype(np.int64)
+        if int(m["env_id_base"]) != self.env_id_base or not np.array_equal(np.asarray(m.get("env_ids", mine)).reshape(-1), mine):
+            raise ValueError(f"checkpoint was written by envs with other global ids (env_id_base {int(m['env_id_base'])} "
+                             f"vs {self.env_id_base}, or different set_env_ids): the RNG streams would not continue")
         with self.backend.on_device():
             for k in self._STATE_TENSORS:
                 self.backend.copy_into(getattr(self, k), np.asarray(d[k]))
@@ -615,38 +698,56 @@ class BatchedJssEnv:
             d["meta"] = {k[len("meta_"):]: (z[k] if z[k].ndim else z[k].item()) for k in z.files if k.startswith("meta_")}
         self.load_state_dict(d)
 
-    def host_state(self, i: int = 0):
+    def host_tensors(self):
+        """NumPy copies of the state and output tensors (not ``solution``).  A small batch comes over in ONE
+        device -> host copy of the arena they were carved from."""
+        be = self.backend
+        if self.batch <= 64 and hasattr(be, "snapshot"):
+            with be.on_device():
+                self._host_arena, flat = be.snapshot(self._arena, self._host_arena)
+            return {k: _carve_numpy(flat, o, sh, dt) for k, (o, sh, dt) in self._layout.items() if not k.startswith("_")}
+        return {k: be.numpy(getattr(self, k)) for k in self._layout if not k.startswith("_")}
+
+    def host_state(self, i: int = 0, with_solution: bool = True):
         """Everything about env i as NumPy, sliced to its true (J, M).  ``job_state`` rows follow the JSS_F_* word
         order with the packed word 0 decoded: row 0 = todo_time_step_job, row 7 = flags (1 legal, 2 blocked);
         ``next_op`` / ``next2_op`` are the record's cached next ops."""
         n = self.backend.numpy
         J, M = int(self.jobs_per_env[i]), int(self.machines_per_env[i])
-        raw = n(self.job_state[i])[:J].astype(np.int64).T         # (NF, J): rows = JSS_F_* words
+        if self.batch <= 64:
+            t = self.host_tensors()
+            t = {k: v[i] for k, v in t.items()}
+        else:
+            t = {k: n(getattr(self, k)[i:i + 1])[0] for k in self._layout if not k.startswith("_")}
+        raw = t["job_state"][:J].astype(np.int64).T                # (NF, J): rows = JSS_F_* words
         js = raw.copy()
         js[_abi.F_TODO] = raw[_abi.F_TODO] & _abi.TODO_MASK
         js[7] = (raw[_abi.F_TODO] >> 8) & 3
-        hdr = n(self.env_header[i])
-        return {
+        hdr = t["env_header"]
+        out = {
             "jobs": J, "machines": M,
             "clock": int(hdr[_abi.H_CLOCK]),
             "job_state": js,
             "next_op": raw[_abi.F_NEXT],
             "next2_op": np.where((raw[_abi.F_TODO] & 0xFFFFFFFF) >> _abi.NEXT2_SHIFT, (raw[_abi.F_TODO] & 0xFFFFFFFF) >> _abi.NEXT2_SHIFT, -1),
-            "tm": n(self.machine_state[i])[:M].astype(np.int64),
-            "mask": n(self.action_mask[i])[:J + 1].astype(bool),
-            "mask_padding": n(self.action_mask[i])[J + 1:],
+            "tm": t["machine_state"][:M].astype(np.int64),
+            "mask": t["action_mask"][:J + 1].astype(bool),
+            "mask_padding": t["action_mask"][J + 1:].copy(),
             "blocked": (js[7] & 2) != 0,
-            "solution": n(self.solution[i])[:J, :M].astype(np.int64),
-            "obs": n(self.real_obs[i])[:J].astype(np.float32),
-            "obs_padding": n(self.real_obs[i])[J:],
-            "reward": float(n(self.reward[i:i + 1])[0]),
-            "done": bool(n(self.done[i:i + 1])[0]),
+            "obs": t["real_obs"][:J].astype(np.float32),
+            "obs_padding": t["real_obs"][J:].copy(),
+            "reward": float(t["reward"]),
+            "done": bool(t["done"]),
             "err": int(hdr[_abi.H_STATUS]) & 0xFF,
             "noop_flag": bool(int(hdr[_abi.H_STATUS]) & _abi.STATUS_NOOP),
-            "makespan": int(n(self.makespan[i:i + 1])[0]),
+            "makespan": int(t["makespan"]),
             "episode": int(hdr[_abi.H_EPISODE]),
             "step_in_episode": int(hdr[_abi.H_STEP]),
+            "counters": t["counters"].copy(),
         }
+        if with_solution:
+            out["solution"] = n(self.solution[i])[:J, :M].astype(np.int64)
+        return out
 
 
 class JssEnv:
@@ -677,6 +778,7 @@ class JssEnv:
         self.last_solution = None                                          # :52
         self._b = BatchedJssEnv([inst], batch=1, device=device, _backend=_backend)
         self._cache = None
+        self._act = np.zeros(1, dtype=np.int32)
         try:  # spaces only when gymnasium is importable (jss_env.py:97, :112-119)
             import gymnasium as gym
             self.action_space = gym.spaces.Discrete(self.jobs + 1)
@@ -689,9 +791,16 @@ class JssEnv:
 
     # -- host mirror of the device state ---------------------------------------------------
     def _h(self):
-        if self._cache is None:
-            self._cache = self._b.host_state(0)
+        if self._cache is None:                    # one device -> host copy per step (the env's arena)
+            self._cache = self._b.host_state(0, with_solution=False)
         return self._cache
+
+    def _solution(self):
+        h = self._h()
+        if "solution" not in h:                    # the start-time table comes over only when somebody reads it
+            b = self._b
+            h["solution"] = b.backend.numpy(b.solution[0])[:self.jobs, :self.machines].astype(np.int64)
+        return h["solution"]
 
     def _obs(self):
         h = self._h()
@@ -705,7 +814,7 @@ class JssEnv:
     total_idle_time_jobs = property(lambda s: s._h()["job_state"][_abi.F_IDLE])
     idle_time_jobs_last_op = property(lambda s: s._h()["job_state"][_abi.F_IDLE_LAST])
     time_until_available_machine = property(lambda s: s._h()["tm"])
-    solution = property(lambda s: s._h()["solution"])
+    solution = property(lambda s: s._solution())
     legal_actions = property(lambda s: s._h()["mask"])
     action_illegal_no_op = property(lambda s: s._h()["blocked"])
     state = property(lambda s: s._h()["obs"])
@@ -767,13 +876,14 @@ class JssEnv:
     def step(self, action):
         """jss_env.py:403-481."""
         action = int(action)
-        self._b.step(np.asarray([action], dtype=np.int32))
+        self._act[0] = action
+        self._b.step(self._act)
         self._cache = None
         h = self._h()
         self._raise_for(h["err"], action)
         if h["done"]:                                                       # :649-652
             self.last_time_step = h["clock"]
-            self.last_solution = h["solution"]
+            self.last_solution = self._solution()
         return self._obs(), h["reward"], h["done"], False, {}
 
     def increase_time_step(self):
@@ -787,6 +897,28 @@ class JssEnv:
         """Gantt chart of ``solution`` (jss_env.py:655-693); needs pandas + plotly on the host."""
         from .render import gantt
         return gantt(self)
+
+    def _run_rule(self, kind, explore: float = 0.0, seed=None):
+        """One whole episode of a dispatching rule, rule + step fused on the device (dispatching.py:55-75 with the
+        exploration drawn from the counter RNG).  Returns (total reward, makespan) like ``run_episode``."""
+        b = self._b
+        if seed is not None:
+            b.seed = int(seed)
+        b.reset()
+        b.zero_counters()
+        chunk = self.jobs * self.machines + 16
+        for _ in range(64):
+            b.rollout(kind, n_iter=chunk, autoreset=False, explore=explore)
+            self._cache = None
+            h = self._h()
+            if h["done"]:
+                break
+        else:
+            raise RuntimeError("episode did not finish")
+        self._raise_for(h["err"])
+        self.last_time_step = h["clock"]
+        self.last_solution = self._solution()
+        return float(h["counters"][3]) / self.max_time_op, h["clock"]
 
     # on-device action selectors for the dispatching module
     def _policy(self, kind):

@@ -4,4 +4,4 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this package.  See oracle/jss_oracle.h for the parity status (pinned against
 golden traces captured from the live reference).
 """
-from .oracle import OracleEnv, build_oracle, rng_u32, POLICY_IDS  # noqa: F401
+from .oracle import OracleEnv, build_oracle, rng_u32, rollout_batch, POLICY_IDS  # noqa: F401

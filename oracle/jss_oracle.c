@@ -15,6 +15,9 @@
 
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 struct OrcEnv {
     int jobs, machines;
@@ -567,4 +570,115 @@ long orc_rollout(OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32_t *
         }
     }
     return executed;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A whole batch of independent envs, from a fresh reset: the same loop as orc_rollout per env (the rules'
+ * NOPE exploration included), OpenMP over envs.  This is how the GPU tests hold EVERY env of a full-size
+ * batch to this restatement -- 65 536 ta01 envs x 300 iterations take seconds on the host cores -- instead
+ * of a sample.  Instances: n_tables padded [jmax][mmax] tables (machine, duration), env i uses table
+ * table_of_env[i] (NULL: table 0 when n_tables == 1, table i otherwise), RNG stream env_ids[i] (NULL:
+ * env_id_base + i).  Every output pointer may be NULL.
+ * ------------------------------------------------------------------------------------------------ */
+int orc_rollout_batch(int n_envs, int n_tables, int jmax, int mmax, const int32_t *jobs_of_table,
+                      const int32_t *machines_of_table, const int32_t *machine_tjm, const int32_t *duration_tjm,
+                      const int32_t *table_of_env, int kind, uint64_t seed, uint64_t env_id_base, const int64_t *env_ids,
+                      uint32_t explore_q16, long iterations, int autoreset, int threads,
+                      int32_t *clock, int32_t *episode, int32_t *step_in_episode, int32_t *job_fields /* [n][6][jmax] */,
+                      int32_t *tm /* [n][mmax] */, int32_t *solution /* [n][jmax][mmax] */, uint8_t *mask /* [n][jmax+1] */,
+                      uint8_t *blocked /* [n][jmax] */, int64_t *counters /* [n][4] */, double *obs /* [n][jmax][7] */,
+                      int32_t *err) {
+    if (n_envs < 0 || n_tables < 1 || jmax < 1 || mmax < 2) return -1;
+    int failed = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < n_envs; ++i) {
+        const int t = table_of_env ? table_of_env[i] : (n_tables == 1 ? 0 : i);
+        const int J = jobs_of_table[t], M = machines_of_table[t];
+        int32_t *mach = (int32_t *)malloc(sizeof(int32_t) * J * M), *dur = (int32_t *)malloc(sizeof(int32_t) * J * M);
+        for (int j = 0; j < J; ++j)
+            for (int k = 0; k < M; ++k) {
+                mach[j * M + k] = machine_tjm[((size_t)t * jmax + j) * mmax + k];
+                dur[j * M + k] = duration_tjm[((size_t)t * jmax + j) * mmax + k];
+            }
+        OrcEnv *e = orc_create(J, M, mach, dur);
+        free(mach);
+        free(dur);
+        if (!e) {
+#pragma omp atomic write
+            failed = 1;
+            continue;
+        }
+        const uint64_t env_id = env_ids ? (uint64_t)env_ids[i] : env_id_base + (uint64_t)i;
+        uint32_t ep = 1, st = 0;                                  /* orc_create resets: first episode */
+        long n_steps = 0, n_done = 0, makespans = 0, reward_num = 0;
+        for (long it = 0; it < iterations; ++it) {
+            if (is_done(e)) {
+                if (!autoreset) break;
+                orc_reset(e);
+                ep += 1;
+                st = 0;
+                continue;
+            }
+            const int a = orc_policy_explore(e, kind, seed, explore_q16, env_id, ep, st);
+            double r;
+            int done;
+            orc_step(e, a, 1, &r, &done);
+            st += 1;
+            n_steps += 1;
+            reward_num += e->last_reward_numerator;
+            if (done) {
+                n_done += 1;
+                makespans += e->current_time_step;
+            }
+        }
+        if (clock) clock[i] = e->current_time_step;
+        if (episode) episode[i] = (int32_t)ep;
+        if (step_in_episode) step_in_episode[i] = (int32_t)st;
+        if (err) err[i] = e->err;
+        if (job_fields) {
+            int32_t *f = job_fields + (size_t)i * 6 * jmax;
+            memset(f, 0, sizeof(int32_t) * 6 * jmax);
+            for (int j = 0; j < J; ++j) {
+                f[0 * jmax + j] = e->todo_time_step_job[j];
+                f[1 * jmax + j] = e->needed_machine_jobs[j];
+                f[2 * jmax + j] = e->time_until_finish_current_op_jobs[j];
+                f[3 * jmax + j] = e->total_perform_op_time_jobs[j];
+                f[4 * jmax + j] = e->total_idle_time_jobs[j];
+                f[5 * jmax + j] = e->idle_time_jobs_last_op[j];
+            }
+        }
+        if (tm) {
+            memset(tm + (size_t)i * mmax, 0, sizeof(int32_t) * mmax);
+            memcpy(tm + (size_t)i * mmax, e->time_until_available_machine, sizeof(int32_t) * M);
+        }
+        if (solution) {
+            int32_t *so = solution + (size_t)i * jmax * mmax;
+            for (int x = 0; x < jmax * mmax; ++x) so[x] = -1;
+            for (int j = 0; j < J; ++j) memcpy(so + (size_t)j * mmax, e->solution + (size_t)j * M, sizeof(int32_t) * M);
+        }
+        if (mask) {
+            memset(mask + (size_t)i * (jmax + 1), 0, jmax + 1);
+            memcpy(mask + (size_t)i * (jmax + 1), e->legal_actions, J + 1);
+        }
+        if (blocked) {
+            memset(blocked + (size_t)i * jmax, 0, jmax);
+            memcpy(blocked + (size_t)i * jmax, e->action_illegal_no_op, J);
+        }
+        if (counters) {
+            counters[(size_t)i * 4 + 0] = n_steps;
+            counters[(size_t)i * 4 + 1] = n_done;
+            counters[(size_t)i * 4 + 2] = makespans;
+            counters[(size_t)i * 4 + 3] = reward_num;
+        }
+        if (obs) {
+            double *o = obs + (size_t)i * jmax * 7;
+            memset(o, 0, sizeof(double) * jmax * 7);
+            memcpy(o, e->state, sizeof(double) * J * 7);
+        }
+        orc_destroy(e);
+    }
+    return failed ? -2 : 0;
 }

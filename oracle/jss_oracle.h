@@ -93,6 +93,16 @@ int orc_policy_explore(const OrcEnv *e, int kind, uint64_t seed, uint32_t explor
 long orc_rollout(OrcEnv *e, int kind, uint64_t seed, uint64_t env_id, uint32_t *episode, uint32_t *step_in_episode,
                  long iterations, long counters[3], double *reward_sum);
 
+/* The same loop for a whole batch of independent envs from a fresh reset, OpenMP over envs; returns every env's
+ * final integer state, counters and float64 observation (any output may be NULL).  Lets the GPU tests compare EVERY
+ * env of a full-size batch with this restatement, not a sample.  0 = ok. */
+int orc_rollout_batch(int n_envs, int n_tables, int jmax, int mmax, const int32_t *jobs_of_table,
+                      const int32_t *machines_of_table, const int32_t *machine_tjm, const int32_t *duration_tjm,
+                      const int32_t *table_of_env, int kind, uint64_t seed, uint64_t env_id_base, const int64_t *env_ids,
+                      uint32_t explore_q16, long iterations, int autoreset, int threads,
+                      int32_t *clock, int32_t *episode, int32_t *step_in_episode, int32_t *job_fields, int32_t *tm,
+                      int32_t *solution, uint8_t *mask, uint8_t *blocked, int64_t *counters, double *obs, int32_t *err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,9 @@ def _load():
     lib.orc_rollout.restype = C.c_long
     lib.orc_rollout.argtypes = [P, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                 C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    lib.orc_rollout_batch.restype = C.c_int
+    lib.orc_rollout_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, C.c_int, C.c_uint64, C.c_uint64, P,
+                                      C.c_uint32, C.c_long, C.c_int, C.c_int] + [P] * 11
     _lib = lib
     return lib
 
@@ -179,3 +182,38 @@ class OracleEnv:
         n = self._lib.orc_rollout(self._h, k, seed, env_id, C.byref(ep), C.byref(st), iterations, counters, C.byref(rs))
         return dict(steps=int(n), episodes=int(counters[1]), makespan_sum=int(counters[2]), reward_sum=rs.value,
                     episode=int(ep.value), step_in_episode=int(st.value))
+
+
+def rollout_batch(packed, batch, kind, seed, iterations, table_of_env=None, env_id_base=0, env_ids=None, explore=0.0,
+                  autoreset=True, threads=0, with_obs=True):
+    """``iterations`` x (policy + step) for ``batch`` independent envs from a fresh reset, all on the C oracle
+    (OpenMP over envs): the checker for EVERY env of a full-size device batch.  ``packed`` is a
+    jssenv_amd.instances.PackedBatch (only its arrays are read here).  Returns NumPy arrays padded like the
+    device tensors: clock, episode, step_in_episode (B,), job_fields (B, 6, jmax) in golden_util.JOB_FIELDS
+    order, tm (B, mmax), solution (B, jmax, mmax), mask (B, jmax + 1), blocked (B, jmax), counters (B, 4) =
+    steps / episodes / makespan sum / reward numerator sum, obs (B, jmax, 7) float64, err (B,)."""
+    lib = _load()
+    ops = np.ascontiguousarray(packed.ops)
+    n_tables, jmax, mmax = ops.shape
+    mach = np.ascontiguousarray(ops >> 16, dtype=np.int32)
+    dur = np.ascontiguousarray(ops & 0xFFFF, dtype=np.int32)
+    jobs = np.ascontiguousarray(packed.jobs, dtype=np.int32)
+    machines = np.ascontiguousarray(packed.machines, dtype=np.int32)
+    B = int(batch)
+    toe = None if table_of_env is None else np.ascontiguousarray(table_of_env, dtype=np.int32)
+    ids = None if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int64)
+    out = {"clock": np.zeros(B, np.int32), "episode": np.zeros(B, np.int32), "step_in_episode": np.zeros(B, np.int32),
+           "job_fields": np.zeros((B, 6, jmax), np.int32), "tm": np.zeros((B, mmax), np.int32),
+           "solution": np.zeros((B, jmax, mmax), np.int32), "mask": np.zeros((B, jmax + 1), np.uint8),
+           "blocked": np.zeros((B, jmax), np.uint8), "counters": np.zeros((B, 4), np.int64),
+           "obs": np.zeros((B, jmax, 7), np.float64) if with_obs else None, "err": np.zeros(B, np.int32)}
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    k = POLICY_IDS[kind] if isinstance(kind, str) else int(kind)
+    rc = lib.orc_rollout_batch(B, n_tables, jmax, mmax, ptr(jobs), ptr(machines), ptr(mach), ptr(dur), ptr(toe), k,
+                               int(seed), int(env_id_base), ptr(ids), int(round(explore * 65536)), int(iterations),
+                               int(bool(autoreset)), int(threads),
+                               *[ptr(out[n]) for n in ("clock", "episode", "step_in_episode", "job_fields", "tm", "solution",
+                                                       "mask", "blocked", "counters", "obs", "err")])
+    if rc != 0:
+        raise RuntimeError(f"orc_rollout_batch failed: {rc}")
+    return out

@@ -58,7 +58,7 @@ class EmuBackend:
         from jssenv_amd.env import _NULL_CTX
         return _NULL_CTX
 
-    def with_streams(self, n, fn):
+    def with_streams(self, n, fn, events=None):
         return fn((C.c_void_p * n)())
 
     def as_device(self, x, dtype):

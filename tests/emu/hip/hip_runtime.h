@@ -235,7 +235,7 @@ inline Block &the_block() {
 template <typename... KArgs, typename... Args>
 inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
     emu::Block &b = emu::the_block();
-    b.dyn_smem.assign(shmem + 64, 0);
+    b.dyn_smem.assign(shmem + 64, (char)0x5A);   // LDS is not zeroed on hardware: poison it
     b.body = [=]() { kernel(args...); };
     for (unsigned bx = 0; bx < grid.x; ++bx) emu::run_block(b, bx, grid, block);
 }

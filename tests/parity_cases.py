@@ -11,7 +11,7 @@ import golden_util as G
 from jssenv_amd import _abi
 from jssenv_amd import instances as I
 from jssenv_amd.env import BatchedJssEnv, JssEnv
-from oracle import OracleEnv
+from oracle import OracleEnv, rollout_batch
 
 OBS_TOL = 1e-6
 
@@ -551,8 +551,8 @@ def case_instance_resampling(backend):
     assert not js[15:, [_abi.F_TODO, _abi.F_LEFT, _abi.F_PERF, _abi.F_IDLE, _abi.F_IDLE_LAST, _abi.F_F4]].any(), js[15:]
     assert (env.backend.numpy(env.solution)[4] == -1).all()
     assert not env.backend.numpy(env.machine_state)[4].any()
-    hdr = env.backend.numpy(env.env_header)[4]
-    assert hdr[_abi.H_JOBS] == 15 and hdr[_abi.H_MACHINES] == 15 and hdr[_abi.H_TABLE] == 0, hdr
+    cst = env.backend.numpy(env.env_const)[4]
+    assert cst[_abi.C_JOBS] == 15 and cst[_abi.C_MACHINES] == 15 and cst[_abi.C_TABLE] == 0, cst
     step_all(10)
     for i, o in enumerate(orcs):
         assert_matches_oracle(env.host_state(i), o, f"after larger->smaller reassignment, env {i}")
@@ -590,6 +590,44 @@ def case_rollout_steps(backend, batch=150, steps=6, n_sub=3, seed=31):
     try:
         a.rollout_steps("random", steps=1, n_sub=17)
         raise AssertionError("n_sub > 16 must be rejected")
+    except ValueError:
+        pass
+
+
+def case_dispatching_on_device(backend, inst="ta01", rules=("SPT", "FIFO", "MWR", "CR"), num_episodes=6, seed=5):
+    """The two fused entry points of jssenv_amd.dispatching: rule.run_episode(env, device_rng=True) and the batched
+    compare_rules -- both against the oracle driven with the same counter RNG (exploration 0.1, dispatching.py:113)."""
+    from jssenv_amd import dispatching as D
+    instance = I.builtin_instance(inst)
+
+    def oracle_episode_of(rule, sd, env_id, episode):
+        o = OracleEnv(instance, strict=True)
+        o.reset()
+        st, total = 0, 0.0
+        while o.nb_legal_actions:
+            _, r, _, _, _ = o.step(o.policy(rule, seed=sd, env_id=env_id, episode=episode, step=st, explore=D.EXPLORATION_PROBABILITY))
+            total += r
+            st += 1
+        return total, o.current_time_step, o
+
+    env = JssEnv({"instance_path": inst}, _backend=backend)
+    for ep, rule in enumerate(rules[:2], start=1):
+        total, makespan = D.get_rule(rule).run_episode(env, device_rng=True, seed=seed + ep)
+        want_total, want_makespan, o = oracle_episode_of(rule, seed + ep, 0, ep)
+        assert makespan == want_makespan == env.last_time_step and abs(total - want_total) <= 1e-6 * max(1.0, abs(want_total)), (rule, makespan, want_makespan)
+        assert (env.solution == o.solution).all() and (np.asarray(env.last_solution) == o.solution).all()
+    res = D.compare_rules(env, list(rules), num_episodes=num_episodes, seed=seed)
+    for k, rule in enumerate(rules):
+        runs = [oracle_episode_of(rule, seed + 7919 * k, i, k + 1)[:2] for i in range(num_episodes)]   # the batch is reset once per rule
+        assert abs(res[rule]["avg_makespan"] - sum(m for _, m in runs) / num_episodes) < 1e-9, rule
+        assert abs(res[rule]["avg_reward"] - sum(r for r, _ in runs) / num_episodes) < 1e-6 * 50, rule
+    np.random.seed(3)
+    a = D.compare_rules(env, ["SPT"], num_episodes=3)
+    np.random.seed(3)
+    assert a == D.compare_rules(env, ["SPT"], num_episodes=3)           # np.random.seed still makes it reproducible
+    try:
+        D.CriticalRatio(due_date_factor=2.0).run_episode(env, device_rng=True)
+        raise AssertionError("a custom due-date factor has no device selector")
     except ValueError:
         pass
 
@@ -817,3 +855,49 @@ def case_hip_equals_twin_full_size(hip_backend, configs=None):
                 same = (x == y)
             assert same.all(), f"{what}: {name} differs from the twin in {int((~same).sum())} of {same.size} elements"
         assert a.stats()["steps"] > 0 and a.stats() == b.stats(), what
+
+
+FULL_SIZE_CONFIGS = [   # (label, BatchedJssEnv kwargs factory, policy, iterations, explore)
+    ("config 2: ta01 x 4096, random", lambda: dict(instances="ta01", batch=4096), "random", 300, 0.0),
+    ("config 3: ta41 x 16384, SPT", lambda: dict(instances="ta41", batch=16384), "SPT", 700, 0.0),
+    ("config 4: synthetic 50x20 x 8192, random", lambda: dict(instances=I.synthetic_packed(8192, 50, 20)), "random", 400, 0.0),
+    ("config 5: mixed ta01-80 x 32768, random",
+     lambda: dict(instances=[I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=32768), "random", 300, 0.0),
+    ("headline: ta01 x 65536, random", lambda: dict(instances="ta01", batch=65536), "random", 280, 0.0),
+]
+
+
+def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=6, env_id_base=123, autoreset=True):
+    """EVERY env of a (full-size) batch against the C oracle itself -- no twin in between: after the same fused
+    rollout from a fresh reset, every integer of the state (clock, the six per-job arrays, machine clocks, solution,
+    mask, blocked flags), the RNG position, the four counters and the error flags are bit-equal on all envs, the
+    float32 observation within 1e-6 of the oracle's float64 on all envs."""
+    env = BatchedJssEnv(seed=seed, env_id_base=env_id_base, _backend=backend, **kw)
+    env.reset()
+    env.rollout(kind, n_iter=iters, autoreset=autoreset, explore=explore)
+    n = env.backend.numpy
+    toe = None if env.n_tables == 1 or env.n_tables == env.batch and env._table_of_env is None else env.table_of_env_host
+    want = rollout_batch(env.packed, env.batch, kind, seed, iters, table_of_env=toe, env_id_base=env_id_base,
+                         explore=explore, autoreset=autoreset)
+    hdr, js = n(env.env_header), n(env.job_state)
+    assert np.array_equal(hdr[:, _abi.H_CLOCK], want["clock"]), f"{label}: clock"
+    assert np.array_equal(hdr[:, _abi.H_EPISODE], want["episode"]) and np.array_equal(hdr[:, _abi.H_STEP], want["step_in_episode"]), \
+        f"{label}: RNG position"
+    assert np.array_equal(hdr[:, _abi.H_STATUS] & 0xFF, want["err"]) and not want["err"].any(), f"{label}: error flags"
+    J = env.jobs_per_env
+    live = np.arange(env.jmax)[None, :] < J[:, None]                    # rows of real jobs
+    got_fields = [js[:, :, _abi.F_TODO] & _abi.TODO_MASK, np.where(live, js[:, :, _abi.F_CUR] >> 16, 0), js[:, :, _abi.F_LEFT],
+                  js[:, :, _abi.F_PERF], js[:, :, _abi.F_IDLE], js[:, :, _abi.F_IDLE_LAST]]
+    for f, (name, got) in enumerate(zip(G.JOB_FIELDS, got_fields)):
+        bad = np.flatnonzero((got != want["job_fields"][:, f]).any(axis=1))
+        assert bad.size == 0, f"{label}: {name} differs on {bad.size} envs, first {bad[:5]}"
+    assert np.array_equal(n(env.machine_state), want["tm"]), f"{label}: time_until_available_machine"
+    assert np.array_equal(n(env.solution), want["solution"]), f"{label}: solution"
+    assert np.array_equal(n(env.action_mask), want["mask"]), f"{label}: action mask"
+    assert np.array_equal((js[:, :, _abi.F_TODO] >> 9) & 1, want["blocked"]), f"{label}: action_illegal_no_op"
+    assert np.array_equal(n(env.counters), want["counters"]), f"{label}: counters"
+    assert np.array_equal((hdr[:, _abi.H_STATUS] & _abi.STATUS_NOOP) != 0, want["mask"][np.arange(env.batch), J] != 0), f"{label}: NOPE flag"
+    err = np.abs(n(env.real_obs).astype(np.float64) - want["obs"]).max()
+    assert err <= OBS_TOL, f"{label}: observation max |diff| {err}"
+    assert want["counters"][:, 0].min() > 0
+    return env

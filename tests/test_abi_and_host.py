@@ -50,7 +50,12 @@ def test_header_constants_match_python_mirror():
     assert defs["JSS_ERR_NOPE_IDLE"] == _abi.ERR_NOPE_IDLE and defs["JSS_ERR_ILLEGAL_ACTION"] == _abi.ERR_ILLEGAL_ACTION
     for name, kid in _abi.POLICY.items():
         assert defs["JSS_POLICY_" + name.upper()] == kid
-    assert ctypes.sizeof(_abi.JssDesc) == 16 + 5 * 8 + 8 + 16 and ctypes.sizeof(_abi.JssState) == 40 and ctypes.sizeof(_abi.JssOut) == 40
+    assert defs["JSS_NH"] == _abi.NH and defs["JSS_NC"] == _abi.NC and defs["JSS_C_TABLE"] == _abi.C_TABLE
+    assert defs["JSS_C_MAX_TIME_JOBS"] == _abi.C_MAX_TIME_JOBS and defs["JSS_C_RCP_MACHINES"] == _abi.C_RCP_MACHINES
+    # the six normalisers sit in the same order in the instance record and in the per-env constants record
+    assert defs["JSS_C_RCP_MACHINES"] - defs["JSS_C_MAX_TIME_JOBS"] == defs["JSS_I_RCP_MACHINES"] - defs["JSS_I_MAX_TIME_JOBS"] == 5
+    assert ctypes.sizeof(_abi.JssDesc) == 16 + 5 * 8 + 8 + 16 and ctypes.sizeof(_abi.JssState) == 48 and ctypes.sizeof(_abi.JssOut) == 40
+    assert ctypes.sizeof(_abi.JssTraj) == 40
 
 
 def test_argument_errors_without_gpu(hip_lib):

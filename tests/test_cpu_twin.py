@@ -6,6 +6,7 @@ import pytest
 
 import golden_util as G
 import parity_cases as P
+from jssenv_amd import instances as I
 
 
 @pytest.fixture(scope="module")
@@ -83,6 +84,16 @@ def test_vector_env_and_resampling(cpu):
 def test_bucketed_and_rollout_steps(cpu):
     P.case_bucketed_equals_padded(cpu, n_envs=48, n_iter=400)
     P.case_rollout_steps(cpu, batch=150, steps=30, n_sub=3)
+
+
+def test_every_env_against_the_batch_oracle(cpu):
+    """the batch driver of the oracle (OpenMP over envs) as the checker for whole batches, all three table layouts"""
+    P.case_every_env_vs_oracle(cpu, "ta01 x 300", dict(instances="ta01", batch=300), "random", 400)
+    P.case_every_env_vs_oracle(cpu, "ta41 SPT + exploration", dict(instances="ta41", batch=64), "SPT", 700, explore=0.1)
+    P.case_every_env_vs_oracle(cpu, "synthetic 50x20 x 96", dict(instances=I.synthetic_packed(96, 50, 20)), "random", 1200)
+    P.case_every_env_vs_oracle(cpu, "mixed x 240", dict(instances=[I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=240),
+                               "random", 500)
+    P.case_every_env_vs_oracle(cpu, "frozen", dict(instances="ta01", batch=40), "FIFO", 400, autoreset=False)
 
 
 def test_trajectory(cpu):
@@ -177,3 +188,7 @@ def test_config2_every_env_against_the_oracle(cpu):
         assert (orc.solution == sol[i]).all(), i
         assert (cnt[i, 0], cnt[i, 1], cnt[i, 2]) == (r["steps"], r["episodes"], r["makespan_sum"]), i
     P.assert_matches_oracle(env.host_state(B - 1), orc, "last env")
+
+
+def test_dispatching_fused_on_device(cpu):
+    P.case_dispatching_on_device(cpu)

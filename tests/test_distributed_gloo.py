@@ -102,3 +102,45 @@ def test_two_ranks_equal_one_process_hip_engine():
     """GPU box: both ranks drive the HIP engine on the one GPU (gloo for the counters): the union of the two
     shards' state tensors and counters is bit-identical to a single-process batch of twice the size."""
     assert _two_ranks_equal_one_process("cuda:0", global_batch=2 * 4096 + 70, iters=300) == "hip:gfx950"
+
+
+def test_reduce_counters_single_process_tensor_forms():
+    """reduce_counters on [4] and [B,4] tensors, no process group: totals and the rate."""
+    from jssenv_amd.distributed import reduce_counters
+    c = torch.tensor([[1, 2, 3, 4], [10, 20, 30, 40]], dtype=torch.int64)
+    a, b = reduce_counters(c, 2.0), reduce_counters(c.sum(0), 2.0)
+    assert a == b and a["steps"] == 11.0 and a["reward_num_sum"] == 44.0 and a["steps_per_second"] == 5.5
+
+
+@pytest.mark.gpu
+def test_reduce_counters_and_agree_max_on_device_tensors():
+    """The forms bench.py uses on the GPU: counters as a CUDA tensor through reduce_counters (the .to(float64), the
+    MAX of the wall time on the tensor's device) -- the lines only a multi-GPU run otherwise reaches."""
+    from jssenv_amd.distributed import reduce_counters
+    c = torch.tensor([[5, 1, 100, -7], [6, 0, 0, 9]], dtype=torch.int64, device="cuda:0")
+    out = reduce_counters(c, 0.5)
+    assert (out["steps"], out["episodes"], out["makespan_sum"], out["reward_num_sum"]) == (11.0, 1.0, 100.0, 2.0)
+    assert out["seconds"] == 0.5 and out["steps_per_second"] == 22.0
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_gpu():
+    """`bench.py --gpus 8` end to end on the 1-GPU box: 8 ranks under torch.distributed.run sharing cuda:0, gloo for
+    the collectives (RCCL needs one GPU per rank).  Exercises the re-exec under torchrun, the rank/shard arithmetic,
+    the per-window SUM/MAX reductions and the config-4-sharded extra that only exists with N > 1."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-device", "--dist-backend", "gloo",
+           "--steps", "5", "--warmup", "1", "--batch", "4096", "--no-cpu-baseline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 5 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 8 * 4096 and out["value"] > 0
+    assert abs(out["roofline"]["frac"] - out["value"] / 8 * out["roofline"]["alg_bytes_per_env_step"] / 8e12) < 1e-9
+    c4 = out["config4_sharded"]
+    assert c4.get("value"), c4
+    assert c4["global_batch"] == 65536 and c4["batch"] == 8192 and c4["n_gpus"] == 8 and c4["scaling"] == "strong"

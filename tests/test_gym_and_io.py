@@ -96,3 +96,75 @@ def test_instance_text_file_round_trip(tmp_path):
     assert (again.packed() == ta.packed()).all()
     env = make("jss-v1", env_config={"instance_path": str(p)}, device="cpu")
     assert (env.jobs, env.machines, env.max_time_op) == (15, 15, ta.max_time_op)
+
+
+def test_render_gantt_end_to_end():
+    """render() (jss_env.py:655-693) through plotly: None before anything is scheduled, then a Figure with one bar
+    per scheduled operation, machines as the colour index, start/finish = solution + duration."""
+    pytest.importorskip("plotly")
+    pytest.importorskip("pandas")
+    from jssenv_amd import make
+    from jssenv_amd.dispatching import get_rule
+    from jssenv_amd.render import gantt_rows
+    env = make("jss-v1", env_config={"instance_path": "ta01"}, device="cpu")
+    env.reset()
+    assert env.render() is None
+    rule = get_rule("SPT")
+    np.random.seed(0)
+    for _ in range(40):
+        env.step(rule(env))
+    fig = env.render()
+    sol = env.solution
+    n_scheduled = int((sol >= 0).sum())
+    assert n_scheduled > 0 and type(fig).__name__ == "Figure"
+    rows = gantt_rows(sol, env.instance, env._render_t0)
+    assert len(rows) == n_scheduled
+    # plotly's create_gantt draws one filled scatter trace per machine: 5 points per bar, the bars of a trace
+    # separated by sharing the closing point (5 n - 1 points for n bars)
+    bars = [t for t in fig.data if getattr(t, "fill", None) == "toself"]
+    assert len(bars) == len({r["Resource"] for r in rows})
+    assert sum((len(t.x) + 1) // 5 for t in bars) == n_scheduled
+    assert fig.layout.yaxis.autorange == "reversed"
+    for r in rows[:5]:
+        job = int(r["Task"].split()[1])
+        k = [x for x in rows if x["Task"] == r["Task"]].index(r)
+        assert (r["Finish"] - r["Start"]).total_seconds() == env.instance.duration[job][k]
+        assert r["Resource"] == f"Machine {int(env.instance.machine[job][k])}"
+
+
+@pytest.mark.refcheck
+def test_render_rows_equal_the_reference():
+    """Build container only: the rows handed to create_gantt equal the reference's render() dataframe for the same
+    schedule (jss_env.py:666-677)."""
+    tools = os.path.join(ROOT, "tools")
+    sys.path.insert(0, tools)
+    import refload
+    if not refload.reference_available():
+        pytest.skip("reference tree absent")
+    pytest.importorskip("plotly")
+    from jssenv_amd import make
+    from jssenv_amd.render import gantt_rows
+    Ref, _ = refload.load_reference()
+    ref = Ref({"instance_path": refload.reference_instance_path("ta01")})
+    env = make("jss-v1", env_config={"instance_path": "ta01"}, device="cpu")
+    ref.reset()
+    env.reset()
+    rng = np.random.default_rng(1)
+    for _ in range(60):
+        a = int(rng.choice(np.flatnonzero(ref.legal_actions)))
+        ref.step(a)
+        env.step(a)
+    fig = ref.render()
+    mine = gantt_rows(env.solution, env.instance, ref.start_timestamp)
+    import datetime
+    want = []
+    for job in range(ref.jobs):
+        for k in range(ref.machines):
+            if ref.solution[job][k] == -1:
+                break
+            s0 = ref.start_timestamp + ref.solution[job][k]
+            want.append({"Task": f"Job {job}", "Start": datetime.datetime.fromtimestamp(s0),
+                         "Finish": datetime.datetime.fromtimestamp(s0 + ref.instance_matrix[job][k][1]),
+                         "Resource": f"Machine {ref.instance_matrix[job][k][0]}"})
+    assert mine == want and fig is not None
+    assert len(env.render().data) == len(fig.data)

@@ -164,7 +164,8 @@ def test_rules_with_exploration(hip):
 
 
 def test_largest_shape_per_env_tables(hip):
-    """128 jobs x 64 machines, one table per env: ~145 KB of dynamic LDS per workgroup must launch."""
+    """128 jobs x 64 machines, one table per env (read from global memory: the workgroup's LDS holds only the four
+    waves' observation images, 4 x 3.6 KB): the largest shape the ABI admits must launch and agree."""
     rng = np.random.default_rng(0)
     from jssenv_amd import BatchedJssEnv
     from oracle import OracleEnv
@@ -231,3 +232,14 @@ def test_checkpoint_file_resume(hip, tmp_path):
 def test_every_env_at_full_size_equals_the_cpu_twin(hip):
     """Configs 2-5 and the headline batch, every env, every tensor, bit for bit against libjss_cpu.so."""
     P.case_hip_equals_twin_full_size(hip)
+
+
+@pytest.mark.parametrize("cfg", range(len(P.FULL_SIZE_CONFIGS)), ids=[c[0].split(":")[0] for c in P.FULL_SIZE_CONFIGS])
+def test_every_env_at_full_size_equals_the_oracle(hip, cfg):
+    """Configs 2-5 and the headline batch: EVERY env against the C oracle's batch driver (no twin in between)."""
+    label, kw, kind, iters, explore = P.FULL_SIZE_CONFIGS[cfg]
+    P.case_every_env_vs_oracle(hip, label, kw(), kind, iters, explore)
+
+
+def test_dispatching_fused_on_device(hip):
+    P.case_dispatching_on_device(hip, num_episodes=40)

@@ -117,3 +117,7 @@ def test_trajectory_equals_policy_plus_step(emu):
 
 def test_trajectory_frozen_without_autoreset(emu):
     P.case_trajectory(emu, "ta01", batch=4, steps=12, kind="FIFO", warm=220, autoreset=False)
+
+
+def test_dispatching_fused_on_device(emu):
+    P.case_dispatching_on_device(emu, rules=("SPT", "CR"), num_episodes=3)

@@ -21,6 +21,28 @@ def test_published_schedules(inst):
     assert (env.todo_time_step_job == env.machines).all()
 
 
+@pytest.mark.parametrize("inst", G.PUBLISHED)
+def test_numpy_restatement_published_schedules(inst):
+    """The Python / NumPy restatement (bench.py's reference-speed CPU baseline) on the same known answers."""
+    from oracle.np_restatement import NumpyJssEnv
+    g = G.load(f"published_{inst}")
+    env = NumpyJssEnv(I.builtin_instance(inst))
+    env.reset()
+    G.replay(env, g)
+    assert env.current_time_step == G.PUBLISHED_MAKESPAN[inst] == int(g["makespan"])
+    assert (env.solution == g["solution"]).all()
+
+
+@pytest.mark.parametrize("inst", G.RANDOM)
+def test_numpy_restatement_random_traces(inst):
+    """... and on the random traces with forced NOPEs: every integer, the float64 observation and the reward bit-equal."""
+    from oracle.np_restatement import NumpyJssEnv
+    g = G.load(f"random_{inst}")
+    env = NumpyJssEnv(I.builtin_instance(inst))
+    G.replay(env, g)
+    assert (env.solution == g["solution"]).all()
+
+
 @pytest.mark.parametrize("inst", G.RANDOM)
 def test_random_traces_with_forced_nope(inst):
     """G2: random masked traces incl. NOPEs forced while action_mask[J] is False."""
