@@ -157,6 +157,10 @@ extern "C" {
 
 /* jss_rollout flags */
 #define JSS_ROLLOUT_AUTORESET 1 /* an env found done is reset instead of stepped (iteration not counted) */
+#define JSS_ROLLOUT_FORK_JOIN 2 /* jss_rollout_steps only: the library orders streams[1..] behind streams[0] before its first
+                                   launch and streams[0] behind all of them after its last (hipEventRecord /
+                                   hipStreamWaitEvent on events it owns), so that the call is stream-ordered on streams[0]
+                                   like any other -- the caller does not fork / join.  One host thread per device. */
 
 /* argument errors */
 #define JSS_E_NULL (-1)
@@ -258,7 +262,8 @@ int jss_sync_check(void *stream);
 /* n_steps x jss_rollout(n_iter = 1) over the whole batch, issued as n_sub contiguous sub-batches (boundaries at
  * multiples of 64 envs): step s of sub-batch i is launched on streams[i] and depends only on step s - 1 of the same
  * sub-batch, so the tail of one sub-batch's launch overlaps the head of another's.  Same results as n_steps calls
- * of jss_rollout.  The caller orders streams[] against its own stream (fork before, join after).  1 <= n_sub <= 16. */
+ * of jss_rollout.  The caller orders streams[] against its own stream (fork before, join after) unless it passes
+ * JSS_ROLLOUT_FORK_JOIN.  1 <= n_sub <= 16. */
 int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
                       uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub, void *const *streams);
 

@@ -24,7 +24,7 @@ I_RCP_MAX_TIME_OP, I_RCP_MAX_TIME_JOBS, I_RCP_SUM_OP, I_RCP_MACHINES, NI = 5, 6,
 ERR_ILLEGAL_ACTION, ERR_NOPE_IDLE, ERR_BAD_ACTION = 1, 2, 4
 ACTION_SKIP, ACTION_RESET = -1, -2
 POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6, "CR": 7}
-ROLLOUT_AUTORESET = 1
+ROLLOUT_AUTORESET, ROLLOUT_FORK_JOIN = 1, 2
 KERNEL = {"auto": 0, "wave": 1}
 E_NULL, E_SHAPE, E_KIND, E_LDS = -1, -2, -3, -4
 MAX_SUB_BATCHES = 16

@@ -35,6 +35,9 @@ int check_kind(const JssDesc *d, int kind) {
     return 0;
 }
 
+// events of JSS_ROLLOUT_FORK_JOIN (created on first use; one host thread per device drives the library)
+hipEvent_t g_fork = nullptr, g_join[16] = {};
+
 #ifdef JSS_PROFILING
 int g_ablate = 0;
 int g_lds_pad = 0;
@@ -244,7 +247,7 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
     if (!streams) return JSS_E_NULL;
     Params p = {};
     p.d = *desc; p.s = *state; p.o = *out; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
-    p.n_iter = 1; p.flags = flags;
+    p.n_iter = 1; p.flags = flags & ~JSS_ROLLOUT_FORK_JOIN;
     LaunchPlan lp;
     if ((rc = plan<kRollout1>(p, lp))) return rc;
     // contiguous sub-batches with boundaries at multiples of 64 envs (whole workgroups, 16-byte aligned rows)
@@ -256,9 +259,28 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
         if (start >= desc->batch) break;
         sub[n++] = sub_batch(p, start, desc->batch - start < chunk ? desc->batch - start : chunk);
     }
+    const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n > 1;
+    hipStream_t s0 = reinterpret_cast<hipStream_t>(streams[0]);
+    if (fork_join) {   // streams[1..] start behind everything queued on streams[0] so far
+        if (!g_fork) {
+            if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+            for (int i = 0; i < 16; ++i)
+                if (hipEventCreateWithFlags(&g_join[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+        }
+        if (hipEventRecord(g_fork, s0) != hipSuccess) return (int)hipGetLastError();
+        for (int i = 1; i < n; ++i)
+            if (hipStreamWaitEvent(reinterpret_cast<hipStream_t>(streams[i]), g_fork, 0) != hipSuccess) return (int)hipGetLastError();
+    }
     for (int s = 0; s < n_steps; ++s)
         for (int i = 0; i < n; ++i)
             if ((rc = fire(sub[i], lp, streams[i]))) return rc;
+    if (fork_join) {   // ... and streams[0] continues behind all of them
+        for (int i = 1; i < n; ++i) {
+            hipStream_t si = reinterpret_cast<hipStream_t>(streams[i]);
+            if (hipEventRecord(g_join[i], si) != hipSuccess) return (int)hipGetLastError();
+            if (hipStreamWaitEvent(s0, g_join[i], 0) != hipSuccess) return (int)hipGetLastError();
+        }
+    }
     return 0;
 }
 

@@ -54,6 +54,7 @@ class HipBackend:
         if not self.lib.jss_backend().startswith(b"hip"):
             raise RuntimeError(f"{path} is not the HIP library ({self.lib.jss_backend()!r})")
         self._scalars = {}
+        self._stream_arrays = {}
 
     # -- memory ----------------------------------------------------------------------------
     def zeros(self, shape, dtype):
@@ -169,6 +170,16 @@ class HipBackend:
             main.wait_event(ev["join"][i])
         return rc
 
+    def stream_array(self, n):
+        """(void* * n): the current stream + n - 1 of the process-wide side streams, for JSS_ROLLOUT_FORK_JOIN calls."""
+        main = self.torch.cuda.current_stream(self.device).cuda_stream
+        key = (n, main)
+        arr = self._stream_arrays.get(key)
+        if arr is None:
+            side = self.side_pool(n - 1)["streams"][:n - 1]
+            arr = self._stream_arrays[key] = (C.c_void_p * n)(main, *[st.cuda_stream for st in side])
+        return arr
+
     def side_pool(self, n):
         """The process-wide side streams of this device (at least n of them)."""
         t = self.torch
@@ -255,7 +266,7 @@ class CpuBackend:
         return _carve_numpy(arena, off, shape, dtype)
 
     def snapshot(self, arena, host=None):
-        return None, arena
+        return arena, arena                 # host memory already: the "copy" is the arena itself
 
     def select_into(self, out, flags, a, b):
         np.copyto(out, b)
@@ -367,6 +378,7 @@ class BatchedJssEnv:
             for name, (o, shape, dtype) in self._layout.items():
                 setattr(self, name, carve(self._arena, o, shape, dtype))
             self._host_arena = None
+            self._host_views = None
             self._stream_events = {}                             # fork / join events of rollout_steps, owned by this env
             self.solution = be.zeros((B, J, M), "int32")         # the one large, rarely read tensor stays on its own
             if hasattr(be, "scalar"):
@@ -469,6 +481,16 @@ class BatchedJssEnv:
             _abi.check(be.lib, be.lib.jss_step(d, s, be.ptr(a), o, be.stream()), "jss_step")
         return self._obs(), self.reward, self.done, False, {}
 
+    def step_raw(self, actions_ptr: int):
+        """jss_step with a caller-owned int32[B] action buffer given by address (device memory, or pinned host memory the
+        device can read): no staging, nothing allocated.  The B = 1 facade's path."""
+        if not self._is_reset:
+            raise RuntimeError("call reset() before step()")
+        be = self.backend
+        d, s, o = self._refs()
+        with be.on_device():
+            _abi.check(be.lib, be.lib.jss_step(d, s, actions_ptr, o, be.stream()), "jss_step")
+
     def increase_time_step(self, which=None):
         """increase_time_step() of jss_env.py:495-637 per env; returns hole_planning (B,) int32 (the env's own
         buffer, overwritten by the next call)."""
@@ -526,8 +548,12 @@ class BatchedJssEnv:
         d, s, o = self._refs()
         sd = self.seed if seed is None else int(seed)
         with be.on_device():
-            rc = be.with_streams(int(n_sub), lambda streams: be.lib.jss_rollout_steps(
-                d, s, o, k, sd, int(round(explore * 65536)), int(steps), flags, int(n_sub), streams), self._stream_events)
+            if hasattr(be, "stream_array"):     # the library forks / joins the side streams itself (two C calls per stream)
+                rc = be.lib.jss_rollout_steps(d, s, o, k, sd, int(round(explore * 65536)), int(steps),
+                                              flags | _abi.ROLLOUT_FORK_JOIN, int(n_sub), be.stream_array(int(n_sub)))
+            else:
+                rc = be.with_streams(int(n_sub), lambda streams: be.lib.jss_rollout_steps(
+                    d, s, o, k, sd, int(round(explore * 65536)), int(steps), flags, int(n_sub), streams), self._stream_events)
         _abi.check(be.lib, rc, "jss_rollout_steps")
         return self._obs(), self.reward, self.done, False, {}
 
@@ -704,8 +730,12 @@ class BatchedJssEnv:
         be = self.backend
         if self.batch <= 64 and hasattr(be, "snapshot"):
             with be.on_device():
-                self._host_arena, flat = be.snapshot(self._arena, self._host_arena)
-            return {k: _carve_numpy(flat, o, sh, dt) for k, (o, sh, dt) in self._layout.items() if not k.startswith("_")}
+                host, flat = be.snapshot(self._arena, self._host_arena)
+            if self._host_views is None or host is not self._host_arena:      # the staging buffer is reused: so are its views
+                self._host_views = {k: _carve_numpy(flat, o, sh, dt) for k, (o, sh, dt) in self._layout.items()
+                                    if not k.startswith("_")}
+            self._host_arena = host
+            return self._host_views
         return {k: be.numpy(getattr(self, k)) for k in self._layout if not k.startswith("_")}
 
     def host_state(self, i: int = 0, with_solution: bool = True):
@@ -750,6 +780,59 @@ class BatchedJssEnv:
         return out
 
 
+class _Snap:
+    """Env 0 of a host snapshot, decoded lazily: ``step()`` needs the observation, mask, reward, done and the error
+    bits; everything else (the per-job arrays the reference exposes as attributes) is unpacked when it is read."""
+
+    def __init__(self, t, J, M):
+        self.t, self.J, self.M, self.c = t, J, M, {}
+
+    def __contains__(self, k):
+        return k in self.c
+
+    def __setitem__(self, k, v):
+        self.c[k] = v
+
+    def __getitem__(self, k):
+        c = self.c
+        if k in c:
+            return c[k]
+        t, J, M = self.t, self.J, self.M
+        if k in ("clock", "err", "noop_flag", "episode", "step_in_episode"):
+            hdr = t["env_header"][0]
+            st = int(hdr[_abi.H_STATUS])
+            c.update(clock=int(hdr[_abi.H_CLOCK]), err=st & 0xFF, noop_flag=bool(st & _abi.STATUS_NOOP),
+                     episode=int(hdr[_abi.H_EPISODE]), step_in_episode=int(hdr[_abi.H_STEP]))
+        elif k in ("job_state", "next_op", "next2_op", "blocked"):
+            raw = t["job_state"][0, :J].astype(np.int64).T
+            js = raw.copy()
+            js[_abi.F_TODO] = raw[_abi.F_TODO] & _abi.TODO_MASK
+            js[7] = (raw[_abi.F_TODO] >> 8) & 3
+            n2 = (raw[_abi.F_TODO] & 0xFFFFFFFF) >> _abi.NEXT2_SHIFT
+            c.update(job_state=js, next_op=raw[_abi.F_NEXT], next2_op=np.where(n2, n2, -1), blocked=(js[7] & 2) != 0)
+        elif k == "tm":
+            c[k] = t["machine_state"][0, :M].astype(np.int64)
+        elif k == "mask":
+            c[k] = t["action_mask"][0, :J + 1] != 0
+        elif k == "obs":
+            c[k] = t["real_obs"][0, :J].copy()
+        elif k == "reward":
+            c[k] = float(t["reward"][0])
+        elif k == "done":
+            c[k] = bool(t["done"][0])
+        elif k == "makespan":
+            c[k] = int(t["makespan"][0])
+        elif k == "counters":
+            c[k] = t["counters"][0].copy()
+        elif k == "mask_padding":
+            c[k] = t["action_mask"][0, J + 1:].copy()
+        elif k == "obs_padding":
+            c[k] = t["real_obs"][0, J:].copy()
+        else:
+            raise KeyError(k)
+        return c[k]
+
+
 class JssEnv:
     """Drop-in for ``JSSEnv.envs.jss_env.JssEnv``: one env (B = 1) on the GPU.
 
@@ -779,6 +862,12 @@ class JssEnv:
         self._b = BatchedJssEnv([inst], batch=1, device=device, _backend=_backend)
         self._cache = None
         self._act = np.zeros(1, dtype=np.int32)
+        self._act_pinned, self._zero_copy = None, False
+        be = self._b.backend
+        if getattr(be, "name", "") == "hip":
+            self._act_pinned = be.torch.zeros(1, dtype=be.torch.int32).pin_memory()
+            # JSSENV_AMD_ZEROCOPY=1: jss_step reads the action straight from the pinned host word (one H2D copy less per step)
+            self._zero_copy = os.environ.get("JSSENV_AMD_ZEROCOPY", "0") == "1"
         try:  # spaces only when gymnasium is importable (jss_env.py:97, :112-119)
             import gymnasium as gym
             self.action_space = gym.spaces.Discrete(self.jobs + 1)
@@ -791,8 +880,8 @@ class JssEnv:
 
     # -- host mirror of the device state ---------------------------------------------------
     def _h(self):
-        if self._cache is None:                    # one device -> host copy per step (the env's arena)
-            self._cache = self._b.host_state(0, with_solution=False)
+        if self._cache is None:                    # one device -> host copy per step (the env's arena), decoded lazily
+            self._cache = _Snap(self._b.host_tensors(), self.jobs, self.machines)
         return self._cache
 
     def _solution(self):
@@ -876,8 +965,17 @@ class JssEnv:
     def step(self, action):
         """jss_env.py:403-481."""
         action = int(action)
-        self._act[0] = action
-        self._b.step(self._act)
+        if self._act_pinned is not None:           # GPU: the action goes out through a pinned word, nothing is allocated
+            self._act_pinned[0] = action
+            b = self._b
+            if self._zero_copy:                    # the kernel reads the pinned word itself
+                b.step_raw(self._act_pinned.data_ptr())
+            else:
+                b._act_in.copy_(self._act_pinned, non_blocking=True)
+                b.step_raw(b._act_in.data_ptr())
+        else:
+            self._act[0] = action
+            self._b.step(self._act)
         self._cache = None
         h = self._h()
         self._raise_for(h["err"], action)

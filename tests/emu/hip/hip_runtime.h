@@ -43,6 +43,11 @@ typedef void *hipStream_t;
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+typedef void *hipEvent_t;
+#define hipEventDisableTiming 2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (void *)1; return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 #define hipDeviceAttributeMultiprocessorCount 0
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
