@@ -52,6 +52,10 @@ class DispatchingRule:
         raise NotImplementedError("Subclasses must implement __call__")
 
     def _best_job(self, env, legal_actions) -> int:
+        if self.kind is not None and hasattr(env, "_rule_best"):
+            # jssenv_amd env: the state of this step is already on the host (one copy per step()); the arg-best over
+            # the legal jobs is one vectorised pass over it -- no second launch / copy / sync per decision
+            return env._rule_best(self.kind, legal_actions)
         if self.kind is not None and hasattr(env, "_policy"):
             a = env._policy(self.kind)            # device arg-best, lowest index wins ties
             return a if a < env.jobs else -1

@@ -862,6 +862,8 @@ class JssEnv:
         self._b = BatchedJssEnv([inst], batch=1, device=device, _backend=_backend)
         self._cache = None
         self._act = np.zeros(1, dtype=np.int32)
+        # remaining work of job j from op k on (MWR / LWR / CR on the host): suffix sums of the durations
+        self._remaining = np.cumsum(inst.duration[:, ::-1], axis=1)[:, ::-1].astype(np.int64)
         self._act_pinned, self._zero_copy = None, False
         be = self._b.backend
         if getattr(be, "name", "") == "hip":
@@ -1017,6 +1019,35 @@ class JssEnv:
         self.last_time_step = h["clock"]
         self.last_solution = self._solution()
         return float(h["counters"][3]) / self.max_time_op, h["clock"]
+
+    def _rule_best(self, kind, legal_actions):
+        """arg-best of a dispatching rule over the legal jobs from the host snapshot of this step (dispatching.py's
+        strict comparisons: the lowest job index wins ties); -1 when no job is legal.  Same selectors as the device's
+        jss_policy (tests hold the two to each other)."""
+        legal = np.asarray(legal_actions[:self.jobs], dtype=bool)
+        if not legal.any():
+            return -1
+        js = self._h()["job_state"]
+        todo = js[_abi.F_TODO]
+        if kind == "FIFO":
+            key = js[_abi.F_IDLE_LAST]
+        elif kind == "SPT":
+            key = -(js[_abi.F_CUR] & 0xFFFF)
+        elif kind in ("MOR", "LOR"):
+            key = (self.machines - todo) * (1 if kind == "MOR" else -1)
+        else:
+            rem = self._remaining[np.arange(self.jobs), np.minimum(todo, self.machines - 1)]
+            if kind == "MWR":
+                key = rem
+            elif kind == "LWR":
+                key = -rem
+            elif kind == "CR":     # smallest (1.5 * job length - now) / remaining work, as the reference's floats (:391-398)
+                with np.errstate(divide="ignore"):
+                    key = -np.where(rem > 0, (1.5 * self._remaining[:, 0] - self._h()["clock"]) / np.maximum(rem, 1), np.inf)
+            else:
+                raise KeyError(kind)
+        key = np.where(legal, key, -np.inf)
+        return int(np.argmax(key))           # first maximum = lowest index among ties
 
     # on-device action selectors for the dispatching module
     def _policy(self, kind):

@@ -361,6 +361,12 @@ def case_dispatching_deterministic(backend, rules=("SPT", "FIFO", "MWR", "LWR", 
             for rule in rules:
                 total, makespan = D.get_rule(rule).run_episode(env)
                 ri, ii = rnames.index(rule), inames.index(inst)
+                # the facade ranks on the host snapshot (JssEnv._rule_best); the device selector must agree with it
+                env.reset()
+                for _ in range(40):
+                    dev = env._policy(rule)                    # job index, or J (NOPE) when no job is legal
+                    assert env._rule_best(rule, env.get_legal_actions()) == (dev if dev < env.jobs else -1), rule
+                    env.step(D.get_rule(rule)(env))
                 assert makespan == g["makespan"][ri, ii], (rule, inst, makespan)
                 assert abs(total - g["total_reward"][ri, ii]) < 1e-4, (rule, inst)
     finally:
