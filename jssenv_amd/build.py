@@ -11,7 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "jss_kernels.hip")
 OUT = os.path.join(_HERE, "libjss_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(_ROOT, "include")]
+# (the counters are bumped by one lane per env: the compiler's wave-aggregation scaffolding around every atomic --
+#  mbcnt, compare, exec save / restore, popcount, multiply -- is pure overhead there)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(_ROOT, "include"),
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 CPU_SRC = os.path.join(_HERE, "csrc", "jss_cpu.cpp")
 CPU_OUT = os.path.join(_HERE, "libjss_cpu.so")
 CPU_FLAGS = ["-O3", "-std=c++17", "-fopenmp", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(_ROOT, "include")]

@@ -109,6 +109,19 @@ __device__ __forceinline__ int as_int(float x) {
     return u.i;
 }
 
+// A wave-uniform value that only vector instructions consume (the observation's normalisers): moved out of the scalar
+// register file once, so that it does not sit in SGPRs -- the scarce resource of the one-wavefront-per-env kernels --
+// from the first load to the last store.  (Host pass and the test emulator: the value itself.)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int in_vgpr(int x) {
+    int r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+}
+#else
+__device__ __forceinline__ int in_vgpr(int x) { return x; }
+#endif
+
 #define JSS_DPP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xF, 0xF, false)
 
 // min / max / or over the 16 lanes of a DPP row, result in every lane of the row

@@ -386,6 +386,9 @@ float div_by(float a, float b, float rb) {
     return std::fmaf(std::fmaf(-q, b, a), rb, q);
 }
 
+// _reward_scaler (jss_env.py:483-493), evaluated like the kernels do (reciprocal + one residual correction)
+float reward_of(const Env &e, int rn) { return div_by((float)rn, (float)e.max_time_op, as_float(e.norm[2])); }
+
 // observation rows < J and the mask row of one env (padding: obs rows behind J are zeroed when `pad`)
 void write_obs_mask(const Env &e, int jm, float *obs, uint8_t *mk, bool pad) {
     const float f_op = (float)e.max_time_op, f_jobs = (float)e.norm[0], f_sum = (float)e.norm[1];
@@ -462,7 +465,7 @@ void run_env(const Call &c, int mode, int b) {
         const int rn = step_env(e, a);
         const bool done = n_legal(e) == 0;                                // :639-653
         e.hdr[JSS_H_STEP] += 1;
-        c.o.reward[b] = (float)rn / (float)e.max_time_op;                 // :483-493
+        c.o.reward[b] = reward_of(e, rn);                                 // :483-493
         c.o.done[b] = done ? 1 : 0;
         if (done) c.o.makespan[b] = e.t();                                // :650
         add_counters(c, b, 1, done ? 1 : 0, done ? e.t() : 0, rn);
@@ -520,11 +523,11 @@ void run_env(const Call &c, int mode, int b) {
             }
             if (mode == kTraj) {
                 if (c.t.action) c.t.action[slot] = a;
-                if (c.t.reward) c.t.reward[slot] = (float)last_rn / (float)e.max_time_op;
+                if (c.t.reward) c.t.reward[slot] = reward_of(e, last_rn);
                 if (c.t.done) c.t.done[slot] = done ? 1 : 0;
             }
         }
-        if (n_steps) c.o.reward[b] = (float)last_rn / (float)e.max_time_op;
+        if (n_steps) c.o.reward[b] = reward_of(e, last_rn);
         c.o.done[b] = n_legal(e) == 0 ? 1 : 0;
         if (last_makespan >= 0) c.o.makespan[b] = last_makespan;
         add_counters(c, b, n_steps, n_done, sum_makespan, sum_rn);

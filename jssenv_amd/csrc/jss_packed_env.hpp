@@ -714,7 +714,7 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
         const bool done = !grp_any<G>(e.legal, c.gbase);
         if (called) hd.step += 1;
         if (c.alive && c.gl == 0 && called) {         // a skipped env keeps its reward / done / makespan
-            st_off<float>(p.o.reward + fe, c.rel * 4u, (float)rn / (float)c.max_time_op);   // :483-493
+            st_off<float>(p.o.reward + fe, c.rel * 4u, div_by((float)rn, (float)c.max_time_op, p_norm(c).r_op));   // :483-493
             st_off<uint8_t>(p.o.done + fe, c.rel, done ? 1 : 0);                            // :639-653
             if (done) st_off<int>(p.o.makespan + fe, c.rel * 4u, e.t);                      // :650
             if (p.s.counters) add_counters(p.s.counters + (fe + c.rel) * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
@@ -771,13 +771,13 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
             if (MODE == kTraj && c.alive && c.gl == 0) {
                 const size_t slot = slot0 + c.rel;
                 if (p.t.action) p.t.action[slot] = do_step ? a : (do_reset ? JSS_ACTION_RESET : JSS_ACTION_SKIP);
-                if (p.t.reward) p.t.reward[slot] = do_step ? (float)rn / (float)c.max_time_op : 0.f;
+                if (p.t.reward) p.t.reward[slot] = do_step ? div_by((float)rn, (float)c.max_time_op, p_norm(c).r_op) : 0.f;
                 if (p.t.done) p.t.done[slot] = do_step ? (done1 ? 1 : 0) : (do_reset ? 0 : 1);
             }
         }
         const bool done = !grp_any<G>(e.legal, c.gbase);
         if (c.alive && c.gl == 0) {
-            if (n_steps) st_off<float>(p.o.reward + fe, c.rel * 4u, (float)last_rn / (float)c.max_time_op);
+            if (n_steps) st_off<float>(p.o.reward + fe, c.rel * 4u, div_by((float)last_rn, (float)c.max_time_op, p_norm(c).r_op));
             st_off<uint8_t>(p.o.done + fe, c.rel, done ? 1 : 0);
             if (last_makespan >= 0) st_off<int>(p.o.makespan + fe, c.rel * 4u, last_makespan);
             if (p.s.counters) add_counters(p.s.counters + (fe + c.rel) * 4, n_steps, n_done, sum_makespan, sum_rn);

@@ -1,8 +1,9 @@
 #pragma once
 // Wave-per-env kernel: one 64-lane wavefront simulates one env (J <= 128, M <= 64).
-// Job j on lane j % 64, slot j / 64 (JPL = 1 or 2 slots); machine m on lane m.  The legal / blocked
-// job sets are wave-uniform 64-bit masks (SGPR pairs): nb_legal_actions is one s_bcnt1, "any legal"
-// one s_cmp, and the data-dependent while-loops of step() are scalar branches.
+// Job j on lane j % 64, slot j / 64 (JPL = 1 or 2 slots); machine m on lane m.  The legal job set is a
+// wave-uniform 64-bit mask (an SGPR pair per slot): nb_legal_actions is one s_bcnt1, "any legal" one s_cmp,
+// and the data-dependent while-loops of step() are scalar branches.  The blocked flag
+// (action_illegal_no_op) is only ever needed by its own job: it stays a per-lane bit.
 //
 // Memory round trips of a step-type call (the wave is latency-bound at the batch sizes this flavour
 // serves -- profiles/README.md): ONE mandatory trip -- the env's header and constants record (scalar loads: clock,
@@ -38,7 +39,8 @@ struct Env {
     int t;                                                               // current_time_step
     int todo[JPL], cur[JPL], nxt[JPL], nxt2[JPL], left[JPL], perf[JPL], idle[JPL], idle_last[JPL], f4[JPL];
     int fill[JPL];                                                       // the load behind a kPending nxt2
-    uint64_t legal[JPL], blocked[JPL];                                   // job sets, wave-uniform
+    uint64_t legal[JPL];                                                 // legal job set, wave-uniform
+    bool blocked[JPL];                                                   // action_illegal_no_op of my job
     int tm;                                                              // lane m: time_until_available_machine[m]
     int noop;                                                            // legal_actions[J]
     int err;
@@ -97,7 +99,7 @@ __device__ __forceinline__ void reset_env(Env<JPL> &e, const Ctx &c, const Param
         e.left[s] = e.perf[s] = e.idle[s] = e.idle_last[s] = 0;          // :165-170
         e.f4[s] = 0;                                                     // :180 state zeros
         e.legal[s] = __ballot(v);                                        // :160
-        e.blocked[s] = 0;                                                // :171-172
+        e.blocked[s] = false;                                            // :171-172
     }
     // solution = -1 (:163): the whole padded [jmax][mmax] block of the env, coalesced (rows behind J(env) too, so
     // that nothing of a previous, larger instance of this env survives a reset)
@@ -157,7 +159,7 @@ __device__ __forceinline__ int advance(Env<JPL> &e, const Ctx &c) {
         // re-legalisation :616-634: need[j] on a free machine, not legal, not blocked.
         // (a job that just completed has cur = -1 and is never legal, :589-591)
         const bool can = j < c.J && ncur >= 0 && ((free_m >> ((ncur >> 16) & 63)) & 1);
-        e.legal[s] |= __ballot(can) & ~e.blocked[s];
+        e.legal[s] |= __ballot(can && !e.blocked[s]);
     }
     return hole;
 }
@@ -179,7 +181,7 @@ __device__ __forceinline__ void jump(Env<JPL> &e, const Ctx &c, bool is_nope, in
         const bool v = s * kWave + c.lane < c.J;
         const bool running = e.left[s] > 0;
         const bool waiting = v && !running && e.cur[s] >= 0;
-        const bool bl = (e.blocked[s] >> c.lane) & 1;
+        const bool bl = e.blocked[s];
         tmx[s] = __shfl(e.tm, ((running ? e.nxt[s] : e.cur[s]) >> 16) & 63);
         if (running) {
             if (e.nxt[s] >= 0) cand = imin(cand, imax(e.left[s], tmx[s]));
@@ -240,7 +242,7 @@ __device__ __forceinline__ void jump(Env<JPL> &e, const Ctx &c, bool is_nope, in
             e.idle_last[s] += T;
             can = tmx[s] <= T;
         }
-        e.legal[s] |= __ballot(can) & ~e.blocked[s];                     // :616-634 at T
+        e.legal[s] |= __ballot(can && !e.blocked[s]);                    // :616-634 at T
     }
 }
 
@@ -368,7 +370,7 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
         const int j = s * kWave + c.lane;
         const bool v = j < c.J;
         const bool lg = (e.legal[s] >> c.lane) & 1;
-        const bool bl = (e.blocked[s] >> c.lane) & 1;
+        const bool bl = e.blocked[s];
         const bool caseA = v && !lg && e.left[s] > 0 && e.todo[s] + 1 < c.M;      // :327-330
         const bool caseB = v && !lg && !caseA && !bl && e.todo[s] < c.M;          // :366-369
         const int tm_need = __shfl(e.tm, (e.cur[s] >> 16) & 63);                   // :376
@@ -391,6 +393,7 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
             ++k;
             go = k < last && hz.mh > tn;
         }
+#ifndef JSS_EXP_NO_DEEP_WALK   // A/B builds only (wrong results): what the table reads of the look-ahead cost
         if (go) {                                                                 // further: the op table, two entries per trip
             const int32_t *row = c.tab + j * c.stride;
             do {
@@ -403,6 +406,7 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
                 }
             } while (k < last && hz.mh > tn);
         }
+#endif
     }
     const int covered = (__ballot(u & 1) != 0) + (__ballot(u & 2) != 0) + (__ballot(u & 4) != 0);
     e.noop = (covered == n_ml) ? 1 : 0;                                  // :357-359 / :395-397
@@ -423,7 +427,7 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
     if (a == c.J) {                                                      // :419 NOPE
 #pragma unroll
         for (int s = 0; s < JPL; ++s) {                                  // :422-428
-            e.blocked[s] |= e.legal[s];
+            e.blocked[s] = e.blocked[s] || ((e.legal[s] >> c.lane) & 1);
             e.legal[s] = 0;
         }
         if (!JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) jump(e, c, true, rn);   // :429-430 in one jump
@@ -448,8 +452,9 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
 #pragma unroll
         for (int s = 0; s < JPL; ++s) {
             const uint64_t same = __ballot(e.cur[s] >= 0 && (e.cur[s] >> 16) == m);   // padding lanes hold cur = -1
+            const bool mine = e.cur[s] >= 0 && (e.cur[s] >> 16) == m;
             e.legal[s] &= ~same;                                         // :455-463
-            e.blocked[s] &= ~same;                                       // :464-467
+            if (mine) e.blocked[s] = false;                              // :464-467
         }
         if (!any_legal(e) && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) jump(e, c, false, rn);   // :469-470 in one jump
     }
@@ -613,7 +618,7 @@ __device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawE
         e.nxt2[s] = n2 ? n2 : -1;
         e.fill[s] = -1;
         e.legal[s] = __ballot((lo.x & JSS_FLAG_LEGAL) != 0);
-        e.blocked[s] = __ballot((lo.x & JSS_FLAG_BLOCKED) != 0);
+        e.blocked[s] = (lo.x & JSS_FLAG_BLOCKED) != 0;
     }
 }
 
@@ -654,7 +659,7 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
-        const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = (int)((e.blocked[s] >> c.lane) & 1);
+        const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = e.blocked[s] ? 1 : 0;
         const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0) |
                                       (e.nxt2[s] >= 0 ? (int)((unsigned)e.nxt2[s] << JSS_NEXT2_SHIFT) : 0), e.cur[s], e.left[s], e.perf[s]);
         const int4 hi = make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]);
@@ -702,17 +707,21 @@ __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, float
     wave_lds_sync();
     float *dst0 = dst - sh;                                              // 16-byte aligned
     const int end = sh + rows * 7;                                       // image floats [sh, end) are the block
-    for (int i = c.lane; i < ((end + 3) >> 2); i += kWave) {
-        const int lo = i << 2;
-        if (lo >= sh && lo + 4 <= end) {                                 // streaming store: whole lines, never read back (see st_nt)
-            st_nt(dst0, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (lo + k >= sh && lo + k < end) st_off<float>(dst0, (unsigned)(lo + k) * 4u, scratch[lo + k]);
-        }
-    }
+    // whole 16-byte lines [i0, i1) as streaming dwordx4 stores (whole lines, never read back: see st_nt); the <= 3
+    // floats in front of the first line and behind the last one as single dwords
+    const int i0 = (sh + 3) >> 2, i1 = end >> 2;
+    for (int i = i0 + c.lane; i < i1; i += kWave)
+        st_nt(dst0, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+    const int head_end = imin(i0 << 2, end), tail_begin = imax(i1 << 2, head_end);
+    if (sh + c.lane < head_end) st_off<float>(dst0, (unsigned)(sh + c.lane) * 4u, scratch[sh + c.lane]);
+    if (tail_begin + c.lane < end) st_off<float>(dst0, (unsigned)(tail_begin + c.lane) * 4u, scratch[tail_begin + c.lane]);
     wave_lds_sync();
+}
+
+// _reward_scaler (jss_env.py:483-493): the integer numerator over max_time_op, with the record's reciprocal and one
+// residual correction like the observation (<= 1 ulp; the host-core twin evaluates the same sequence)
+__device__ __forceinline__ float reward_of(int rn, const Ctx &c) {
+    return div_by((float)rn, (float)c.max_time_op, c.r_op);
 }
 
 // The env's instance constants from the instance record (reset paths; step-type calls take them from the header)
@@ -766,12 +775,12 @@ __device__ __forceinline__ void ctx_from_header(Ctx &c, const HeaderWords &h) {
     c.M = __builtin_amdgcn_readfirstlane(h.M);
     c.max_time_op = __builtin_amdgcn_readfirstlane(h.max_time_op);
     c.tid = __builtin_amdgcn_readfirstlane(h.tid);
-    c.max_time_jobs = __builtin_amdgcn_readfirstlane(h.max_time_jobs);
-    c.sum_op = __builtin_amdgcn_readfirstlane(h.sum_op);
-    c.r_op = as_float(__builtin_amdgcn_readfirstlane(h.r_op));
-    c.r_jobs = as_float(__builtin_amdgcn_readfirstlane(h.r_jobs));
-    c.r_sum = as_float(__builtin_amdgcn_readfirstlane(h.r_sum));
-    c.r_m = as_float(__builtin_amdgcn_readfirstlane(h.r_m));
+    c.max_time_jobs = in_vgpr(__builtin_amdgcn_readfirstlane(h.max_time_jobs));     // consumed by the observation's VALU code only
+    c.sum_op = in_vgpr(__builtin_amdgcn_readfirstlane(h.sum_op));
+    c.r_op = as_float(in_vgpr(__builtin_amdgcn_readfirstlane(h.r_op)));
+    c.r_jobs = as_float(in_vgpr(__builtin_amdgcn_readfirstlane(h.r_jobs)));
+    c.r_sum = as_float(in_vgpr(__builtin_amdgcn_readfirstlane(h.r_sum)));
+    c.r_m = as_float(in_vgpr(__builtin_amdgcn_readfirstlane(h.r_m)));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -831,7 +840,7 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
         const bool done = !any_legal(e);
         if (called) hd.step += 1;
         if (lane == 0 && called) {                                       // a skipped env keeps its reward / done / makespan
-            p.o.reward[b] = (float)rn / (float)c.max_time_op;            // :483-493 (0 for ignored actions)
+            p.o.reward[b] = reward_of(rn, c);                            // :483-493 (0 for ignored actions)
             p.o.done[b] = done ? 1 : 0;                                  // :639-653
             if (done) p.o.makespan[b] = e.t;                             // last_time_step :650
             if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
@@ -887,12 +896,12 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
             }
             if (MODE == kTraj && lane == 0) {
                 if (p.t.action) p.t.action[slot] = a;
-                if (p.t.reward) p.t.reward[slot] = (float)last_rn / (float)c.max_time_op;
+                if (p.t.reward) p.t.reward[slot] = reward_of(last_rn, c);
                 if (p.t.done) p.t.done[slot] = done ? 1 : 0;
             }
         }
         if (lane == 0) {
-            if (n_steps) p.o.reward[b] = (float)last_rn / (float)c.max_time_op;
+            if (n_steps) p.o.reward[b] = reward_of(last_rn, c);
             p.o.done[b] = any_legal(e) ? 0 : 1;
             if (last_makespan >= 0) p.o.makespan[b] = last_makespan;
             if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, n_steps, n_done, sum_makespan, sum_rn);
@@ -916,11 +925,16 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
 #ifndef JSS_WAVE_MIN_BLOCKS
 #define JSS_WAVE_MIN_BLOCKS 8
 #endif
+// waves per SIMD each instantiation is compiled for: the largest occupancy it reaches without scratch memory
+constexpr int wave_min_blocks(int jpl, int mode) {
+    return mode == kTraj ? (jpl == 2 ? 4 : 6)
+         : mode == kRollout ? (jpl == 2 ? 5 : 7)
+         : mode == kStep ? (jpl == 2 ? 5 : 8)
+         : mode == kRollout1 ? (jpl == 2 ? 7 : JSS_WAVE_MIN_BLOCKS)
+         : (jpl == 2 ? 7 : 8);
+}
 template <int JPL, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, MODE == kTraj ? (JPL == 2 ? 4 : 6)
-                                     : (MODE == kStep || MODE == kRollout || MODE == kRollout1)
-                                         ? (JPL == 2 ? (MODE == kRollout ? 5 : 7) : JSS_WAVE_MIN_BLOCKS)
-                                         : 8) void jss_kernel(Params p) {
+__global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from jssenv_amd.build import build_extension  # noqa: E402
 
-VARIANTS = {"profiling": ["-DJSS_PROFILING"], "occ7": ["-DJSS_WAVE_MIN_BLOCKS=7"], "pg8": ["-DJSS_PACKED_GLOBAL_MIN_BLOCKS=8"]}
+VARIANTS = {"profiling": ["-DJSS_PROFILING"], "occ7": ["-DJSS_WAVE_MIN_BLOCKS=7"], "pg8": ["-DJSS_PACKED_GLOBAL_MIN_BLOCKS=8"],
+            "nodeepwalk": ["-DJSS_EXP_NO_DEEP_WALK"]}
 
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)

@@ -19,7 +19,10 @@ B = int(args[0]) if args else 65536
 what = args[1] if len(args) > 1 else "ta01"
 use_graph = "--graph" in sys.argv
 kernel = "wave" if "--wave" in sys.argv else None      # force one wavefront per env (A/B against the packed kernels)
-if what.startswith("synthetic"):
+if what == "mixed":                                      # BASELINE config 5: env i <- ta(1 + i % 80), padded 100x20
+    from jssenv_amd import builtin_instance
+    env = BatchedJssEnv([builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=B, device="cuda:0", kernel=kernel)
+elif what.startswith("synthetic"):
     J, M = (int(x) for x in what[len("synthetic"):].split("x"))
     env = BatchedJssEnv(synthetic_packed(B, J, M), device="cuda:0", kernel=kernel)
 else:
@@ -31,10 +34,11 @@ for r in range(15):
     for _ in range(16):
         env.step(torch.where(ids > r, env.policy("random"), skip))
 env.rollout("random", n_iter=64)
+print(f"{what} B={B} lib={os.environ.get('JSSENV_AMD_LIB', 'shipped')}", flush=True)
 if os.environ.get("JSS_ABLATE"):      # instrumented build only (JSSENV_AMD_LIB=variants/profiling.so): phase ablation mask
     assert env.lib.jss_profiling_set(1, int(os.environ["JSS_ABLATE"])) == 0
     print("ablation mask", os.environ["JSS_ABLATE"], "(results are wrong by construction; timing only)")
-K = 200
+K = int(os.environ.get("JSS_K", "200"))
 for n_sub in [int(x) for x in os.environ.get("JSS_NSUB", "1,2,3,4,6,8").split(",")]:
     env.rollout_steps("random", steps=K, n_sub=n_sub)          # warm (stream creation)
     torch.cuda.synchronize()
@@ -49,11 +53,12 @@ for n_sub in [int(x) for x in os.environ.get("JSS_NSUB", "1,2,3,4,6,8").split(",
         e1.record()
         t_host = time.perf_counter() - t0
         torch.cuda.synchronize()
+        t_wall = time.perf_counter() - t0
         gpu = e0.elapsed_time(e1) / K * 1e3
         steps = env.stats()["steps"]
-        row = (gpu, t_host / K * 1e6, steps / (gpu * 1e-6 * K))
+        row = (gpu, t_host / K * 1e6, steps / (gpu * 1e-6 * K), t_wall / K * 1e6)
         best = row if best is None or row[0] < best[0] else best
-    print(f"eager  n_sub={n_sub}: GPU {best[0]:7.2f} us/step   host enqueue {best[1]:6.2f} us/step   {best[2] / 1e9:.3f} G env-steps/s", flush=True)
+    print(f"eager  n_sub={n_sub}: GPU {best[0]:7.2f} us/step   host enqueue {best[1]:6.2f} us/step   {best[2] / 1e9:.3f} G env-steps/s   wall {best[3]:6.2f} us/step (K={K})", flush=True)
     if use_graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
