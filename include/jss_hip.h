@@ -267,6 +267,16 @@ int jss_sync_check(void *stream);
 int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
                       uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub, void *const *streams);
 
+/* The same for SEVERAL independent env sets at once (the shape classes of a ragged population, each a compact batch of
+ * its own: jssenv_amd.BucketedJssEnv): n_steps x jss_rollout(n_iter = 1) per set, set i on streams[i], the launches
+ * issued step-major (step s of every set before step s + 1 of any), so that sets whose streams share a hardware queue
+ * lose their overlap and nothing more.  One host call per window instead of one per set and chunk.  flags as
+ * jss_rollout_steps (JSS_ROLLOUT_FORK_JOIN: streams[1..] are ordered against streams[0] by the library).
+ * 1 <= n_sets <= 16. */
+int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states,
+                            const JssOut *const *outs, int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps,
+                            int32_t flags, void *const *streams);
+
 #ifdef JSS_PROFILING
 /* Instrumented builds only (tools/build_instrumented.py compiles with -DJSS_PROFILING; the shipped library does
  * not export this).  JSS_PROF_ABLATE: bit mask of phases the kernels skip -- results become WRONG -- used to

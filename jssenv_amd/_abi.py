@@ -30,7 +30,7 @@ E_NULL, E_SHAPE, E_KIND, E_LDS = -1, -2, -3, -4
 MAX_SUB_BATCHES = 16
 
 SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_backend", "jss_reset", "jss_step", "jss_advance", "jss_policy",
-           "jss_rollout", "jss_rollout_steps", "jss_trajectory", "jss_sync_check")
+           "jss_rollout", "jss_rollout_steps", "jss_rollout_steps_multi", "jss_trajectory", "jss_sync_check")
 
 _p = C.c_void_p
 
@@ -79,6 +79,9 @@ def bind(lib):
     lib.jss_rollout_steps.restype = C.c_int
     lib.jss_rollout_steps.argtypes = [D, S, O, C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(_p)]
+    lib.jss_rollout_steps_multi.restype = C.c_int
+    lib.jss_rollout_steps_multi.argtypes = [C.c_int32, C.POINTER(D), C.POINTER(S), C.POINTER(O), C.c_int, C.c_uint64, C.c_uint32,
+                                            C.c_int32, C.c_int32, C.POINTER(_p)]
     lib.jss_trajectory.restype = C.c_int
     lib.jss_trajectory.argtypes = [D, S, O, C.POINTER(JssTraj), C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, _p]
     lib.jss_sync_check.restype, lib.jss_sync_check.argtypes = C.c_int, [_p]

@@ -70,6 +70,8 @@ class BucketedJssEnv:
         # one side stream per bucket: the buckets are independent env sets, so their launches may overlap.
         # Every call forks from / joins back to the caller's current stream, so callers see ordinary
         # stream-ordered semantics (and a graph capture of the caller's stream records the fork/join too).
+        self._backend = _backend
+        self._multi = None
         self._torch = getattr(_backend, "torch", None) if concurrent else None
         self._streams = None
         self._device = getattr(_backend, "device", None)
@@ -130,6 +132,28 @@ class BucketedJssEnv:
         if self._streams is None:
             for _, b in self._each():
                 self._run_bucket(b, kind, steps, n_iter, seed, autoreset, explore)
+            return
+        if n_iter == 1 and hasattr(self._backend, "stream_array"):
+            # ONE host call for the whole window: the library issues the launches step-major over the buckets and
+            # forks / joins the side streams itself (jss_rollout_steps_multi)
+            import ctypes as C
+            from . import _abi
+            each = self._each()
+            be = self._backend
+            if not all(b._is_reset for _, b in each):
+                raise RuntimeError("call reset() before rollout_steps()")
+            n = len(each)
+            if self._multi is None:
+                D, S, O = C.POINTER(_abi.JssDesc), C.POINTER(_abi.JssState), C.POINTER(_abi.JssOut)
+                self._multi = ((D * n)(*[C.pointer(b._desc) for _, b in each]), (S * n)(*[C.pointer(b._state) for _, b in each]),
+                               (O * n)(*[C.pointer(b._out) for _, b in each]))
+            k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
+            flags = (_abi.ROLLOUT_AUTORESET if autoreset else 0) | _abi.ROLLOUT_FORK_JOIN
+            sd = each[0][1].seed if seed is None else int(seed)
+            with be.on_device():
+                rc = be.lib.jss_rollout_steps_multi(n, *self._multi, k, sd, int(round(explore * 65536)), int(steps), flags,
+                                                    be.stream_array(n))
+            _abi.check(be.lib, rc, "jss_rollout_steps_multi")
             return
         t = self._torch
         main = t.cuda.current_stream(self._device)

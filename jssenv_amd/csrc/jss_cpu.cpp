@@ -669,4 +669,17 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
     return jss_rollout(desc, state, out, kind, seed, explore_q16, n_steps, flags, nullptr);
 }
 
+// several independent env sets: each is its own synchronous rollout here
+int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states,
+                            const JssOut *const *outs, int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps,
+                            int32_t flags, void *const *streams) {
+    if (!descs || !states || !outs || !streams) return JSS_E_NULL;
+    if (n_sets < 1 || n_sets > 16 || n_steps < 0) return JSS_E_SHAPE;
+    for (int i = 0; i < n_sets; ++i) {
+        const int rc = jss_rollout(descs[i], states[i], outs[i], kind, seed, explore_q16, n_steps, flags & JSS_ROLLOUT_AUTORESET, nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -38,6 +38,27 @@ int check_kind(const JssDesc *d, int kind) {
 // events of JSS_ROLLOUT_FORK_JOIN (created on first use; one host thread per device drives the library)
 hipEvent_t g_fork = nullptr, g_join[16] = {};
 
+// streams[1..n) start behind everything queued on streams[0] so far ...
+int fork_streams(void *const *streams, int n) {
+    if (!g_fork) {
+        if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+        for (int i = 0; i < 16; ++i)
+            if (hipEventCreateWithFlags(&g_join[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    }
+    if (hipEventRecord(g_fork, reinterpret_cast<hipStream_t>(streams[0])) != hipSuccess) return (int)hipGetLastError();
+    for (int i = 1; i < n; ++i)
+        if (hipStreamWaitEvent(reinterpret_cast<hipStream_t>(streams[i]), g_fork, 0) != hipSuccess) return (int)hipGetLastError();
+    return 0;
+}
+// ... and streams[0] continues behind all of them
+int join_streams(void *const *streams, int n) {
+    for (int i = 1; i < n; ++i) {
+        if (hipEventRecord(g_join[i], reinterpret_cast<hipStream_t>(streams[i])) != hipSuccess) return (int)hipGetLastError();
+        if (hipStreamWaitEvent(reinterpret_cast<hipStream_t>(streams[0]), g_join[i], 0) != hipSuccess) return (int)hipGetLastError();
+    }
+    return 0;
+}
+
 #ifdef JSS_PROFILING
 int g_ablate = 0;
 int g_lds_pad = 0;
@@ -260,28 +281,37 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
         sub[n++] = sub_batch(p, start, desc->batch - start < chunk ? desc->batch - start : chunk);
     }
     const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n > 1;
-    hipStream_t s0 = reinterpret_cast<hipStream_t>(streams[0]);
-    if (fork_join) {   // streams[1..] start behind everything queued on streams[0] so far
-        if (!g_fork) {
-            if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
-            for (int i = 0; i < 16; ++i)
-                if (hipEventCreateWithFlags(&g_join[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
-        }
-        if (hipEventRecord(g_fork, s0) != hipSuccess) return (int)hipGetLastError();
-        for (int i = 1; i < n; ++i)
-            if (hipStreamWaitEvent(reinterpret_cast<hipStream_t>(streams[i]), g_fork, 0) != hipSuccess) return (int)hipGetLastError();
-    }
+    if (fork_join && (rc = fork_streams(streams, n))) return rc;
     for (int s = 0; s < n_steps; ++s)
         for (int i = 0; i < n; ++i)
             if ((rc = fire(sub[i], lp, streams[i]))) return rc;
-    if (fork_join) {   // ... and streams[0] continues behind all of them
-        for (int i = 1; i < n; ++i) {
-            hipStream_t si = reinterpret_cast<hipStream_t>(streams[i]);
-            if (hipEventRecord(g_join[i], si) != hipSuccess) return (int)hipGetLastError();
-            if (hipStreamWaitEvent(s0, g_join[i], 0) != hipSuccess) return (int)hipGetLastError();
-        }
+    return fork_join ? join_streams(streams, n) : 0;
+}
+
+int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states,
+                            const JssOut *const *outs, int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps,
+                            int32_t flags, void *const *streams) {
+    if (!descs || !states || !outs || !streams) return JSS_E_NULL;
+    if (n_sets < 1 || n_sets > 16 || n_steps < 0) return JSS_E_SHAPE;
+    Params ps[16];
+    LaunchPlan lps[16];
+    for (int i = 0; i < n_sets; ++i) {
+        int rc = check_args(descs[i], states[i], outs[i], true);
+        if (rc) return rc;
+        if ((rc = check_kind(descs[i], kind))) return rc;
+        Params &p = ps[i];
+        p = {};
+        p.d = *descs[i]; p.s = *states[i]; p.o = *outs[i]; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
+        p.n_iter = 1; p.flags = flags & ~JSS_ROLLOUT_FORK_JOIN;
+        if ((rc = plan<kRollout1>(p, lps[i]))) return rc;
     }
-    return 0;
+    const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n_sets > 1;
+    int rc = fork_join ? fork_streams(streams, n_sets) : 0;
+    if (rc) return rc;
+    for (int s = 0; s < n_steps; ++s)
+        for (int i = 0; i < n_sets; ++i)
+            if ((rc = fire(ps[i], lps[i], streams[i]))) return rc;
+    return fork_join ? join_streams(streams, n_sets) : 0;
 }
 
 }  // extern "C"

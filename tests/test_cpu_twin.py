@@ -192,3 +192,26 @@ def test_config2_every_env_against_the_oracle(cpu):
 
 def test_dispatching_fused_on_device(cpu):
     P.case_dispatching_on_device(cpu)
+
+
+def test_rollout_steps_multi_equals_separate_rollouts(cpu):
+    """jss_rollout_steps_multi (several env sets in one call) == one jss_rollout per set"""
+    import ctypes as C
+    from jssenv_amd import _abi
+    from jssenv_amd.env import BatchedJssEnv
+    kws = [dict(instances="ta01", batch=9), dict(instances=["ta31", "ta02"], batch=5), dict(instances="ta51", batch=3)]
+    a = [BatchedJssEnv(seed=4, env_id_base=10 * i, _backend=cpu, **kw) for i, kw in enumerate(kws)]
+    b = [BatchedJssEnv(seed=4, env_id_base=10 * i, _backend=cpu, **kw) for i, kw in enumerate(kws)]
+    for e in a + b:
+        e.reset()
+    n = len(a)
+    D, S, O = C.POINTER(_abi.JssDesc), C.POINTER(_abi.JssState), C.POINTER(_abi.JssOut)
+    rc = cpu.lib.jss_rollout_steps_multi(n, (D * n)(*[C.pointer(e._desc) for e in a]), (S * n)(*[C.pointer(e._state) for e in a]),
+                                         (O * n)(*[C.pointer(e._out) for e in a]), _abi.POLICY["random"], 4, 0, 120,
+                                         _abi.ROLLOUT_AUTORESET | _abi.ROLLOUT_FORK_JOIN, (C.c_void_p * n)())
+    assert rc == 0
+    for x, y in zip(a, b):
+        y.rollout("random", n_iter=120)
+        for name in BatchedJssEnv._STATE_TENSORS:
+            assert np.array_equal(getattr(x, name), getattr(y, name)), name
+    assert cpu.lib.jss_rollout_steps_multi(0, None, None, None, 0, 0, 0, 1, 0, None) == _abi.E_NULL
