@@ -953,7 +953,7 @@ __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel
     bool selected = true;
     if ((MODE == kReset || MODE == kAdvance) && p.which) selected = __builtin_amdgcn_readfirstlane((int)p.which[b]) != 0;
     if (TAB == kTabLds) {                                                // one instance for the whole batch: its op table -> LDS
-        stage_shared_table(lds, p.d.ops, p.d.inst[JSS_I_JOBS] * p.d.mmax, (int)threadIdx.x);
+        stage_shared_table(lds, p.d.ops, p.d.jmax * p.d.mmax, (int)threadIdx.x);   // one instance: jmax rows are its J rows
         __syncthreads();
     }
     if (!alive || !selected) return;

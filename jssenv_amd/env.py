@@ -557,6 +557,30 @@ class BatchedJssEnv:
         _abi.check(be.lib, rc, "jss_rollout_steps")
         return self._obs(), self.reward, self.done, False, {}
 
+    def bind_rollout_steps(self, kind: Union[str, int] = "random", steps: int = 1, n_sub: int = 2, seed: Optional[int] = None,
+                           autoreset: bool = True, explore: float = 0.0):
+        """``rollout_steps`` with every argument resolved now: returns a zero-argument callable that issues the same
+        launches on the stream that is current NOW and on the side streams (one C call, no Python-side work between
+        the call and the first launch).  For loops that issue the same window over and over (bench.py)."""
+        if not self._is_reset:
+            raise RuntimeError("call reset() before rollout_steps()")
+        be = self.backend
+        if not hasattr(be, "stream_array"):
+            return lambda: self.rollout_steps(kind, steps, n_sub, seed, autoreset, explore)
+        k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
+        flags = (_abi.ROLLOUT_AUTORESET if autoreset else 0) | _abi.ROLLOUT_FORK_JOIN
+        d, s, o = self._refs()
+        with be.on_device():
+            streams = be.stream_array(int(n_sub))
+        fn, sd, q16, n_steps, n = be.lib.jss_rollout_steps, self.seed if seed is None else int(seed), int(round(explore * 65536)), int(steps), int(n_sub)
+        lib = be.lib
+
+        def issue():
+            rc = fn(d, s, o, k, sd, q16, n_steps, flags, n, streams)
+            if rc:
+                _abi.check(lib, rc, "jss_rollout_steps")
+        return issue
+
     def trajectory(self, kind: Union[str, int] = "random", steps: int = 1, seed: Optional[int] = None,
                    autoreset: bool = True, explore: float = 0.0, buffers: Optional[dict] = None,
                    record=("real_obs", "action_mask", "action", "reward", "done")):
