@@ -65,20 +65,10 @@ template <int G>
 struct PEnv {
     int t;                    // group-uniform
     int todo, cur, nxt, nxt2, left, perf, idle, idle_last, f4;  // job gl (cur / nxt / nxt2: the job's next three ops, -1 = none)
-    int fill;                 // kTabGlobal: the op table entry refilling nxt2 while it is in flight (nxt2 == kPendingOp)
     int tm;                   // machine gl
     bool legal, blocked;      // job gl
     int noop, err;            // group-uniform
 };
-
-// nxt2 of a job that has just moved on to a new op while the global-memory read that refills it is still in flight
-// (PEnv::fill receives it): p_jump requests, p_settle consumes -- at the end of step(), earlier only if a look-ahead
-// walk of _check_no_op needs that very entry -- so the request's latency hides behind the rest of the step.
-constexpr int kPendingOp = -2;
-template <int G>
-__device__ __forceinline__ void p_settle(PEnv<G> &e) {
-    if (e.nxt2 == kPendingOp) e.nxt2 = e.fill;
-}
 
 template <int G>
 __device__ __forceinline__ uint32_t grp_ballot(bool p, int gbase) {
@@ -133,7 +123,6 @@ __device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G, TAB> &c, const
         e.cur = c.jvalid ? c.row(p)[0] : -1;                                // :174-176
         e.nxt = (c.jvalid && 1 < c.M) ? c.row(p)[1] : -1;
         e.nxt2 = (c.jvalid && 2 < c.M) ? c.row(p)[2] : -1;
-        e.fill = -1;
         e.left = e.perf = e.idle = e.idle_last = 0;                      // :165-170
         e.f4 = 0;                                                        // :180
         e.legal = c.jvalid;                                              // :160
@@ -253,12 +242,7 @@ __device__ __forceinline__ void p_jump(PEnv<G> &e, const PCtx<G, TAB> &c, const 
                 e.todo += 1;                                             // :558
                 e.cur = e.nxt;                                           // :562-566 / :581
                 e.nxt = e.nxt2;
-                if (e.todo + 2 < c.M) {
-                    e.fill = c.row(p)[e.todo + 2];                       // in flight until p_settle (an LDS read with kTabLds)
-                    e.nxt2 = TAB == kTabGlobal ? kPendingOp : e.fill;
-                } else {
-                    e.nxt2 = -1;
-                }
+                e.nxt2 = (e.todo + 2 < c.M) ? c.row(p)[e.todo + 2] : -1;
                 const bool more = e.cur >= 0;
                 e.idle += more ? T - f : 0;                              // :552 (+0 at the finish), then :596 per later event
                 e.idle_last = more ? T - f : 0;                          // :554, then :597
@@ -396,7 +380,6 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G, TAB> &c,
         ++k;
         go = k < last && mh > tn;
     }
-    if (TAB == kTabGlobal && __ballot(go && e.nxt2 == kPendingOp) != 0) p_settle(e);   // rare: the walk needs the entry being refilled
     if (go) {                                                                         // op k == todo + 2: the one after it
         const int m = e.nxt2 >> 16;
         if (tab[m] > tn) u |= 1u << m;
@@ -465,7 +448,6 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G, TAB> &c, const P
     }
     if (!JSS_ABLATED(p, JSS_ABLATE_PRIORITIZE)) p_prioritize(e, c, stepping);        // :432 / :471
     if (!JSS_ABLATED(p, JSS_ABLATE_CHECK_NO_OP)) p_check_no_op(e, c, p, stepping, mvtab);  // :433 / :472
-    if (TAB == kTabGlobal) p_settle(e);                                  // the refill p_jump requested has had the rest of the step to land
     return rn;
 }
 
@@ -565,7 +547,6 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, c
     e.f4 = v ? r.hi.z : 0;
     e.nxt = v ? r.hi.w : -1;
     e.nxt2 = (v && ((unsigned)r.lo.x >> JSS_NEXT2_SHIFT)) ? (int)((unsigned)r.lo.x >> JSS_NEXT2_SHIFT) : -1;
-    e.fill = -1;
     e.legal = v && (r.lo.x & JSS_FLAG_LEGAL);
     e.blocked = v && (r.lo.x & JSS_FLAG_BLOCKED);
     PHeader hd;
