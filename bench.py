@@ -322,8 +322,6 @@ def main():
         return e
 
     # ---- timing ---------------------------------------------------------------------------------------------
-    bound = {}
-
     def window(env, policy, n_launch, n_iter, mode, graph=None, run=None, prep=None, events=False):
         """Time n_launch steps.  Returns (wall seconds, GPU ms per step from HIP events on the launch stream -- only in
         the windows that ask for them: the windows behind `value` carry nothing but the steps)."""
@@ -341,11 +339,11 @@ def main():
         elif graph is not None:
             graph.replay()
         elif hasattr(env, "rollout_steps") and mode.startswith("sub"):
-            key = (id(env), policy, n_launch, mode)
-            if key not in bound:                 # arguments resolved once: the timed region holds one C call
-                bound.clear()
-                bound[key] = env.bind_rollout_steps(policy, steps=n_launch, n_sub=int(mode[3:]), autoreset=True)
-            bound[key]()
+            key = (policy, n_launch, mode)
+            cache = env.__dict__.setdefault("_bench_bound", {})     # lives and dies with the env object
+            if key not in cache:                 # arguments resolved once: the timed region holds one C call
+                cache[key] = env.bind_rollout_steps(policy, steps=n_launch, n_sub=int(mode[3:]), autoreset=True)
+            cache[key]()
         elif hasattr(env, "buckets"):   # one fork/join around the window, every bucket's launches on its own stream
             env.rollout_steps(policy, steps=n_launch, n_iter=n_iter, autoreset=True)
         else:
