@@ -47,6 +47,11 @@ import time
 # work, and the interrupt path adds tens of microseconds to every synchronize().  Process-wide HSA runtime setting,
 # must be in the environment before the runtime starts; reported in the JSON line (host.hsa_enable_interrupt).
 os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+# HIP deals streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; two streams that share a queue
+# run strictly one after the other.  The pipelined forms use up to 5 streams (main + side streams of sub-batches or
+# shape buckets): 8 queues keep them apart whatever was created before (profiles/README.md: the bucketed env measured
+# 0.43-0.53 of the roofline inside the full bench with 4 queues, depending on which queues its streams drew).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -704,7 +709,8 @@ def main():
             out["config4_sharded"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.synchronize()
 
-    out["host"] = {"hsa_enable_interrupt": os.environ.get("HSA_ENABLE_INTERRUPT"), **host_cores()}
+    out["host"] = {"hsa_enable_interrupt": os.environ.get("HSA_ENABLE_INTERRUPT"),
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), **host_cores()}
     out["csrc_sha16"] = csrc_hash()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "shared":
         for name, fn in (("cpu_baseline", cpu_baseline_restatement), ("cpu_baseline_port", cpu_baseline_port),
