@@ -344,13 +344,19 @@ def main():
         elif graph is not None:
             graph.replay()
         elif hasattr(env, "rollout_steps") and mode.startswith("sub"):
-            key = (policy, n_launch, mode)
+            # every window starts on an idle device and ends with a device-wide synchronize(): the sub-batch streams need
+            # no fork / join events inside it (caller_orders_streams; A/B: JSS_BENCH_FORK_JOIN=1).  The windows that carry
+            # HIP events on the launch stream keep the join, or the closing event would not wait for the side streams.
+            free = (not events) and os.environ.get("JSS_BENCH_FORK_JOIN", "0") != "1"
+            key = (policy, n_launch, mode, free)
             cache = env.__dict__.setdefault("_bench_bound", {})     # lives and dies with the env object
             if key not in cache:                 # arguments resolved once: the timed region holds one C call
-                cache[key] = env.bind_rollout_steps(policy, steps=n_launch, n_sub=int(mode[3:]), autoreset=True)
+                cache[key] = env.bind_rollout_steps(policy, steps=n_launch, n_sub=int(mode[3:]), autoreset=True,
+                                                    caller_orders_streams=free)
             cache[key]()
-        elif hasattr(env, "buckets"):   # one fork/join around the window, every bucket's launches on its own stream
-            env.rollout_steps(policy, steps=n_launch, n_iter=n_iter, autoreset=True)
+        elif hasattr(env, "buckets"):   # every bucket's launches on its own stream, one host call for the window
+            env.rollout_steps(policy, steps=n_launch, n_iter=n_iter, autoreset=True,
+                              caller_orders_streams=(not events) and os.environ.get("JSS_BENCH_FORK_JOIN", "0") != "1")
         else:
             for _ in range(n_launch):
                 env.rollout(policy, n_iter=n_iter, autoreset=True)

@@ -119,7 +119,8 @@ class BucketedJssEnv:
     def rollout(self, kind="random", n_iter=1, seed=None, autoreset=True, explore=0.0):
         self._fan_out(lambda k, b: b.rollout(kind, n_iter=n_iter, seed=seed, autoreset=autoreset, explore=explore))
 
-    def rollout_steps(self, kind="random", steps=1, n_iter=1, seed=None, autoreset=True, explore=0.0, chunk=8):
+    def rollout_steps(self, kind="random", steps=1, n_iter=1, seed=None, autoreset=True, explore=0.0, chunk=8,
+                      caller_orders_streams=False):
         """`steps` consecutive rollout(n_iter) launches per bucket with ONE fork/join around the whole
         window: bucket k's launch i+1 depends only on bucket k's launch i, so the buckets run ahead of
         each other on their own streams (no per-step synchronisation, no graph capture needed).
@@ -148,7 +149,8 @@ class BucketedJssEnv:
                 self._multi = ((D * n)(*[C.pointer(b._desc) for _, b in each]), (S * n)(*[C.pointer(b._state) for _, b in each]),
                                (O * n)(*[C.pointer(b._out) for _, b in each]))
             k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
-            flags = (_abi.ROLLOUT_AUTORESET if autoreset else 0) | _abi.ROLLOUT_FORK_JOIN
+            # caller_orders_streams: the device is idle now and the caller synchronises the whole device afterwards
+            flags = (_abi.ROLLOUT_AUTORESET if autoreset else 0) | (0 if caller_orders_streams else _abi.ROLLOUT_FORK_JOIN)
             sd = each[0][1].seed if seed is None else int(seed)
             with be.on_device():
                 rc = be.lib.jss_rollout_steps_multi(n, *self._multi, k, sd, int(round(explore * 65536)), int(steps), flags,

@@ -558,17 +558,20 @@ class BatchedJssEnv:
         return self._obs(), self.reward, self.done, False, {}
 
     def bind_rollout_steps(self, kind: Union[str, int] = "random", steps: int = 1, n_sub: int = 2, seed: Optional[int] = None,
-                           autoreset: bool = True, explore: float = 0.0):
+                           autoreset: bool = True, explore: float = 0.0, caller_orders_streams: bool = False):
         """``rollout_steps`` with every argument resolved now: returns a zero-argument callable that issues the same
         launches on the stream that is current NOW and on the side streams (one C call, no Python-side work between
-        the call and the first launch).  For loops that issue the same window over and over (bench.py)."""
+        the call and the first launch).  For loops that issue the same window over and over (bench.py).
+        ``caller_orders_streams=True``: the library does not fork / join the side streams -- the caller guarantees that
+        the device is idle when the call is made and synchronises the whole device (not just its stream) before it
+        touches the results (include/jss_hip.h: "the caller orders streams[] against its own stream")."""
         if not self._is_reset:
             raise RuntimeError("call reset() before rollout_steps()")
         be = self.backend
         if not hasattr(be, "stream_array"):
             return lambda: self.rollout_steps(kind, steps, n_sub, seed, autoreset, explore)
         k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
-        flags = (_abi.ROLLOUT_AUTORESET if autoreset else 0) | _abi.ROLLOUT_FORK_JOIN
+        flags = (_abi.ROLLOUT_AUTORESET if autoreset else 0) | (0 if caller_orders_streams else _abi.ROLLOUT_FORK_JOIN)
         d, s, o = self._refs()
         with be.on_device():
             streams = be.stream_array(int(n_sub))
