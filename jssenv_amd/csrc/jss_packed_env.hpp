@@ -793,11 +793,17 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
 // With kTabGlobal the instance (tid, J, M, max_time_op) is group-uniform data in VGPRs instead of SGPRs: the step
 // kernels need 66-70 VGPRs.  7 waves/SIMD (72 VGPRs) beats 8 with two VGPRs in scratch: 19.4 vs 21.5 us per step
 // on synthetic 15x15, B = 65 536 (profiles/README.md).
+#ifndef JSS_PTRAJ_LDS_MIN_BLOCKS
+#define JSS_PTRAJ_LDS_MIN_BLOCKS 4
+#endif
+#ifndef JSS_PTRAJ_GLOBAL_MIN_BLOCKS
+#define JSS_PTRAJ_GLOBAL_MIN_BLOCKS 4
+#endif
 #ifndef JSS_PACKED_GLOBAL_MIN_BLOCKS
 #define JSS_PACKED_GLOBAL_MIN_BLOCKS 7
 #endif
 template <int G, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, MODE == kTraj ? (TAB == kTabGlobal ? 3 : 4)
+__global__ __launch_bounds__(kBlock, MODE == kTraj ? (TAB == kTabGlobal ? JSS_PTRAJ_GLOBAL_MIN_BLOCKS : JSS_PTRAJ_LDS_MIN_BLOCKS)
                                      : MODE == kRollout ? (TAB == kTabGlobal ? 4 : 5)
                                      : ((TAB == kTabGlobal && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
 void jss_packed_kernel(Params p) {
