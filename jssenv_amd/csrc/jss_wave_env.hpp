@@ -925,6 +925,9 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
 #ifndef JSS_WAVE_MIN_BLOCKS
 #define JSS_WAVE_MIN_BLOCKS 8
 #endif
+#ifndef JSS_WAVE2_MIN_BLOCKS
+#define JSS_WAVE2_MIN_BLOCKS 7
+#endif
 #ifndef JSS_TRAJ1_MIN_BLOCKS
 #define JSS_TRAJ1_MIN_BLOCKS 6
 #endif
@@ -936,7 +939,7 @@ constexpr int wave_min_blocks(int jpl, int mode) {
     return mode == kTraj ? (jpl == 2 ? JSS_TRAJ2_MIN_BLOCKS : JSS_TRAJ1_MIN_BLOCKS)
          : mode == kRollout ? (jpl == 2 ? 5 : 7)
          : mode == kStep ? (jpl == 2 ? 5 : 8)
-         : mode == kRollout1 ? (jpl == 2 ? 7 : JSS_WAVE_MIN_BLOCKS)
+         : mode == kRollout1 ? (jpl == 2 ? JSS_WAVE2_MIN_BLOCKS : JSS_WAVE_MIN_BLOCKS)
          : (jpl == 2 ? 7 : 8);
 }
 template <int JPL, int MODE, int TAB>
