@@ -51,6 +51,8 @@
  *                                                float32 reciprocals
  *   job state     int32 [B][jmax][JSS_NF]        one 32-byte record per job (JSS_F_* words below):
  *                                                a lane moves its job with two dwordx4 accesses
+ *                 or    [B][jmax][JSS_NFC]       24-byte compact records (JSS_FC_*) when the batch shares one instance
+ *                                                and JssDesc.record_ints says so
  *   env header    int32 [B][JSS_NH]              JSS_H_*: clock, episode, step, status
  *   env constants int32 [B][JSS_NC]              JSS_C_*: the env's instance constants (copied in by reset)
  *   machine state int32 [B][mmax]                time_until_available_machine
@@ -68,7 +70,7 @@
 extern "C" {
 #endif
 
-#define JSS_ABI_VERSION 6
+#define JSS_ABI_VERSION 7
 
 #define JSS_MAX_JOBS 128
 #define JSS_MAX_MACHINES 64
@@ -90,6 +92,17 @@ extern "C" {
                              touches the op table only when a job moves on, or when a look-ahead walk of
                              _check_no_op goes further than three ops */
 #define JSS_NF 8
+/* The compact record (JssDesc.record_ints == JSS_NFC; only for a batch that shares ONE instance, n_tables == 1): the
+ * three cached ops are what the op table says at [j][todo .. todo + 2], and with one table for the whole batch every
+ * workgroup has that table in LDS anyway -- so the record does not carry them: 24 bytes per job instead of 32, a
+ * quarter less state traffic.  Words: */
+#define JSS_FC_TODO 0      /* bits 0-7 todo_time_step_job, bit 8 legal, bit 9 action_illegal_no_op; bits 10-31 zero */
+#define JSS_FC_LEFT 1
+#define JSS_FC_PERF 2
+#define JSS_FC_IDLE 3
+#define JSS_FC_IDLE_LAST 4
+#define JSS_FC_F4 5
+#define JSS_NFC 6
 #define JSS_F4_ONE (-1)
 #define JSS_TODO_MASK 255
 #define JSS_FLAG_LEGAL 256
@@ -190,13 +203,14 @@ typedef struct JssDesc {
     int32_t jmin;                /* hint: smallest J among the batch's instances (0 = unknown, read as jmax).  When
                                     jmin < jmax (a ragged, padded batch) the one-wavefront-per-env kernels read the
                                     instance record BEFORE the job records and never load the rows behind J(env)  */
-    int32_t reserved;            /* 0                                                       */
+    int32_t record_ints;         /* ints per job record: 0 or JSS_NF = full records; JSS_NFC = compact records
+                                    (n_tables == 1 only, else JSS_E_SHAPE)                  */
 } JssDesc;
 
 typedef struct JssState {
     int32_t *env;      /* [B][JSS_NH]  JSS_H_*                                         */
     int32_t *env_const;/* [B][JSS_NC]  JSS_C_*: written by reset, read by the step-type calls */
-    int32_t *job;      /* [B][jmax][JSS_NF]                                            */
+    int32_t *job;      /* [B][jmax][JSS_NF] (or [B][jmax][JSS_NFC], JssDesc.record_ints)   */
     int32_t *machine;  /* [B][mmax]                                                    */
     int32_t *solution; /* [B][jmax][mmax]                                              */
     int64_t *counters; /* [B][4]: env steps, finished episodes, sum of makespans,

@@ -9,10 +9,14 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_JOBS, MAX_MACHINES = 128, 64
 F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_NEXT, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
 TODO_MASK, FLAG_LEGAL, FLAG_BLOCKED, NEXT2_SHIFT = 255, 256, 512, 10
+# compact 24-byte record of shared-instance batches (JSS_FC_*): no cached ops
+FC_TODO, FC_LEFT, FC_PERF, FC_IDLE, FC_IDLE_LAST, FC_F4, NFC = 0, 1, 2, 3, 4, 5, 6
+# position of JSS_F_* word f in the compact record (-1: not stored, read from the op table)
+FC_OF_F = (FC_TODO, -1, FC_LEFT, FC_PERF, FC_IDLE, FC_IDLE_LAST, FC_F4, -1)
 H_CLOCK, H_EPISODE, H_STEP, H_STATUS = 0, 1, 2, 3
 NH = 4
 C_JOBS, C_MACHINES, C_MAX_TIME_OP, C_TABLE, C_MAX_TIME_JOBS, C_SUM_OP = 0, 1, 2, 3, 4, 5
@@ -39,7 +43,7 @@ class JssDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("jmax", C.c_int32), ("mmax", C.c_int32), ("n_tables", C.c_int32),
                 ("ops", _p), ("rem", _p), ("inst", _p), ("table_of_env", _p), ("env_ids", _p),
                 ("env_id_base", C.c_int64), ("kernel", C.c_int32), ("threads", C.c_int32),
-                ("jmin", C.c_int32), ("reserved", C.c_int32)]
+                ("jmin", C.c_int32), ("record_ints", C.c_int32)]
 
 
 class JssState(C.Structure):

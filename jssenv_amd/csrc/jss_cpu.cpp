@@ -50,15 +50,32 @@ struct Env {
     int32_t *tm;                // [mmax]
     int32_t *sol;               // [jmax][mmax]
 
-    int32_t &w(int j, int f) const { return job[j * JSS_NF + f]; }
+    bool compact;               // 24-byte records (JSS_FC_*): the cached ops are read from the op table instead
+    // word f (JSS_F_* numbering) of job j's record; the compact record holds TODO, LEFT, PERF, IDLE, IDLE_LAST, F4 only
+    int32_t &w(int j, int f) const {
+        static const int pos[JSS_NF] = {JSS_FC_TODO, -1, JSS_FC_LEFT, JSS_FC_PERF, JSS_FC_IDLE, JSS_FC_IDLE_LAST, JSS_FC_F4, -1};
+        return compact ? job[j * JSS_NFC + pos[f]] : job[j * JSS_NF + f];
+    }
+    int op_at(int j, int k) const { return k < M ? ops[j * stride + k] : -1; }
+    int cur(int j) const { return compact ? op_at(j, todo(j)) : w(j, JSS_F_CUR); }          // current op, -1 = job finished
+    int nxt(int j) const { return compact ? op_at(j, todo(j) + 1) : w(j, JSS_F_NEXT); }
     int todo(int j) const { return w(j, JSS_F_TODO) & JSS_TODO_MASK; }
     bool legal(int j) const { return w(j, JSS_F_TODO) & JSS_FLAG_LEGAL; }
     bool blocked(int j) const { return w(j, JSS_F_TODO) & JSS_FLAG_BLOCKED; }
     void set_legal(int j, bool v) const { w(j, JSS_F_TODO) = (w(j, JSS_F_TODO) & ~JSS_FLAG_LEGAL) | (v ? JSS_FLAG_LEGAL : 0); }
     void set_blocked(int j, bool v) const { w(j, JSS_F_TODO) = (w(j, JSS_F_TODO) & ~JSS_FLAG_BLOCKED) | (v ? JSS_FLAG_BLOCKED : 0); }
     int next2(int j) const {                                             // op table entry [j][todo + 2], -1 = none
+        if (compact) return op_at(j, todo(j) + 2);
         const unsigned v = (unsigned)w(j, JSS_F_TODO) >> JSS_NEXT2_SHIFT;
         return v ? (int)v : -1;
+    }
+    // the record's cached ops after todo(j) changed (or at reset): cur <- [todo], next <- [todo + 1], next2 <- [todo + 2]
+    void refresh_ops(int j, bool valid) const {
+        if (compact) return;
+        const int k = todo(j);
+        w(j, JSS_F_CUR) = valid ? op_at(j, k) : -1;
+        w(j, JSS_F_NEXT) = valid ? op_at(j, k + 1) : -1;
+        set_next2(j, valid ? op_at(j, k + 2) : -1);
     }
     void set_next2(int j, int op) const {
         w(j, JSS_F_TODO) = (int32_t)(((unsigned)w(j, JSS_F_TODO) & ((1u << JSS_NEXT2_SHIFT) - 1u)) |
@@ -97,7 +114,8 @@ Env env_of(const Call &c, int b, bool from_instance) {
     e.stride = d.mmax;
     e.jmax = d.jmax;
     e.mmax = d.mmax;
-    e.job = c.s.job + (size_t)b * d.jmax * JSS_NF;
+    e.compact = d.record_ints == JSS_NFC;
+    e.job = c.s.job + (size_t)b * d.jmax * (e.compact ? JSS_NFC : JSS_NF);
     e.tm = c.s.machine + (size_t)b * d.mmax;
     e.sol = c.s.solution + b * region;
     return e;
@@ -131,9 +149,7 @@ void reset_env(const Env &e) {
     for (int j = 0; j < e.jmax; ++j) {                                    // rows behind J: "no job" (todo 0, no op)
         const bool v = j < e.J;
         e.w(j, JSS_F_TODO) = v ? JSS_FLAG_LEGAL : 0;                      // todo 0 (:166), legal (:160), not blocked (:171)
-        e.w(j, JSS_F_CUR) = v ? e.ops[j * e.stride] : -1;                 // :174-176 needed machine = op 0
-        e.w(j, JSS_F_NEXT) = (v && 1 < e.M) ? e.ops[j * e.stride + 1] : -1;
-        e.set_next2(j, (v && 2 < e.M) ? e.ops[j * e.stride + 2] : -1);
+        e.refresh_ops(j, v);                                              // :174-176 needed machine = op 0
         e.w(j, JSS_F_LEFT) = e.w(j, JSS_F_PERF) = e.w(j, JSS_F_IDLE) = e.w(j, JSS_F_IDLE_LAST) = 0;   // :165-170
         e.w(j, JSS_F_F4) = 0;                                             // :180
     }
@@ -161,10 +177,8 @@ int advance(const Env &e) {
                 e.w(j, JSS_F_IDLE_LAST) = d - was;                        // :554
                 const int k = e.todo(j) + 1;                              // :558
                 e.w(j, JSS_F_TODO) = (e.w(j, JSS_F_TODO) & ~JSS_TODO_MASK) | k;
-                const int cur = e.w(j, JSS_F_NEXT);                       // :562-566 the job moves on (-1: complete, :581)
-                e.w(j, JSS_F_CUR) = cur;
-                e.w(j, JSS_F_NEXT) = e.next2(j);                          // the record carries the next three ops
-                e.set_next2(j, k + 2 < e.M ? e.ops[j * e.stride + k + 2] : -1);
+                e.refresh_ops(j, true);                                   // :562-566 the job moves on (-1: complete, :581)
+                const int cur = e.cur(j);
                 e.w(j, JSS_F_F4) = cur >= 0 ? e.tm[cur >> 16] : JSS_F4_ONE;   // :569-586 (machine clocks already advanced)
             }
         } else if (e.todo(j) < e.M) {                                     // :594 waiting
@@ -173,7 +187,7 @@ int advance(const Env &e) {
         }
     }
     for (int j = 0; j < e.J; ++j) {                                       // :616-634 re-legalisation
-        const int cur = e.w(j, JSS_F_CUR);
+        const int cur = e.cur(j);
         if (cur >= 0 && e.tm[cur >> 16] == 0 && !e.blocked(j)) e.set_legal(j, true);
     }
     return hole;
@@ -189,13 +203,13 @@ void prioritize(const Env &e) {
     for (int m = 0; m < e.M; ++m) min_nf[m] = kBig;
     for (int j = 0; j < e.J; ++j) {
         if (!e.legal(j) || e.todo(j) >= e.M - 1) continue;
-        if (e.tm[e.w(j, JSS_F_NEXT) >> 16] != 0) continue;                // :234
-        const int cur = e.w(j, JSS_F_CUR);
+        if (e.tm[e.nxt(j) >> 16] != 0) continue;                // :234
+        const int cur = e.cur(j);
         if ((cur & kDurMask) < min_nf[cur >> 16]) min_nf[cur >> 16] = cur & kDurMask;
     }
     for (int j = 0; j < e.J; ++j) {                                       // :244-254
         if (!e.legal(j) || e.todo(j) != e.M - 1) continue;
-        const int cur = e.w(j, JSS_F_CUR);
+        const int cur = e.cur(j);
         if ((cur & kDurMask) > min_nf[cur >> 16]) e.set_legal(j, false);
     }
 }
@@ -222,7 +236,7 @@ void check_no_op(const Env &e) {
     int n_ml = 0;
     for (int m = 0; m < e.M; ++m) m_legal[m] = false;
     for (int i = 0; i < nl; ++i) {
-        const int m = e.w(legal_jobs[i], JSS_F_CUR) >> 16;
+        const int m = e.cur(legal_jobs[i]) >> 16;
         if (!m_legal[m]) {
             m_legal[m] = true;
             ++n_ml;
@@ -232,7 +246,7 @@ void check_no_op(const Env &e) {
     for (int m = 0; m < e.M; ++m) horizon[m] = t + e.max_time_op;         // :300-302
     int max_horizon = t;                                                  // :296
     for (int i = 0; i < nl; ++i) {
-        const int cur = e.w(legal_jobs[i], JSS_F_CUR);
+        const int cur = e.cur(legal_jobs[i]);
         const int end = t + (cur & kDurMask);                             // :310
         if (end < next_event) return;                                     // :314-315
         if (end < horizon[cur >> 16]) horizon[cur >> 16] = end;           // :318
@@ -248,10 +262,10 @@ void check_no_op(const Env &e) {
         const bool caseB = !caseA && !e.blocked(j) && todo < e.M;         // :366-369 waiting for its machine
         if (!caseA && !caseB) continue;
         int k = caseA ? todo + 1 : todo;                                  // :332 / :370
-        int tn = caseA ? t + e.w(j, JSS_F_LEFT) : t + e.tm[e.w(j, JSS_F_CUR) >> 16];   // :334-337 / :374-377
+        int tn = caseA ? t + e.w(j, JSS_F_LEFT) : t + e.tm[e.cur(j) >> 16];   // :334-337 / :374-377
         while (k < e.M - 1 && max_horizon > tn) {                         // :340-342 / :380-382
-            const int op = k == todo ? e.w(j, JSS_F_CUR)
-                           : k == todo + 1 ? e.w(j, JSS_F_NEXT)
+            const int op = k == todo ? e.cur(j)
+                           : k == todo + 1 ? e.nxt(j)
                            : k == todo + 2 ? e.next2(j) : e.ops[j * e.stride + k];
             const int m = op >> 16;
             if (m_legal[m] && horizon[m] > tn) covered[m] = true;         // :346-351
@@ -291,14 +305,14 @@ int step_env(const Env &e, int a) {
             e.flag(JSS_ERR_ILLEGAL_ACTION);
             return 0;
         }
-        const int cur = e.w(a, JSS_F_CUR);
+        const int cur = e.cur(a);
         const int m = cur >> 16, d = cur & kDurMask;                      // :443-444
         rn = d;                                                           // :445
         e.tm[m] = d;                                                      // :446
         e.w(a, JSS_F_LEFT) = d;                                           // :447
         e.sol[a * e.stride + e.todo(a)] = e.t();                          // :454
         for (int j = 0; j < e.J; ++j) {
-            const int cj = e.w(j, JSS_F_CUR);
+            const int cj = e.cur(j);
             if (cj >= 0 && (cj >> 16) == m) {
                 e.set_legal(j, false);                                    // :455-463
                 e.set_blocked(j, false);                                  // :464-467
@@ -357,7 +371,7 @@ int select_action(const Env &e, const Call &c, uint64_t env_id) {
         bool larger = false;
         switch (c.kind) {
         case JSS_POLICY_FIFO: v = e.w(j, JSS_F_IDLE_LAST); larger = true; break;      // :146
-        case JSS_POLICY_SPT: v = e.w(j, JSS_F_CUR) & kDurMask; break;                 // :105-106
+        case JSS_POLICY_SPT: v = e.cur(j) & kDurMask; break;                 // :105-106
         case JSS_POLICY_MWR: v = e.rem[j * e.stride + todo]; larger = true; break;    // :187-189
         case JSS_POLICY_LWR: v = e.rem[j * e.stride + todo]; break;                   // :230-232
         case JSS_POLICY_MOR: v = e.M - todo; larger = true; break;                    // :273
@@ -563,6 +577,8 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
         return JSS_E_SHAPE;
     if (!d->table_of_env && d->n_tables != 1 && d->n_tables != d->batch) return JSS_E_SHAPE;
     if (d->kernel != JSS_KERNEL_AUTO && d->kernel != JSS_KERNEL_WAVE) return JSS_E_KIND;
+    if (d->record_ints != 0 && d->record_ints != JSS_NF && d->record_ints != JSS_NFC) return JSS_E_SHAPE;
+    if (d->record_ints == JSS_NFC && d->n_tables != 1) return JSS_E_SHAPE;
     return 0;
 }
 

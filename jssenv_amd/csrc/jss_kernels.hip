@@ -26,6 +26,8 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
         return JSS_E_SHAPE;
     if (!d->table_of_env && d->n_tables != 1 && d->n_tables != d->batch) return JSS_E_SHAPE;
     if (d->kernel != JSS_KERNEL_AUTO && d->kernel != JSS_KERNEL_WAVE) return JSS_E_KIND;
+    if (d->record_ints != 0 && d->record_ints != JSS_NF && d->record_ints != JSS_NFC) return JSS_E_SHAPE;
+    if (d->record_ints == JSS_NFC && d->n_tables != 1) return JSS_E_SHAPE;   // compact records need the ONE table in LDS
     return 0;
 }
 
@@ -75,12 +77,17 @@ int packed_group(const JssDesc &d) {
 
 using KernelFn = void (*)(Params);
 
+template <int MODE, int TAB>
+KernelFn pick_tab(int G, int jpl) {
+    if (G == 16) return jss_packed_kernel<16, MODE, TAB>;
+    if (G == 32) return jss_packed_kernel<32, MODE, TAB>;
+    if (jpl == 1) return jss_kernel<1, MODE, TAB>;
+    return jss_kernel<2, MODE, TAB>;
+}
 template <int MODE>
-KernelFn pick(int G, int jpl, bool shared) {
-    if (G == 16) return shared ? jss_packed_kernel<16, MODE, kTabLds> : jss_packed_kernel<16, MODE, kTabGlobal>;
-    if (G == 32) return shared ? jss_packed_kernel<32, MODE, kTabLds> : jss_packed_kernel<32, MODE, kTabGlobal>;
-    if (jpl == 1) return shared ? jss_kernel<1, MODE, kTabLds> : jss_kernel<1, MODE, kTabGlobal>;
-    return shared ? jss_kernel<2, MODE, kTabLds> : jss_kernel<2, MODE, kTabGlobal>;
+KernelFn pick(int G, int jpl, bool shared, bool compact) {
+    if (!shared) return pick_tab<MODE, kTabGlobal>(G, jpl);
+    return compact ? pick_tab<MODE, kTabLdsC>(G, jpl) : pick_tab<MODE, kTabLds>(G, jpl);
 }
 
 struct LaunchPlan {
@@ -116,7 +123,7 @@ int plan(Params &p, LaunchPlan &lp) {
     lp.shmem += g_lds_pad;
 #endif
     if (lp.shmem > kMaxDynamicLds) return JSS_E_LDS;
-    lp.fn = pick<MODE>(G, p.d.jmax <= kWave ? 1 : 2, shared);
+    lp.fn = pick<MODE>(G, p.d.jmax <= kWave ? 1 : 2, shared, p.d.record_ints == JSS_NFC);
     return 0;
 }
 
@@ -146,7 +153,7 @@ Params sub_batch(const Params &p, int start, int count) {
     q.d.env_id_base = p.d.env_id_base + start;
     q.s.env = p.s.env + s0 * JSS_NH;
     q.s.env_const = p.s.env_const + s0 * JSS_NC;
-    q.s.job = p.s.job + s0 * jm * JSS_NF;
+    q.s.job = p.s.job + s0 * jm * (p.d.record_ints == JSS_NFC ? JSS_NFC : JSS_NF);
     q.s.machine = p.s.machine + s0 * mm;
     q.s.solution = p.s.solution + s0 * jm * mm;
     if (p.s.counters) q.s.counters = p.s.counters + s0 * 4;

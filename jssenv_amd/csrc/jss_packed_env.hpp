@@ -56,7 +56,7 @@ struct PCtx {                 // per-lane view of "my env"
     // op table row of my job.  With kTabGlobal the 64-bit address is rebuilt from `tid` at each of its (few) uses
     // rather than carried in two VGPRs through the whole kernel (these kernels are the register-hungry ones).
     __device__ __forceinline__ const int32_t *row(const Params &p) const {
-        if (TAB == kTabLds) return lds_row;
+        if (tab_in_lds(TAB)) return lds_row;
         return p.d.ops + (size_t)tid * p.region_ints + (gl < p.d.jmax ? gl : 0) * p.d.mmax;
     }
 };
@@ -523,10 +523,18 @@ __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G, TAB> &c, const Pa
     const unsigned mc = (unsigned)c.gl < mm ? c.gl : 0;
     const size_t fe = (size_t)c.first_env;
     r.h = ld_off<int4>(p.s.env + fe * JSS_NH, c.rel * (JSS_NH * 4u));
-    const int32_t *jb = p.s.job + fe * jm * JSS_NF;
-    const unsigned jo = (c.rel * jm + jc) * 32u;
-    r.lo = ld_off<int4>(jb, jo);
-    r.hi = ld_off<int4>(jb, jo + 16u);
+    if (tab_compact(TAB)) {          // 24-byte records: (w0, left, perf, idle | idle_last, f4)
+        const int32_t *jb = p.s.job + fe * jm * JSS_NFC;
+        const unsigned jo = (c.rel * jm + jc) * (JSS_NFC * 4u);
+        r.lo = ld_off<int4>(jb, jo);
+        const int2 h2 = ld_off<int2>(jb, jo + 16u);
+        r.hi = make_int4(h2.x, h2.y, 0, 0);
+    } else {
+        const int32_t *jb = p.s.job + fe * jm * JSS_NF;
+        const unsigned jo = (c.rel * jm + jc) * 32u;
+        r.lo = ld_off<int4>(jb, jo);
+        r.hi = ld_off<int4>(jb, jo + 16u);
+    }
     r.tm = ld_off<int>(p.s.machine + fe * mm, (c.rel * mm + mc) * 4u);
     return r;
 }
@@ -539,14 +547,25 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, c
     e.tm = c.mvalid ? r.tm : 0;
     const bool v = c.jvalid;
     e.todo = v ? (r.lo.x & JSS_TODO_MASK) : 0;
-    e.cur = v ? r.lo.y : -1;
-    e.left = v ? r.lo.z : 0;
-    e.perf = v ? r.lo.w : 0;
-    e.idle = v ? r.hi.x : 0;
-    e.idle_last = v ? r.hi.y : 0;
-    e.f4 = v ? r.hi.z : 0;
-    e.nxt = v ? r.hi.w : -1;
-    e.nxt2 = (v && ((unsigned)r.lo.x >> JSS_NEXT2_SHIFT)) ? (int)((unsigned)r.lo.x >> JSS_NEXT2_SHIFT) : -1;
+    if (tab_compact(TAB)) {          // the job's next three ops are what the LDS table says (staged before this runs)
+        e.left = v ? r.lo.y : 0;
+        e.perf = v ? r.lo.z : 0;
+        e.idle = v ? r.lo.w : 0;
+        e.idle_last = v ? r.hi.x : 0;
+        e.f4 = v ? r.hi.y : 0;
+        e.cur = (v && e.todo < c.M) ? c.lds_row[e.todo] : -1;
+        e.nxt = (v && e.todo + 1 < c.M) ? c.lds_row[e.todo + 1] : -1;
+        e.nxt2 = (v && e.todo + 2 < c.M) ? c.lds_row[e.todo + 2] : -1;
+    } else {
+        e.cur = v ? r.lo.y : -1;
+        e.left = v ? r.lo.z : 0;
+        e.perf = v ? r.lo.w : 0;
+        e.idle = v ? r.hi.x : 0;
+        e.idle_last = v ? r.hi.y : 0;
+        e.f4 = v ? r.hi.z : 0;
+        e.nxt = v ? r.hi.w : -1;
+        e.nxt2 = (v && ((unsigned)r.lo.x >> JSS_NEXT2_SHIFT)) ? (int)((unsigned)r.lo.x >> JSS_NEXT2_SHIFT) : -1;
+    }
     e.legal = v && (r.lo.x & JSS_FLAG_LEGAL);
     e.blocked = v && (r.lo.x & JSS_FLAG_BLOCKED);
     PHeader hd;
@@ -574,7 +593,7 @@ struct PNorm {
 template <int G, int TAB>
 __device__ __forceinline__ PNorm p_norm(const PCtx<G, TAB> &c) {
     PNorm n;
-    if (TAB == kTabLds) {
+    if (tab_in_lds(TAB)) {
         n.max_time_jobs = c.max_time_jobs; n.sum_op = c.sum_op;
         n.r_op = c.r_op; n.r_jobs = c.r_jobs; n.r_sum = c.r_sum; n.r_m = c.r_m;
     } else {
@@ -607,7 +626,16 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
     }
     if (fresh ? (unsigned)c.gl < mm : (c.mvalid && e.tm != raw.tm))      // idle machines stay 0
         st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
-    if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
+    if (tab_compact(TAB)) {
+        if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
+            int32_t *jb = p.s.job + fe * jm * JSS_NFC;
+            const unsigned jo = (c.rel * jm + c.gl) * (JSS_NFC * 4u);
+            const int4 lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0), e.left, e.perf, e.idle);
+            // unchanged parts of the record are not rewritten (steps without a time advance touch few jobs)
+            if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
+            if (fresh || e.idle_last != raw.hi.x || e.f4 != raw.hi.y) st_off(jb, jo + 16u, make_int2(e.idle_last, e.f4));
+        }
+    } else if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
         int32_t *jb = p.s.job + fe * jm * JSS_NF;
         const unsigned jo = (c.rel * jm + c.gl) * 32u;
         const int4 lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0) |
@@ -661,7 +689,7 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G, TAB>
 // instance record (kTabGlobal; with kTabLds the whole batch shares one instance and nothing changes)
 template <int G, int TAB>
 __device__ __forceinline__ void p_reload_instance(PCtx<G, TAB> &c, const Params &p, bool on) {
-    if (TAB == kTabLds) return;
+    if (tab_in_lds(TAB)) return;
     if (__ballot(on) == 0) return;
     const size_t fe = (size_t)c.first_env;
     int tid = c.tid;
@@ -851,12 +879,12 @@ void jss_packed_kernel(Params p) {
         }
     }
     // 2. instance constants; the shared op table -> LDS
-    if (TAB == kTabLds) {
+    if (tab_in_lds(TAB)) {
         stage_shared_table(lds, p.d.ops, p.d.jmax * p.d.mmax, (int)threadIdx.x);   // one instance: jmax rows are its J rows
         __syncthreads();
     }
     if (wave_dead) return;
-    if (TAB == kTabLds) {                             // one instance for the whole batch: scalar loads, issued up here
+    if (tab_in_lds(TAB)) {                            // one instance for the whole batch: scalar loads, issued up here
         const int32_t *ir = p.d.inst;
         c.J = ir[JSS_I_JOBS];
         c.M = ir[JSS_I_MACHINES];

@@ -567,37 +567,47 @@ struct RawEnv {  // what the state loads returned: unchanged halves of a record 
 // Rows j < jlimit of the env's job records + its machine clocks.  Lanes behind the limit issue no request and hold
 // the record of a job that does not exist (todo 0, no op, nothing running) -- which is also what reset() leaves in
 // the rows between J(env) and jmax, so nothing has to be masked after the load.
-template <int JPL>
+template <int JPL, int TAB>
 __device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params &p, int jlimit) {
     RawEnv<JPL> r;
-    const int32_t *jb = p.s.job + (size_t)b * p.d.jmax * JSS_NF;
+    const int32_t *jb = p.s.job + (size_t)b * p.d.jmax * (tab_compact(TAB) ? JSS_NFC : JSS_NF);
     r.tm = ld_off<int>(p.s.machine + (size_t)b * p.d.mmax, (unsigned)(lane < p.d.mmax ? lane : 0) * 4u);
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + lane;
-        r.lo[s] = make_int4(0, -1, 0, 0);
-        r.hi[s] = make_int4(0, 0, 0, -1);
-        if (j < jlimit) {
-            r.lo[s] = ld_off<int4>(jb, (unsigned)j * 32u);
-            r.hi[s] = ld_off<int4>(jb, (unsigned)j * 32u + 16u);
+        if (tab_compact(TAB)) {          // 24-byte records: (w0, left, perf, idle | idle_last, f4)
+            r.lo[s] = make_int4(0, 0, 0, 0);
+            r.hi[s] = make_int4(0, 0, 0, 0);
+            if (j < jlimit) {
+                r.lo[s] = ld_off<int4>(jb, (unsigned)j * (JSS_NFC * 4u));
+                const int2 h2 = ld_off<int2>(jb, (unsigned)j * (JSS_NFC * 4u) + 16u);
+                r.hi[s] = make_int4(h2.x, h2.y, 0, 0);
+            }
+        } else {
+            r.lo[s] = make_int4(0, -1, 0, 0);
+            r.hi[s] = make_int4(0, 0, 0, -1);
+            if (j < jlimit) {
+                r.lo[s] = ld_off<int4>(jb, (unsigned)j * 32u);
+                r.hi[s] = ld_off<int4>(jb, (unsigned)j * 32u + 16u);
+            }
         }
     }
     return r;
 }
 
-template <int JPL>
+template <int JPL, int TAB>
 __device__ __forceinline__ RawEnv<JPL> blank_raw() {                      // reset: nothing is read, everything is written
     RawEnv<JPL> r;
     r.tm = 0;
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
-        r.lo[s] = make_int4(0, -1, 0, 0);
-        r.hi[s] = make_int4(0, 0, 0, -1);
+        r.lo[s] = tab_compact(TAB) ? make_int4(0, 0, 0, 0) : make_int4(0, -1, 0, 0);
+        r.hi[s] = tab_compact(TAB) ? make_int4(0, 0, 0, 0) : make_int4(0, 0, 0, -1);
     }
     return r;
 }
 
-template <int JPL>
+template <int JPL, int TAB>
 __device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawEnv<JPL> &r, int clock, int status) {
     e.t = clock;
     e.err = status & 0xFF;
@@ -607,15 +617,28 @@ __device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawE
     for (int s = 0; s < JPL; ++s) {
         const int4 lo = r.lo[s], hi = r.hi[s];
         e.todo[s] = lo.x & JSS_TODO_MASK;
-        e.cur[s] = lo.y;
-        e.left[s] = lo.z;
-        e.perf[s] = lo.w;
-        e.idle[s] = hi.x;
-        e.idle_last[s] = hi.y;
-        e.f4[s] = hi.z;
-        e.nxt[s] = hi.w;
-        const int n2 = (int)((unsigned)lo.x >> JSS_NEXT2_SHIFT);
-        e.nxt2[s] = n2 ? n2 : -1;
+        if (tab_compact(TAB)) {      // the job's next three ops are what the LDS table says
+            const int j = s * kWave + c.lane, k = e.todo[s];
+            const bool v = j < c.J;
+            e.left[s] = lo.y;
+            e.perf[s] = lo.z;
+            e.idle[s] = lo.w;
+            e.idle_last[s] = hi.x;
+            e.f4[s] = hi.y;
+            e.cur[s] = (v && k < c.M) ? c.tab[j * c.stride + k] : -1;
+            e.nxt[s] = (v && k + 1 < c.M) ? c.tab[j * c.stride + k + 1] : -1;
+            e.nxt2[s] = (v && k + 2 < c.M) ? c.tab[j * c.stride + k + 2] : -1;
+        } else {
+            e.cur[s] = lo.y;
+            e.left[s] = lo.z;
+            e.perf[s] = lo.w;
+            e.idle[s] = hi.x;
+            e.idle_last[s] = hi.y;
+            e.f4[s] = hi.z;
+            e.nxt[s] = hi.w;
+            const int n2 = (int)((unsigned)lo.x >> JSS_NEXT2_SHIFT);
+            e.nxt2[s] = n2 ? n2 : -1;
+        }
         e.fill[s] = -1;
         e.legal[s] = __ballot((lo.x & JSS_FLAG_LEGAL) != 0);
         e.blocked[s] = (lo.x & JSS_FLAG_BLOCKED) != 0;
@@ -636,11 +659,11 @@ __device__ __forceinline__ void store_mask(const Env<JPL> &e, const Ctx &c, uint
 
 // State back to HBM.  all_rows = the env was (re)initialised: every row of the padded block is written (rows behind
 // J(env) as "no job"); otherwise rows < J(env), and of those only the halves that changed.
-template <int JPL>
+template <int JPL, int TAB>
 __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p, const Header &hd,
                                           const RawEnv<JPL> &raw, bool all_rows) {
     const int jm = p.d.jmax;
-    int32_t *jb = p.s.job + (size_t)c.b * jm * JSS_NF;
+    int32_t *jb = p.s.job + (size_t)c.b * jm * (tab_compact(TAB) ? JSS_NFC : JSS_NF);
     if (c.lane == 0) {
         *reinterpret_cast<int4 *>(p.s.env + (size_t)c.b * JSS_NH) =
             make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
@@ -660,6 +683,15 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = e.blocked[s] ? 1 : 0;
+        if (tab_compact(TAB)) {
+            const unsigned jo = (unsigned)j * (JSS_NFC * 4u);
+            const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0), e.left[s], e.perf[s], e.idle[s]);
+            const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
+            if (all_rows ? j < jm : (j < c.J && (lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w))) st_off<int4>(jb, jo, lo);
+            if (all_rows ? j < jm : (j < c.J && (e.idle_last[s] != hi0.x || e.f4[s] != hi0.y)))
+                st_off<int2>(jb, jo + 16u, make_int2(e.idle_last[s], e.f4[s]));
+            continue;
+        }
         const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0) |
                                       (e.nxt2[s] >= 0 ? (int)((unsigned)e.nxt2[s] << JSS_NEXT2_SHIFT) : 0), e.cur[s], e.left[s], e.perf[s]);
         const int4 hi = make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]);
@@ -742,7 +774,7 @@ __device__ __forceinline__ void ctx_from_instance(Ctx &c, const Params &p, int t
 template <int TAB>
 __device__ __forceinline__ void ctx_table(Ctx &c, const Params &p, const int32_t *lds) {
     c.stride = p.d.mmax;
-    c.tab = TAB == kTabLds ? lds : p.d.ops + (size_t)c.tid * p.region_ints;
+    c.tab = tab_in_lds(TAB) ? lds : p.d.ops + (size_t)c.tid * p.region_ints;
 }
 
 // Header and constants record of env b as wave-uniform values (scalar loads: nothing in this kernel has written them yet)
@@ -796,7 +828,7 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
     bool fresh = false;                                                  // the env was (re)initialised by this call
     if (MODE == kReset) {
         // nothing of the old state is needed but the episode counter
-        raw = blank_raw<JPL>();
+        raw = blank_raw<JPL, TAB>();
         hd.episode = __builtin_amdgcn_readfirstlane(h.episode) + 1;
         hd.step = 0;
         ctx_table<TAB>(c, p, lds);
@@ -809,21 +841,21 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
     } else {
         // 1. state loads: their addresses depend on nothing but the env index -- unless the batch is ragged
         //    (jmin < jmax): then the rows behind J(env), known from the header, are never requested
-        if (!ragged) raw = issue_loads<JPL>(b, lane, p, p.d.jmax);
+        if (!ragged) raw = issue_loads<JPL, TAB>(b, lane, p, p.d.jmax);
         ctx_from_header(c, h);
-        if (ragged) raw = issue_loads<JPL>(b, lane, p, c.J);
+        if (ragged) raw = issue_loads<JPL, TAB>(b, lane, p, c.J);
         if (c.J == 0) return;                                            // never reset: nothing to step
         ctx_table<TAB>(c, p, lds);
         hd.episode = __builtin_amdgcn_readfirstlane(h.episode);
         hd.step = __builtin_amdgcn_readfirstlane(h.step);
-        unpack_env(e, c, raw, __builtin_amdgcn_readfirstlane(h.clock), __builtin_amdgcn_readfirstlane(h.status));
+        unpack_env<JPL, TAB>(e, c, raw, __builtin_amdgcn_readfirstlane(h.clock), __builtin_amdgcn_readfirstlane(h.status));
     }
 
     if (MODE == kStep) {
         const bool restart = a_in == JSS_ACTION_RESET;                   // reset() this env instead of stepping it
         if (restart) {
             // the env may have been given another instance since its last reset (table_of_env)
-            const int tid = TAB == kTabLds ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : c.tid);
+            const int tid = tab_in_lds(TAB) ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : c.tid);
             ctx_from_instance(c, p, tid);
             ctx_table<TAB>(c, p, lds);
             hd.episode += 1;
@@ -907,7 +939,7 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
             if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, n_steps, n_done, sum_makespan, sum_rn);
         }
     }
-    store_env(e, c, p, hd, raw, fresh);
+    store_env<JPL, TAB>(e, c, p, hd, raw, fresh);
     store_mask(e, c, p.o.action_mask + (size_t)b * (p.d.jmax + 1), p.d.jmax);
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
         store_obs(e, c, p.o.real_obs + (size_t)b * p.d.jmax * 7, scratch, fresh ? p.d.jmax : c.J);
@@ -961,14 +993,14 @@ __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel
     if (MODE == kStep) a_in = __builtin_amdgcn_readfirstlane(p.actions[b]);
     bool selected = true;
     if ((MODE == kReset || MODE == kAdvance) && p.which) selected = __builtin_amdgcn_readfirstlane((int)p.which[b]) != 0;
-    if (TAB == kTabLds) {                                                // one instance for the whole batch: its op table -> LDS
+    if (tab_in_lds(TAB)) {                                                // one instance for the whole batch: its op table -> LDS
         stage_shared_table(lds, p.d.ops, p.d.jmax * p.d.mmax, (int)threadIdx.x);   // one instance: jmax rows are its J rows
         __syncthreads();
     }
     if (!alive || !selected) return;
     const bool ragged = p.d.jmin > 0 && p.d.jmin < p.d.jmax;
     if (MODE == kReset) {
-        const int tid = TAB == kTabLds ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : b);
+        const int tid = tab_in_lds(TAB) ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : b);
         ctx_from_instance(c, p, tid);
         wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);   // full width: a reset writes every row of the padded block
     } else {

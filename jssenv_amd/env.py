@@ -314,7 +314,7 @@ class BatchedJssEnv:
 
     def __init__(self, instances, batch: Optional[int] = None, device=None, env_id_base: int = 0,
                  table_of_env: Optional[Sequence[int]] = None, seed: int = 0, kernel: Optional[str] = None,
-                 _backend=None):
+                 compact: Optional[bool] = None, _backend=None):
         self._owns_backend = _backend is None
         self.backend = be = _backend if _backend is not None else make_backend(device)
         if isinstance(instances, PackedBatch):
@@ -344,6 +344,12 @@ class BatchedJssEnv:
             raise ValueError("table_of_env must hold B indices into instances")
         self.jobs_per_env = pk.jobs[self.table_of_env_host]
         self.machines_per_env = pk.machines[self.table_of_env_host]
+        # job records: 24-byte compact records (no cached ops: they are read from the ONE op table, which every workgroup
+        # has in LDS) whenever the batch shares one instance; 32-byte records otherwise
+        self.compact = (n == 1) if compact is None else bool(compact)
+        if self.compact and n != 1:
+            raise ValueError("compact job records need a batch that shares one instance")
+        self.record_ints = _abi.NFC if self.compact else _abi.NF
         self.kernel = kernel if kernel is not None else getattr(be, "default_kernel", "auto")
         if self.kernel not in _abi.KERNEL:
             raise ValueError(f"kernel must be one of {list(_abi.KERNEL)}")
@@ -361,7 +367,7 @@ class BatchedJssEnv:
             J, M = self.jmax, self.mmax
             specs = [("env_header", (B, _abi.NH), "int32"),     # clock, episode, step_in_episode, status
                      ("env_const", (B, _abi.NC), "int32"),      # the env's instance constants, written by reset (JSS_C_*)
-                     ("job_state", (B, J, _abi.NF), "int32"),   # one 32-byte record per job
+                     ("job_state", (B, J, self.record_ints), "int32"),   # one 32- (or compact: 24-) byte record per job
                      ("machine_state", (B, M), "int32"),
                      ("counters", (B, 4), "int64"),
                      ("real_obs", (B, J, 7), "float32"),
@@ -387,7 +393,7 @@ class BatchedJssEnv:
         p = be.ptr
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._rem), p(self._inst), p(self._table_of_env), None,
                                   self.env_id_base, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)),
-                                  int(pk.jobs.min()), 0)
+                                  int(pk.jobs.min()), self.record_ints)
         self._state = _abi.JssState(p(self.env_header), p(self.env_const), p(self.job_state), p(self.machine_state), p(self.solution),
                                     p(self.counters))
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
@@ -660,25 +666,37 @@ class BatchedJssEnv:
     def todo_time_step_job(self):
         return self.job_state[:, :, _abi.F_TODO] & _abi.TODO_MASK
 
+    def _word(self, f):
+        """Word JSS_F_* `f` of every job record as a (B, J) view, whichever record layout the batch uses."""
+        return self.job_state[:, :, _abi.FC_OF_F[f] if self.compact else f]
+
     @property
     def needed_machine_jobs(self):
-        return self.job_state[:, :, _abi.F_CUR] >> 16
+        """(B, J) machine of every job's current op, -1 once the job is finished.  With compact records the op is not
+        stored: it is looked up in the (one) op table -- on the host, as NumPy."""
+        if not self.compact:
+            return self.job_state[:, :, _abi.F_CUR] >> 16
+        todo = self.backend.numpy(self.todo_time_step_job).astype(np.int64)
+        ops = self.packed.ops[0].astype(np.int64)
+        M = int(self.packed.machines[0])
+        cur = ops[np.arange(self.jmax)[None, :], np.minimum(todo, M - 1)]
+        return np.where(todo < M, cur >> 16, -1)
 
     @property
     def time_until_finish_current_op_jobs(self):
-        return self.job_state[:, :, _abi.F_LEFT]
+        return self._word(_abi.F_LEFT)
 
     @property
     def total_perform_op_time_jobs(self):
-        return self.job_state[:, :, _abi.F_PERF]
+        return self._word(_abi.F_PERF)
 
     @property
     def total_idle_time_jobs(self):
-        return self.job_state[:, :, _abi.F_IDLE]
+        return self._word(_abi.F_IDLE)
 
     @property
     def idle_time_jobs_last_op(self):
-        return self.job_state[:, :, _abi.F_IDLE_LAST]
+        return self._word(_abi.F_IDLE_LAST)
 
     @property
     def time_until_available_machine(self):
@@ -712,7 +730,7 @@ class BatchedJssEnv:
         """Host copy of everything needed to resume: state + last outputs + the batch description."""
         n = self.backend.numpy
         d = {k: n(getattr(self, k)) for k in self._STATE_TENSORS}
-        d["meta"] = {"abi": _abi.ABI_VERSION, "batch": self.batch, "jmax": self.jmax, "mmax": self.mmax, "seed": self.seed,
+        d["meta"] = {"abi": _abi.ABI_VERSION, "record_ints": self.record_ints, "batch": self.batch, "jmax": self.jmax, "mmax": self.mmax, "seed": self.seed,
                      "env_id_base": self.env_id_base, "table_of_env": self.table_of_env_host.copy(),
                      "ops": self.packed.ops.copy(),
                      # the global env ids key the per-env RNG streams: a resumed run continues them only on the same ids
@@ -723,6 +741,8 @@ class BatchedJssEnv:
         m = d["meta"]
         if int(m.get("abi", 0)) != _abi.ABI_VERSION:
             raise ValueError(f"checkpoint was written with state layout v{m.get('abi')}, this build is v{_abi.ABI_VERSION}")
+        if int(m.get("record_ints", _abi.NF)) != self.record_ints:
+            raise ValueError("checkpoint uses the other job-record layout (compact vs full)")
         if (int(m["batch"]), int(m["jmax"]), int(m["mmax"])) != (self.batch, self.jmax, self.mmax) or \
                 not np.array_equal(m["ops"], self.packed.ops) or not np.array_equal(m["table_of_env"], self.table_of_env_host):
             raise ValueError("checkpoint belongs to a different batch (shape or instances differ)")
@@ -751,6 +771,30 @@ class BatchedJssEnv:
             d["meta"] = {k[len("meta_"):]: (z[k] if z[k].ndim else z[k].item()) for k in z.files if k.startswith("meta_")}
         self.load_state_dict(d)
 
+    def decode_jobs(self, raw, i: int):
+        """One env's job records (rows of ``job_state[i]``, either layout) as an (8, J) int64 matrix in JSS_F_* word order
+        with word 0 decoded -- row 0 = todo_time_step_job, row 7 = flags (1 legal, 2 blocked) -- plus the cached next ops
+        (which a compact record does not store: they are what the op table says)."""
+        J, M = int(self.jobs_per_env[i]), int(self.machines_per_env[i])
+        raw = np.asarray(raw)[:J].astype(np.int64)
+        w0 = raw[:, 0]
+        todo = w0 & _abi.TODO_MASK
+        js = np.zeros((8, J), dtype=np.int64)
+        js[_abi.F_TODO], js[7] = todo, (w0 >> 8) & 3
+        if self.compact:
+            ops = self.packed.ops[int(self.table_of_env_host[i])][:J].astype(np.int64)
+            at = lambda k: np.where(todo + k < M, ops[np.arange(J), np.minimum(todo + k, M - 1)], -1)   # noqa: E731
+            js[_abi.F_CUR], nxt, nxt2 = at(0), at(1), at(2)
+            for f in (_abi.F_LEFT, _abi.F_PERF, _abi.F_IDLE, _abi.F_IDLE_LAST, _abi.F_F4):
+                js[f] = raw[:, _abi.FC_OF_F[f]]
+        else:
+            for f in range(1, 7):
+                js[f] = raw[:, f]
+            nxt = raw[:, _abi.F_NEXT]
+            n2 = (w0 & 0xFFFFFFFF) >> _abi.NEXT2_SHIFT
+            nxt2 = np.where(n2, n2, -1)
+        return js, nxt, nxt2
+
     def host_tensors(self):
         """NumPy copies of the state and output tensors (not ``solution``).  A small batch comes over in ONE
         device -> host copy of the arena they were carved from."""
@@ -776,17 +820,14 @@ class BatchedJssEnv:
             t = {k: v[i] for k, v in t.items()}
         else:
             t = {k: n(getattr(self, k)[i:i + 1])[0] for k in self._layout if not k.startswith("_")}
-        raw = t["job_state"][:J].astype(np.int64).T                # (NF, J): rows = JSS_F_* words
-        js = raw.copy()
-        js[_abi.F_TODO] = raw[_abi.F_TODO] & _abi.TODO_MASK
-        js[7] = (raw[_abi.F_TODO] >> 8) & 3
+        js, nxt, nxt2 = self.decode_jobs(t["job_state"], i)
         hdr = t["env_header"]
         out = {
             "jobs": J, "machines": M,
             "clock": int(hdr[_abi.H_CLOCK]),
             "job_state": js,
-            "next_op": raw[_abi.F_NEXT],
-            "next2_op": np.where((raw[_abi.F_TODO] & 0xFFFFFFFF) >> _abi.NEXT2_SHIFT, (raw[_abi.F_TODO] & 0xFFFFFFFF) >> _abi.NEXT2_SHIFT, -1),
+            "next_op": nxt,
+            "next2_op": nxt2,
             "tm": t["machine_state"][:M].astype(np.int64),
             "mask": t["action_mask"][:J + 1].astype(bool),
             "mask_padding": t["action_mask"][J + 1:].copy(),
@@ -811,8 +852,8 @@ class _Snap:
     """Env 0 of a host snapshot, decoded lazily: ``step()`` needs the observation, mask, reward, done and the error
     bits; everything else (the per-job arrays the reference exposes as attributes) is unpacked when it is read."""
 
-    def __init__(self, t, J, M):
-        self.t, self.J, self.M, self.c = t, J, M, {}
+    def __init__(self, t, J, M, decode):
+        self.t, self.J, self.M, self.c, self.decode = t, J, M, {}, decode
 
     def __contains__(self, k):
         return k in self.c
@@ -831,12 +872,8 @@ class _Snap:
             c.update(clock=int(hdr[_abi.H_CLOCK]), err=st & 0xFF, noop_flag=bool(st & _abi.STATUS_NOOP),
                      episode=int(hdr[_abi.H_EPISODE]), step_in_episode=int(hdr[_abi.H_STEP]))
         elif k in ("job_state", "next_op", "next2_op", "blocked"):
-            raw = t["job_state"][0, :J].astype(np.int64).T
-            js = raw.copy()
-            js[_abi.F_TODO] = raw[_abi.F_TODO] & _abi.TODO_MASK
-            js[7] = (raw[_abi.F_TODO] >> 8) & 3
-            n2 = (raw[_abi.F_TODO] & 0xFFFFFFFF) >> _abi.NEXT2_SHIFT
-            c.update(job_state=js, next_op=raw[_abi.F_NEXT], next2_op=np.where(n2, n2, -1), blocked=(js[7] & 2) != 0)
+            js, nxt, nxt2 = self.decode(t["job_state"][0], 0)
+            c.update(job_state=js, next_op=nxt, next2_op=nxt2, blocked=(js[7] & 2) != 0)
         elif k == "tm":
             c[k] = t["machine_state"][0, :M].astype(np.int64)
         elif k == "mask":
@@ -910,7 +947,7 @@ class JssEnv:
     # -- host mirror of the device state ---------------------------------------------------
     def _h(self):
         if self._cache is None:                    # one device -> host copy per step (the env's arena), decoded lazily
-            self._cache = _Snap(self._b.host_tensors(), self.jobs, self.machines)
+            self._cache = _Snap(self._b.host_tensors(), self.jobs, self.machines, self._b.decode_jobs)
         return self._cache
 
     def _solution(self):

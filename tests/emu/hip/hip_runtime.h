@@ -65,6 +65,10 @@ struct float4 {
     float x, y, z, w;
 };
 inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+struct int2 {
+    int x, y;
+};
+inline int2 make_int2(int x, int y) { return int2{x, y}; }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 // cache-policy hints have no meaning on the CPU
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))

@@ -638,6 +638,41 @@ def case_dispatching_on_device(backend, inst="ta01", rules=("SPT", "FIFO", "MWR"
         pass
 
 
+def case_compact_equals_full(backend, insts=("ta01", "ta41", "ta51"), batch=7, n_iter=260, seed=23):
+    """A shared-instance batch with compact 24-byte job records (the default) and with full 32-byte records (what an
+    ABI caller may still pass) are the same simulation: every other tensor bit-identical, the records equal after
+    decoding, through rollout, step, advance, partial reset and the trajectory recorder."""
+    for inst in insts:
+        a = BatchedJssEnv(inst, batch=batch, seed=seed, env_id_base=3, _backend=backend)
+        b = BatchedJssEnv(inst, batch=batch, seed=seed, env_id_base=3, compact=False, _backend=backend)
+        assert a.compact and not b.compact and a.job_state.shape[-1] == _abi.NFC and b.job_state.shape[-1] == _abi.NF
+        n = a.backend.numpy
+        for e in (a, b):
+            e.reset()
+            e.rollout("random", n_iter=n_iter)
+            e.rollout_steps("SPT", steps=5, n_sub=2, explore=0.1)
+            acts = n(e.policy("FIFO")).astype(np.int32)
+            acts[1] = e.jobs_per_env[1]                      # a NOPE forced against the mask
+            e.step(acts)
+            e.increase_time_step(which=np.arange(batch) % 2)
+            e.reset(which=(np.arange(batch) == 2))
+            e.step(n(e.policy("random")).astype(np.int32), autoreset=True)
+        ta, tb = a.trajectory("MWR", steps=9), b.trajectory("MWR", steps=9)
+        for k in ta:
+            assert np.array_equal(n(ta[k]), n(tb[k])), f"{inst}: trajectory {k}"
+        for name in BatchedJssEnv._STATE_TENSORS:
+            if name != "job_state":
+                assert np.array_equal(n(getattr(a, name)), n(getattr(b, name))), f"{inst}: {name}"
+        for i in range(batch):
+            (ja, na, n2a), (jb, nb, n2b) = a.decode_jobs(n(a.job_state)[i], i), b.decode_jobs(n(b.job_state)[i], i)
+            assert np.array_equal(ja, jb) and np.array_equal(na, nb) and np.array_equal(n2a, n2b), f"{inst}: records of env {i}"
+    try:
+        BatchedJssEnv(["ta01", "ta02"], batch=2, compact=True, _backend=backend)
+        raise AssertionError("compact records need one shared instance")
+    except ValueError:
+        pass
+
+
 def case_trajectory(backend, instances="ta01", batch=9, steps=40, kind="random", seed=17, explore=0.0, autoreset=True,
                     warm=0, table_of_env=None):
     """jss_trajectory (K steps per launch, every transition recorded) against K x (jss_policy, jss_step with next-step
@@ -892,8 +927,9 @@ def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=
     assert np.array_equal(hdr[:, _abi.H_STATUS] & 0xFF, want["err"]) and not want["err"].any(), f"{label}: error flags"
     J = env.jobs_per_env
     live = np.arange(env.jmax)[None, :] < J[:, None]                    # rows of real jobs
-    got_fields = [js[:, :, _abi.F_TODO] & _abi.TODO_MASK, np.where(live, js[:, :, _abi.F_CUR] >> 16, 0), js[:, :, _abi.F_LEFT],
-                  js[:, :, _abi.F_PERF], js[:, :, _abi.F_IDLE], js[:, :, _abi.F_IDLE_LAST]]
+    need = np.asarray(n(env.needed_machine_jobs) if not isinstance(env.needed_machine_jobs, np.ndarray) else env.needed_machine_jobs)
+    got_fields = [js[:, :, 0] & _abi.TODO_MASK, np.where(live, need, 0), n(env.time_until_finish_current_op_jobs),
+                  n(env.total_perform_op_time_jobs), n(env.total_idle_time_jobs), n(env.idle_time_jobs_last_op)]   # either record layout
     for f, (name, got) in enumerate(zip(G.JOB_FIELDS, got_fields)):
         bad = np.flatnonzero((got != want["job_fields"][:, f]).any(axis=1))
         assert bad.size == 0, f"{label}: {name} differs on {bad.size} envs, first {bad[:5]}"

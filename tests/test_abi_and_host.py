@@ -50,6 +50,9 @@ def test_header_constants_match_python_mirror():
     assert defs["JSS_ERR_NOPE_IDLE"] == _abi.ERR_NOPE_IDLE and defs["JSS_ERR_ILLEGAL_ACTION"] == _abi.ERR_ILLEGAL_ACTION
     for name, kid in _abi.POLICY.items():
         assert defs["JSS_POLICY_" + name.upper()] == kid
+    assert defs["JSS_NFC"] == _abi.NFC and [defs[f"JSS_FC_{n}"] for n in ("TODO", "LEFT", "PERF", "IDLE", "IDLE_LAST", "F4")] == \
+        [_abi.FC_TODO, _abi.FC_LEFT, _abi.FC_PERF, _abi.FC_IDLE, _abi.FC_IDLE_LAST, _abi.FC_F4]
+    assert [_abi.FC_OF_F[f] for f in (_abi.F_TODO, _abi.F_LEFT, _abi.F_PERF, _abi.F_IDLE, _abi.F_IDLE_LAST, _abi.F_F4)] == list(range(6))
     assert defs["JSS_NH"] == _abi.NH and defs["JSS_NC"] == _abi.NC and defs["JSS_C_TABLE"] == _abi.C_TABLE
     assert defs["JSS_C_MAX_TIME_JOBS"] == _abi.C_MAX_TIME_JOBS and defs["JSS_C_RCP_MACHINES"] == _abi.C_RCP_MACHINES
     # the six normalisers sit in the same order in the instance record and in the per-env constants record

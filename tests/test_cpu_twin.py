@@ -215,3 +215,7 @@ def test_rollout_steps_multi_equals_separate_rollouts(cpu):
         for name in BatchedJssEnv._STATE_TENSORS:
             assert np.array_equal(getattr(x, name), getattr(y, name)), name
     assert cpu.lib.jss_rollout_steps_multi(0, None, None, None, 0, 0, 0, 1, 0, None) == _abi.E_NULL
+
+
+def test_compact_records_equal_full_records(cpu):
+    P.case_compact_equals_full(cpu)

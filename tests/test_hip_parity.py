@@ -243,3 +243,7 @@ def test_every_env_at_full_size_equals_the_oracle(hip, cfg):
 
 def test_dispatching_fused_on_device(hip):
     P.case_dispatching_on_device(hip, num_episodes=40)
+
+
+def test_compact_records_equal_full_records(hip):
+    P.case_compact_equals_full(hip, batch=70, n_iter=700)

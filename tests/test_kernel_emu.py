@@ -121,3 +121,7 @@ def test_trajectory_frozen_without_autoreset(emu):
 
 def test_dispatching_fused_on_device(emu):
     P.case_dispatching_on_device(emu, rules=("SPT", "CR"), num_episodes=3)
+
+
+def test_compact_records_equal_full_records(emu):
+    P.case_compact_equals_full(emu, insts=("ta01", "ta51"), batch=3, n_iter=120)
