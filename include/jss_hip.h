@@ -51,7 +51,7 @@
  *                                                float32 reciprocals
  *   job state     int32 [B][jmax][JSS_NF]        one 32-byte record per job (JSS_F_* words below):
  *                                                a lane moves its job with two dwordx4 accesses
- *                 or    [B][jmax][JSS_NFC]       24-byte compact records (JSS_FC_*) when the batch shares one instance
+ *                 or    [B][jmax][JSS_NFC]       16-byte compact records (JSS_FC_*) when the batch shares one instance
  *                                                and JssDesc.record_ints says so
  *   env header    int32 [B][JSS_NH]              JSS_H_*: clock, episode, step, status
  *   env constants int32 [B][JSS_NC]              JSS_C_*: the env's instance constants (copied in by reset)
@@ -94,15 +94,22 @@ extern "C" {
 #define JSS_NF 8
 /* The compact record (JssDesc.record_ints == JSS_NFC; only for a batch that shares ONE instance, n_tables == 1): the
  * three cached ops are what the op table says at [j][todo .. todo + 2], and with one table for the whole batch every
- * workgroup has that table in LDS anyway -- so the record does not carry them: 24 bytes per job instead of 32, a
- * quarter less state traffic.  Words: */
-#define JSS_FC_TODO 0      /* bits 0-7 todo_time_step_job, bit 8 legal, bit 9 action_illegal_no_op; bits 10-31 zero */
-#define JSS_FC_LEFT 1
-#define JSS_FC_PERF 2
-#define JSS_FC_IDLE 3
-#define JSS_FC_IDLE_LAST 4
-#define JSS_FC_F4 5
-#define JSS_NFC 6
+ * workgroup has that table in LDS anyway -- so the record does not carry them; and within the library's limits
+ * (durations <= 65535, machines <= 64) the remaining fields fit four words: ONE 16-byte access per job instead of two,
+ * half the state traffic.  Words: */
+#define JSS_FC_W0 0        /* bits 0-6 todo_time_step_job (<= 64), bit 7 legal_actions[j], bit 8 action_illegal_no_op[j],
+                              bit 9 observation feature 4 is "1.0" (JSS_F4_ONE), bits 10-31 total_perform_op_time_jobs
+                              (<= 64 x 65535 < 2^22)                                                                   */
+#define JSS_FC_LEFT_F4 1   /* bits 0-15 time_until_finish_current_op_jobs, bits 16-31 the feature-4 numerator (0 when bit
+                              9 of word 0 is set)                                                                     */
+#define JSS_FC_IDLE 2      /* total_idle_time_jobs                                  */
+#define JSS_FC_IDLE_LAST 3 /* idle_time_jobs_last_op                                */
+#define JSS_NFC 4
+#define JSS_FC_TODO_MASK 127
+#define JSS_FC_FLAG_LEGAL 128
+#define JSS_FC_FLAG_BLOCKED 256
+#define JSS_FC_FLAG_F4_ONE 512
+#define JSS_FC_PERF_SHIFT 10
 #define JSS_F4_ONE (-1)
 #define JSS_TODO_MASK 255
 #define JSS_FLAG_LEGAL 256

@@ -13,10 +13,9 @@ ABI_VERSION = 7
 MAX_JOBS, MAX_MACHINES = 128, 64
 F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_NEXT, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
 TODO_MASK, FLAG_LEGAL, FLAG_BLOCKED, NEXT2_SHIFT = 255, 256, 512, 10
-# compact 24-byte record of shared-instance batches (JSS_FC_*): no cached ops
-FC_TODO, FC_LEFT, FC_PERF, FC_IDLE, FC_IDLE_LAST, FC_F4, NFC = 0, 1, 2, 3, 4, 5, 6
-# position of JSS_F_* word f in the compact record (-1: not stored, read from the op table)
-FC_OF_F = (FC_TODO, -1, FC_LEFT, FC_PERF, FC_IDLE, FC_IDLE_LAST, FC_F4, -1)
+# compact 16-byte record of shared-instance batches (JSS_FC_*): no cached ops, packed words
+FC_W0, FC_LEFT_F4, FC_IDLE, FC_IDLE_LAST, NFC = 0, 1, 2, 3, 4
+FC_TODO_MASK, FC_FLAG_LEGAL, FC_FLAG_BLOCKED, FC_FLAG_F4_ONE, FC_PERF_SHIFT = 127, 128, 256, 512, 10
 H_CLOCK, H_EPISODE, H_STEP, H_STATUS = 0, 1, 2, 3
 NH = 4
 C_JOBS, C_MACHINES, C_MAX_TIME_OP, C_TABLE, C_MAX_TIME_JOBS, C_SUM_OP = 0, 1, 2, 3, 4, 5

@@ -50,28 +50,24 @@ struct Env {
     int32_t *tm;                // [mmax]
     int32_t *sol;               // [jmax][mmax]
 
-    bool compact;               // 24-byte records (JSS_FC_*): the cached ops are read from the op table instead
-    // word f (JSS_F_* numbering) of job j's record; the compact record holds TODO, LEFT, PERF, IDLE, IDLE_LAST, F4 only
-    int32_t &w(int j, int f) const {
-        static const int pos[JSS_NF] = {JSS_FC_TODO, -1, JSS_FC_LEFT, JSS_FC_PERF, JSS_FC_IDLE, JSS_FC_IDLE_LAST, JSS_FC_F4, -1};
-        return compact ? job[j * JSS_NFC + pos[f]] : job[j * JSS_NF + f];
-    }
+    // word f (JSS_F_*) of job j's record.  `job` is the batch tensor itself for full records; for compact 16-byte
+    // records (JSS_FC_*) it is a thread-local full-layout copy that load_compact() fills and store_compact() writes back
+    int32_t *packed;            // compact records of my env in the batch tensor (nullptr with full records)
+    int32_t &w(int j, int f) const { return job[j * JSS_NF + f]; }
     int op_at(int j, int k) const { return k < M ? ops[j * stride + k] : -1; }
-    int cur(int j) const { return compact ? op_at(j, todo(j)) : w(j, JSS_F_CUR); }          // current op, -1 = job finished
-    int nxt(int j) const { return compact ? op_at(j, todo(j) + 1) : w(j, JSS_F_NEXT); }
+    int cur(int j) const { return w(j, JSS_F_CUR); }                                     // current op, -1 = job finished
+    int nxt(int j) const { return w(j, JSS_F_NEXT); }
     int todo(int j) const { return w(j, JSS_F_TODO) & JSS_TODO_MASK; }
     bool legal(int j) const { return w(j, JSS_F_TODO) & JSS_FLAG_LEGAL; }
     bool blocked(int j) const { return w(j, JSS_F_TODO) & JSS_FLAG_BLOCKED; }
     void set_legal(int j, bool v) const { w(j, JSS_F_TODO) = (w(j, JSS_F_TODO) & ~JSS_FLAG_LEGAL) | (v ? JSS_FLAG_LEGAL : 0); }
     void set_blocked(int j, bool v) const { w(j, JSS_F_TODO) = (w(j, JSS_F_TODO) & ~JSS_FLAG_BLOCKED) | (v ? JSS_FLAG_BLOCKED : 0); }
     int next2(int j) const {                                             // op table entry [j][todo + 2], -1 = none
-        if (compact) return op_at(j, todo(j) + 2);
         const unsigned v = (unsigned)w(j, JSS_F_TODO) >> JSS_NEXT2_SHIFT;
         return v ? (int)v : -1;
     }
     // the record's cached ops after todo(j) changed (or at reset): cur <- [todo], next <- [todo + 1], next2 <- [todo + 2]
     void refresh_ops(int j, bool valid) const {
-        if (compact) return;
         const int k = todo(j);
         w(j, JSS_F_CUR) = valid ? op_at(j, k) : -1;
         w(j, JSS_F_NEXT) = valid ? op_at(j, k + 1) : -1;
@@ -86,6 +82,36 @@ struct Env {
     void set_noop(int v) const { hdr[JSS_H_STATUS] = (hdr[JSS_H_STATUS] & ~JSS_STATUS_NOOP) | (v ? JSS_STATUS_NOOP : 0); }
     void flag(int err) const { hdr[JSS_H_STATUS] |= err; }
 };
+
+// compact 16-byte records <-> the full-layout working copy (the cached ops are what the op table says)
+void load_compact(const Env &e) {
+    for (int j = 0; j < e.jmax; ++j) {
+        const int32_t *r = e.packed + j * JSS_NFC;
+        const unsigned w0 = (unsigned)r[JSS_FC_W0], w1 = (unsigned)r[JSS_FC_LEFT_F4];
+        const int todo = (int)(w0 & JSS_FC_TODO_MASK);
+        const bool v = j < e.J;
+        e.w(j, JSS_F_TODO) = todo | ((w0 & JSS_FC_FLAG_LEGAL) ? JSS_FLAG_LEGAL : 0) | ((w0 & JSS_FC_FLAG_BLOCKED) ? JSS_FLAG_BLOCKED : 0);
+        e.w(j, JSS_F_LEFT) = (int)(w1 & 0xffffu);
+        e.w(j, JSS_F_PERF) = (int)(w0 >> JSS_FC_PERF_SHIFT);
+        e.w(j, JSS_F_IDLE) = r[JSS_FC_IDLE];
+        e.w(j, JSS_F_IDLE_LAST) = r[JSS_FC_IDLE_LAST];
+        e.w(j, JSS_F_F4) = (w0 & JSS_FC_FLAG_F4_ONE) ? JSS_F4_ONE : (int)(w1 >> 16);
+        e.refresh_ops(j, v);
+    }
+}
+void store_compact(const Env &e) {
+    if (!e.packed) return;
+    for (int j = 0; j < e.jmax; ++j) {
+        int32_t *r = e.packed + j * JSS_NFC;
+        const int w0 = e.w(j, JSS_F_TODO), f4 = e.w(j, JSS_F_F4);
+        r[JSS_FC_W0] = (int32_t)((unsigned)(w0 & JSS_TODO_MASK) | ((w0 & JSS_FLAG_LEGAL) ? JSS_FC_FLAG_LEGAL : 0u) |
+                                 ((w0 & JSS_FLAG_BLOCKED) ? JSS_FC_FLAG_BLOCKED : 0u) | (f4 == JSS_F4_ONE ? JSS_FC_FLAG_F4_ONE : 0u) |
+                                 ((unsigned)e.w(j, JSS_F_PERF) << JSS_FC_PERF_SHIFT));
+        r[JSS_FC_LEFT_F4] = (int32_t)((unsigned)e.w(j, JSS_F_LEFT) | ((unsigned)(f4 == JSS_F4_ONE ? 0 : f4) << 16));
+        r[JSS_FC_IDLE] = e.w(j, JSS_F_IDLE);
+        r[JSS_FC_IDLE_LAST] = e.w(j, JSS_F_IDLE_LAST);
+    }
+}
 
 // The env's view of the batch.  from_instance: a reset -- its shape and normalisers come from its instance record
 // (env -> table_of_env -> record) and are copied into its header; every other call reads them back from the header.
@@ -114,8 +140,15 @@ Env env_of(const Call &c, int b, bool from_instance) {
     e.stride = d.mmax;
     e.jmax = d.jmax;
     e.mmax = d.mmax;
-    e.compact = d.record_ints == JSS_NFC;
-    e.job = c.s.job + (size_t)b * d.jmax * (e.compact ? JSS_NFC : JSS_NF);
+    if (d.record_ints == JSS_NFC) {
+        static thread_local int32_t unpacked[JSS_MAX_JOBS * JSS_NF];
+        e.packed = c.s.job + (size_t)b * d.jmax * JSS_NFC;
+        e.job = unpacked;
+        load_compact(e);
+    } else {
+        e.packed = nullptr;
+        e.job = c.s.job + (size_t)b * d.jmax * JSS_NF;
+    }
     e.tm = c.s.machine + (size_t)b * d.mmax;
     e.sol = c.s.solution + b * region;
     return e;
@@ -463,6 +496,7 @@ void run_env(const Call &c, int mode, int b) {
         const Env e = env_of(c, b, true);
         restart(e, c, b);
         write_outputs(e, c, b);
+        store_compact(e);
         return;
     }
     Env e = env_of(c, b, false);
@@ -549,6 +583,7 @@ void run_env(const Call &c, int mode, int b) {
     }
     }
     write_outputs(e, c, b);
+    store_compact(e);
 }
 
 int run(const Call &c, int mode) {

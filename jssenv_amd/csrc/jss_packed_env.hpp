@@ -523,12 +523,9 @@ __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G, TAB> &c, const Pa
     const unsigned mc = (unsigned)c.gl < mm ? c.gl : 0;
     const size_t fe = (size_t)c.first_env;
     r.h = ld_off<int4>(p.s.env + fe * JSS_NH, c.rel * (JSS_NH * 4u));
-    if (tab_compact(TAB)) {          // 24-byte records: (w0, left, perf, idle | idle_last, f4)
-        const int32_t *jb = p.s.job + fe * jm * JSS_NFC;
-        const unsigned jo = (c.rel * jm + jc) * (JSS_NFC * 4u);
-        r.lo = ld_off<int4>(jb, jo);
-        const int2 h2 = ld_off<int2>(jb, jo + 16u);
-        r.hi = make_int4(h2.x, h2.y, 0, 0);
+    if (tab_compact(TAB)) {          // 16-byte records (JSS_FC_*): one access per job
+        r.lo = ld_off<int4>(p.s.job + fe * jm * JSS_NFC, (c.rel * jm + jc) * (JSS_NFC * 4u));
+        r.hi = make_int4(0, 0, 0, 0);
     } else {
         const int32_t *jb = p.s.job + fe * jm * JSS_NF;
         const unsigned jo = (c.rel * jm + jc) * 32u;
@@ -546,17 +543,21 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, c
     e.noop = (r.h.w & JSS_STATUS_NOOP) ? 1 : 0;
     e.tm = c.mvalid ? r.tm : 0;
     const bool v = c.jvalid;
-    e.todo = v ? (r.lo.x & JSS_TODO_MASK) : 0;
     if (tab_compact(TAB)) {          // the job's next three ops are what the LDS table says (staged before this runs)
-        e.left = v ? r.lo.y : 0;
-        e.perf = v ? r.lo.z : 0;
-        e.idle = v ? r.lo.w : 0;
-        e.idle_last = v ? r.hi.x : 0;
-        e.f4 = v ? r.hi.y : 0;
+        const unsigned w0 = (unsigned)r.lo.x, w1 = (unsigned)r.lo.y;
+        e.todo = v ? (int)(w0 & JSS_FC_TODO_MASK) : 0;
+        e.left = v ? (int)(w1 & 0xffffu) : 0;
+        e.perf = v ? (int)(w0 >> JSS_FC_PERF_SHIFT) : 0;
+        e.idle = v ? r.lo.z : 0;
+        e.idle_last = v ? r.lo.w : 0;
+        e.f4 = v ? ((w0 & JSS_FC_FLAG_F4_ONE) ? JSS_F4_ONE : (int)(w1 >> 16)) : 0;
         e.cur = (v && e.todo < c.M) ? c.lds_row[e.todo] : -1;
         e.nxt = (v && e.todo + 1 < c.M) ? c.lds_row[e.todo + 1] : -1;
         e.nxt2 = (v && e.todo + 2 < c.M) ? c.lds_row[e.todo + 2] : -1;
+        e.legal = v && (w0 & JSS_FC_FLAG_LEGAL);
+        e.blocked = v && (w0 & JSS_FC_FLAG_BLOCKED);
     } else {
+        e.todo = v ? (r.lo.x & JSS_TODO_MASK) : 0;
         e.cur = v ? r.lo.y : -1;
         e.left = v ? r.lo.z : 0;
         e.perf = v ? r.lo.w : 0;
@@ -565,9 +566,9 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, c
         e.f4 = v ? r.hi.z : 0;
         e.nxt = v ? r.hi.w : -1;
         e.nxt2 = (v && ((unsigned)r.lo.x >> JSS_NEXT2_SHIFT)) ? (int)((unsigned)r.lo.x >> JSS_NEXT2_SHIFT) : -1;
+        e.legal = v && (r.lo.x & JSS_FLAG_LEGAL);
+        e.blocked = v && (r.lo.x & JSS_FLAG_BLOCKED);
     }
-    e.legal = v && (r.lo.x & JSS_FLAG_LEGAL);
-    e.blocked = v && (r.lo.x & JSS_FLAG_BLOCKED);
     PHeader hd;
     hd.episode = r.h.y;
     hd.step = r.h.z;
@@ -628,12 +629,13 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
         st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
     if (tab_compact(TAB)) {
         if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
-            int32_t *jb = p.s.job + fe * jm * JSS_NFC;
-            const unsigned jo = (c.rel * jm + c.gl) * (JSS_NFC * 4u);
-            const int4 lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0), e.left, e.perf, e.idle);
-            // unchanged parts of the record are not rewritten (steps without a time advance touch few jobs)
-            if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
-            if (fresh || e.idle_last != raw.hi.x || e.f4 != raw.hi.y) st_off(jb, jo + 16u, make_int2(e.idle_last, e.f4));
+            const bool one = e.f4 == JSS_F4_ONE;
+            const int4 lo = make_int4((int)((unsigned)e.todo | (e.legal ? JSS_FC_FLAG_LEGAL : 0u) | (e.blocked ? JSS_FC_FLAG_BLOCKED : 0u) |
+                                            (one ? JSS_FC_FLAG_F4_ONE : 0u) | ((unsigned)e.perf << JSS_FC_PERF_SHIFT)),
+                                      (int)((unsigned)e.left | ((unsigned)(one ? 0 : e.f4) << 16)), e.idle, e.idle_last);
+            // an unchanged record is not rewritten (steps without a time advance touch few jobs)
+            if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w)
+                st_off(p.s.job + fe * jm * JSS_NFC, (c.rel * jm + c.gl) * (JSS_NFC * 4u), lo);
         }
     } else if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
         int32_t *jb = p.s.job + fe * jm * JSS_NF;

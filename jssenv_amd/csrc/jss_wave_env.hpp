@@ -575,14 +575,10 @@ __device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + lane;
-        if (tab_compact(TAB)) {          // 24-byte records: (w0, left, perf, idle | idle_last, f4)
+        if (tab_compact(TAB)) {          // 16-byte records (JSS_FC_*): one access per job
             r.lo[s] = make_int4(0, 0, 0, 0);
             r.hi[s] = make_int4(0, 0, 0, 0);
-            if (j < jlimit) {
-                r.lo[s] = ld_off<int4>(jb, (unsigned)j * (JSS_NFC * 4u));
-                const int2 h2 = ld_off<int2>(jb, (unsigned)j * (JSS_NFC * 4u) + 16u);
-                r.hi[s] = make_int4(h2.x, h2.y, 0, 0);
-            }
+            if (j < jlimit) r.lo[s] = ld_off<int4>(jb, (unsigned)j * (JSS_NFC * 4u));
         } else {
             r.lo[s] = make_int4(0, -1, 0, 0);
             r.hi[s] = make_int4(0, 0, 0, -1);
@@ -616,19 +612,25 @@ __device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawE
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int4 lo = r.lo[s], hi = r.hi[s];
-        e.todo[s] = lo.x & JSS_TODO_MASK;
         if (tab_compact(TAB)) {      // the job's next three ops are what the LDS table says
+            const unsigned w0 = (unsigned)lo.x, w1 = (unsigned)lo.y;
+            e.todo[s] = (int)(w0 & JSS_FC_TODO_MASK);
             const int j = s * kWave + c.lane, k = e.todo[s];
             const bool v = j < c.J;
-            e.left[s] = lo.y;
-            e.perf[s] = lo.z;
-            e.idle[s] = lo.w;
-            e.idle_last[s] = hi.x;
-            e.f4[s] = hi.y;
+            e.left[s] = (int)(w1 & 0xffffu);
+            e.perf[s] = (int)(w0 >> JSS_FC_PERF_SHIFT);
+            e.idle[s] = lo.z;
+            e.idle_last[s] = lo.w;
+            e.f4[s] = (w0 & JSS_FC_FLAG_F4_ONE) ? JSS_F4_ONE : (int)(w1 >> 16);
+            e.legal[s] = __ballot((w0 & JSS_FC_FLAG_LEGAL) != 0);
+            e.blocked[s] = (w0 & JSS_FC_FLAG_BLOCKED) != 0;
             e.cur[s] = (v && k < c.M) ? c.tab[j * c.stride + k] : -1;
             e.nxt[s] = (v && k + 1 < c.M) ? c.tab[j * c.stride + k + 1] : -1;
             e.nxt2[s] = (v && k + 2 < c.M) ? c.tab[j * c.stride + k + 2] : -1;
         } else {
+            e.todo[s] = lo.x & JSS_TODO_MASK;
+            e.legal[s] = __ballot((lo.x & JSS_FLAG_LEGAL) != 0);
+            e.blocked[s] = (lo.x & JSS_FLAG_BLOCKED) != 0;
             e.cur[s] = lo.y;
             e.left[s] = lo.z;
             e.perf[s] = lo.w;
@@ -640,8 +642,6 @@ __device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawE
             e.nxt2[s] = n2 ? n2 : -1;
         }
         e.fill[s] = -1;
-        e.legal[s] = __ballot((lo.x & JSS_FLAG_LEGAL) != 0);
-        e.blocked[s] = (lo.x & JSS_FLAG_BLOCKED) != 0;
     }
 }
 
@@ -685,11 +685,12 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
         const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = e.blocked[s] ? 1 : 0;
         if (tab_compact(TAB)) {
             const unsigned jo = (unsigned)j * (JSS_NFC * 4u);
-            const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0), e.left[s], e.perf[s], e.idle[s]);
-            const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
+            const bool one = e.f4[s] == JSS_F4_ONE;
+            const int4 lo = make_int4((int)((unsigned)e.todo[s] | (lg ? JSS_FC_FLAG_LEGAL : 0u) | (bl ? JSS_FC_FLAG_BLOCKED : 0u) |
+                                            (one ? JSS_FC_FLAG_F4_ONE : 0u) | ((unsigned)e.perf[s] << JSS_FC_PERF_SHIFT)),
+                                      (int)((unsigned)e.left[s] | ((unsigned)(one ? 0 : e.f4[s]) << 16)), e.idle[s], e.idle_last[s]);
+            const int4 lo0 = raw.lo[s];
             if (all_rows ? j < jm : (j < c.J && (lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w))) st_off<int4>(jb, jo, lo);
-            if (all_rows ? j < jm : (j < c.J && (e.idle_last[s] != hi0.x || e.f4[s] != hi0.y)))
-                st_off<int2>(jb, jo + 16u, make_int2(e.idle_last[s], e.f4[s]));
             continue;
         }
         const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0) |

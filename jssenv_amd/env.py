@@ -344,7 +344,7 @@ class BatchedJssEnv:
             raise ValueError("table_of_env must hold B indices into instances")
         self.jobs_per_env = pk.jobs[self.table_of_env_host]
         self.machines_per_env = pk.machines[self.table_of_env_host]
-        # job records: 24-byte compact records (no cached ops: they are read from the ONE op table, which every workgroup
+        # job records: 16-byte compact records (no cached ops: they are read from the ONE op table, which every workgroup
         # has in LDS) whenever the batch shares one instance; 32-byte records otherwise
         self.compact = (n == 1) if compact is None else bool(compact)
         if self.compact and n != 1:
@@ -367,7 +367,7 @@ class BatchedJssEnv:
             J, M = self.jmax, self.mmax
             specs = [("env_header", (B, _abi.NH), "int32"),     # clock, episode, step_in_episode, status
                      ("env_const", (B, _abi.NC), "int32"),      # the env's instance constants, written by reset (JSS_C_*)
-                     ("job_state", (B, J, self.record_ints), "int32"),   # one 32- (or compact: 24-) byte record per job
+                     ("job_state", (B, J, self.record_ints), "int32"),   # one 32- (or compact: 16-) byte record per job
                      ("machine_state", (B, M), "int32"),
                      ("counters", (B, 4), "int64"),
                      ("real_obs", (B, J, 7), "float32"),
@@ -664,11 +664,19 @@ class BatchedJssEnv:
 
     @property
     def todo_time_step_job(self):
-        return self.job_state[:, :, _abi.F_TODO] & _abi.TODO_MASK
+        return self.job_state[:, :, 0] & (_abi.FC_TODO_MASK if self.compact else _abi.TODO_MASK)
 
     def _word(self, f):
-        """Word JSS_F_* `f` of every job record as a (B, J) view, whichever record layout the batch uses."""
-        return self.job_state[:, :, _abi.FC_OF_F[f] if self.compact else f]
+        """Word JSS_F_* `f` (LEFT, PERF, IDLE, IDLE_LAST) of every job record as a (B, J) tensor, whichever record layout
+        the batch uses (a view of the state for full records, decoded from the packed words for compact ones)."""
+        js = self.job_state
+        if not self.compact:
+            return js[:, :, f]
+        if f == _abi.F_LEFT:
+            return js[:, :, _abi.FC_LEFT_F4] & 0xFFFF
+        if f == _abi.F_PERF:
+            return (js[:, :, _abi.FC_W0] >> _abi.FC_PERF_SHIFT) & 0x3FFFFF
+        return js[:, :, {_abi.F_IDLE: _abi.FC_IDLE, _abi.F_IDLE_LAST: _abi.FC_IDLE_LAST}[f]]
 
     @property
     def needed_machine_jobs(self):
@@ -708,7 +716,7 @@ class BatchedJssEnv:
 
     @property
     def action_illegal_no_op(self):
-        return (self.job_state[:, :, _abi.F_TODO] >> 9) & 1
+        return (self.job_state[:, :, 0] >> (8 if self.compact else 9)) & 1
 
     def counter_totals(self):
         """Device tensor [4]: env steps, finished episodes, sum of makespans, sum of reward numerators."""
@@ -776,18 +784,24 @@ class BatchedJssEnv:
         with word 0 decoded -- row 0 = todo_time_step_job, row 7 = flags (1 legal, 2 blocked) -- plus the cached next ops
         (which a compact record does not store: they are what the op table says)."""
         J, M = int(self.jobs_per_env[i]), int(self.machines_per_env[i])
-        raw = np.asarray(raw)[:J].astype(np.int64)
+        raw = np.asarray(raw)[:J].astype(np.int64) & 0xFFFFFFFF
         w0 = raw[:, 0]
-        todo = w0 & _abi.TODO_MASK
         js = np.zeros((8, J), dtype=np.int64)
-        js[_abi.F_TODO], js[7] = todo, (w0 >> 8) & 3
         if self.compact:
+            todo, w1 = w0 & _abi.FC_TODO_MASK, raw[:, _abi.FC_LEFT_F4]
+            js[_abi.F_TODO], js[7] = todo, (w0 >> 7) & 3
             ops = self.packed.ops[int(self.table_of_env_host[i])][:J].astype(np.int64)
             at = lambda k: np.where(todo + k < M, ops[np.arange(J), np.minimum(todo + k, M - 1)], -1)   # noqa: E731
             js[_abi.F_CUR], nxt, nxt2 = at(0), at(1), at(2)
-            for f in (_abi.F_LEFT, _abi.F_PERF, _abi.F_IDLE, _abi.F_IDLE_LAST, _abi.F_F4):
-                js[f] = raw[:, _abi.FC_OF_F[f]]
+            js[_abi.F_LEFT], js[_abi.F_PERF] = w1 & 0xFFFF, w0 >> _abi.FC_PERF_SHIFT
+            js[_abi.F_F4] = np.where(w0 & _abi.FC_FLAG_F4_ONE, _abi.F4_ONE, w1 >> 16)
+            for f, fc in ((_abi.F_IDLE, _abi.FC_IDLE), (_abi.F_IDLE_LAST, _abi.FC_IDLE_LAST)):
+                js[f] = (raw[:, fc] + 2**31) % 2**32 - 2**31   # signed words
         else:
+            raw = (raw + 2**31) % 2**32 - 2**31                 # back to signed words
+            w0 = raw[:, 0]
+            todo = w0 & _abi.TODO_MASK
+            js[_abi.F_TODO], js[7] = todo, (w0 >> 8) & 3
             for f in range(1, 7):
                 js[f] = raw[:, f]
             nxt = raw[:, _abi.F_NEXT]

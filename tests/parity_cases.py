@@ -928,7 +928,7 @@ def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=
     J = env.jobs_per_env
     live = np.arange(env.jmax)[None, :] < J[:, None]                    # rows of real jobs
     need = np.asarray(n(env.needed_machine_jobs) if not isinstance(env.needed_machine_jobs, np.ndarray) else env.needed_machine_jobs)
-    got_fields = [js[:, :, 0] & _abi.TODO_MASK, np.where(live, need, 0), n(env.time_until_finish_current_op_jobs),
+    got_fields = [n(env.todo_time_step_job), np.where(live, need, 0), n(env.time_until_finish_current_op_jobs),
                   n(env.total_perform_op_time_jobs), n(env.total_idle_time_jobs), n(env.idle_time_jobs_last_op)]   # either record layout
     for f, (name, got) in enumerate(zip(G.JOB_FIELDS, got_fields)):
         bad = np.flatnonzero((got != want["job_fields"][:, f]).any(axis=1))
@@ -936,7 +936,7 @@ def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=
     assert np.array_equal(n(env.machine_state), want["tm"]), f"{label}: time_until_available_machine"
     assert np.array_equal(n(env.solution), want["solution"]), f"{label}: solution"
     assert np.array_equal(n(env.action_mask), want["mask"]), f"{label}: action mask"
-    assert np.array_equal((js[:, :, _abi.F_TODO] >> 9) & 1, want["blocked"]), f"{label}: action_illegal_no_op"
+    assert np.array_equal(n(env.action_illegal_no_op), want["blocked"]), f"{label}: action_illegal_no_op"
     assert np.array_equal(n(env.counters), want["counters"]), f"{label}: counters"
     assert np.array_equal((hdr[:, _abi.H_STATUS] & _abi.STATUS_NOOP) != 0, want["mask"][np.arange(env.batch), J] != 0), f"{label}: NOPE flag"
     err = np.abs(n(env.real_obs).astype(np.float64) - want["obs"]).max()

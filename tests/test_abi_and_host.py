@@ -50,9 +50,12 @@ def test_header_constants_match_python_mirror():
     assert defs["JSS_ERR_NOPE_IDLE"] == _abi.ERR_NOPE_IDLE and defs["JSS_ERR_ILLEGAL_ACTION"] == _abi.ERR_ILLEGAL_ACTION
     for name, kid in _abi.POLICY.items():
         assert defs["JSS_POLICY_" + name.upper()] == kid
-    assert defs["JSS_NFC"] == _abi.NFC and [defs[f"JSS_FC_{n}"] for n in ("TODO", "LEFT", "PERF", "IDLE", "IDLE_LAST", "F4")] == \
-        [_abi.FC_TODO, _abi.FC_LEFT, _abi.FC_PERF, _abi.FC_IDLE, _abi.FC_IDLE_LAST, _abi.FC_F4]
-    assert [_abi.FC_OF_F[f] for f in (_abi.F_TODO, _abi.F_LEFT, _abi.F_PERF, _abi.F_IDLE, _abi.F_IDLE_LAST, _abi.F_F4)] == list(range(6))
+    assert defs["JSS_NFC"] == _abi.NFC and [defs[f"JSS_FC_{n}"] for n in ("W0", "LEFT_F4", "IDLE", "IDLE_LAST")] == \
+        [_abi.FC_W0, _abi.FC_LEFT_F4, _abi.FC_IDLE, _abi.FC_IDLE_LAST] == list(range(4))
+    assert [defs[f"JSS_FC_{n}"] for n in ("TODO_MASK", "FLAG_LEGAL", "FLAG_BLOCKED", "FLAG_F4_ONE", "PERF_SHIFT")] == \
+        [_abi.FC_TODO_MASK, _abi.FC_FLAG_LEGAL, _abi.FC_FLAG_BLOCKED, _abi.FC_FLAG_F4_ONE, _abi.FC_PERF_SHIFT]
+    # the packed words hold what the library's limits allow: todo <= 64 machines, perf <= 64 x 65535, left / f4 <= 65535
+    assert I.MAX_MACHINES <= _abi.FC_TODO_MASK and I.MAX_MACHINES * I.MAX_DURATION < 1 << (32 - _abi.FC_PERF_SHIFT) and I.MAX_DURATION < 1 << 16
     assert defs["JSS_NH"] == _abi.NH and defs["JSS_NC"] == _abi.NC and defs["JSS_C_TABLE"] == _abi.C_TABLE
     assert defs["JSS_C_MAX_TIME_JOBS"] == _abi.C_MAX_TIME_JOBS and defs["JSS_C_RCP_MACHINES"] == _abi.C_RCP_MACHINES
     # the six normalisers sit in the same order in the instance record and in the per-env constants record

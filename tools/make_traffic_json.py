@@ -16,11 +16,11 @@ from bench import b_alg, csrc_hash  # noqa: E402
 # key -> (profile dir suffix, kernel substring, kernel label, algorithmic bytes per env step, batch)
 MIXED_ALG = None
 WORKLOADS = {
-    "ta01_b65536": ("ta01_single", "jss_packed_kernel<16, 5, 0>", "jss_packed_kernel<16,kRollout1,kTabLds>", b_alg(15, 15), 65536),
-    "ta01_b262144": ("ta01_b262144", "jss_packed_kernel<16, 5, 0>", "jss_packed_kernel<16,kRollout1,kTabLds>", b_alg(15, 15), 262144),
-    "ta01_b4096": ("ta01_b4096", "jss_packed_kernel<16, 5, 0>", "jss_packed_kernel<16,kRollout1,kTabLds>", b_alg(15, 15), 4096),
+    "ta01_b65536": ("ta01_single", "jss_packed_kernel<16, 5, 2>", "jss_packed_kernel<16,kRollout1,kTabLdsC>", b_alg(15, 15), 65536),
+    "ta01_b262144": ("ta01_b262144", "jss_packed_kernel<16, 5, 2>", "jss_packed_kernel<16,kRollout1,kTabLdsC>", b_alg(15, 15), 262144),
+    "ta01_b4096": ("ta01_b4096", "jss_packed_kernel<16, 5, 2>", "jss_packed_kernel<16,kRollout1,kTabLdsC>", b_alg(15, 15), 4096),
     "syn15x15_b65536": ("syn15x15", "jss_packed_kernel<16, 5, 1>", "jss_packed_kernel<16,kRollout1,kTabGlobal>", b_alg(15, 15), 65536),
-    "ta41_b16384": ("ta41", "jss_packed_kernel<32, 5, 0>", "jss_packed_kernel<32,kRollout1,kTabLds>", b_alg(30, 20), 16384),
+    "ta41_b16384": ("ta41", "jss_packed_kernel<32, 5, 2>", "jss_packed_kernel<32,kRollout1,kTabLdsC>", b_alg(30, 20), 16384),
     "syn50x20_b8192": ("syn50x20", "jss_kernel<1, 5, 1>", "jss_kernel<1,kRollout1,kTabGlobal>", b_alg(50, 20), 8192),
     "mixed_b32768": ("mixed", "jss_kernel<2, 5, 1>", "jss_kernel<2,kRollout1,kTabGlobal> (one-job-per-lane body for J <= 64)", None, 32768),
 }
