@@ -55,7 +55,7 @@
  *                                                and JssDesc.record_ints says so
  *   env header    int32 [B][JSS_NH]              JSS_H_*: clock, episode, step, status
  *   env constants int32 [B][JSS_NC]              JSS_C_*: the env's instance constants (copied in by reset)
- *   machine state int32 [B][mmax]                time_until_available_machine
+ *   machine state int32 [B][mmax]                time_until_available_machine (full records only)
  *   action_mask   uint8 [B][jmax + 1]            legal_actions (output; rebuilt from the flag bits
  *                                                every call); NOPE flag at index J(env), zeros after it
  *   solution      int32 [B][jmax][mmax]          start time of op k of job j, -1 = unscheduled
@@ -96,7 +96,10 @@ extern "C" {
  * three cached ops are what the op table says at [j][todo .. todo + 2], and with one table for the whole batch every
  * workgroup has that table in LDS anyway -- so the record does not carry them; and within the library's limits
  * (durations <= 65535, machines <= 64) the remaining fields fit four words: ONE 16-byte access per job instead of two,
- * half the state traffic.  Words: */
+ * half the state traffic.  A compact batch keeps no machine clocks in memory either (JssState.machine is not
+ * read or written and may be NULL): time_until_available_machine[m] is time_until_finish_current_op_jobs of the job
+ * running on m -- both are set to the op's duration when it is scheduled (jss_env.py:446-449) and count down together
+ * (:521-530) -- 0 for an idle machine, and is rebuilt from the records at every load.  Words: */
 #define JSS_FC_W0 0        /* bits 0-6 todo_time_step_job (<= 64), bit 7 legal_actions[j], bit 8 action_illegal_no_op[j],
                               bit 9 observation feature 4 is "1.0" (JSS_F4_ONE), bits 10-31 total_perform_op_time_jobs
                               (<= 64 x 65535 < 2^22)                                                                   */
@@ -218,7 +221,7 @@ typedef struct JssState {
     int32_t *env;      /* [B][JSS_NH]  JSS_H_*                                         */
     int32_t *env_const;/* [B][JSS_NC]  JSS_C_*: written by reset, read by the step-type calls */
     int32_t *job;      /* [B][jmax][JSS_NF] (or [B][jmax][JSS_NFC], JssDesc.record_ints)   */
-    int32_t *machine;  /* [B][mmax]                                                    */
+    int32_t *machine;  /* [B][mmax]; unused (may be NULL) with compact records         */
     int32_t *solution; /* [B][jmax][mmax]                                              */
     int64_t *counters; /* [B][4]: env steps, finished episodes, sum of makespans,
                           sum of reward numerators (reward * max_time_op); may be NULL */

@@ -98,6 +98,10 @@ void load_compact(const Env &e) {
         e.w(j, JSS_F_F4) = (w0 & JSS_FC_FLAG_F4_ONE) ? JSS_F4_ONE : (int)(w1 >> 16);
         e.refresh_ops(j, v);
     }
+    // no machine clocks in memory: a machine is busy for exactly as long as the job on it (:446-449, :521-530)
+    for (int m = 0; m < e.mmax; ++m) e.tm[m] = 0;
+    for (int j = 0; j < e.J; ++j)
+        if (e.w(j, JSS_F_LEFT) > 0 && e.cur(j) >= 0) e.tm[e.cur(j) >> 16] = e.w(j, JSS_F_LEFT);
 }
 void store_compact(const Env &e) {
     if (!e.packed) return;
@@ -141,15 +145,16 @@ Env env_of(const Call &c, int b, bool from_instance) {
     e.jmax = d.jmax;
     e.mmax = d.mmax;
     if (d.record_ints == JSS_NFC) {
-        static thread_local int32_t unpacked[JSS_MAX_JOBS * JSS_NF];
+        static thread_local int32_t unpacked[JSS_MAX_JOBS * JSS_NF], clocks[JSS_MAX_MACHINES];
         e.packed = c.s.job + (size_t)b * d.jmax * JSS_NFC;
         e.job = unpacked;
+        e.tm = clocks;
         load_compact(e);
     } else {
         e.packed = nullptr;
         e.job = c.s.job + (size_t)b * d.jmax * JSS_NF;
+        e.tm = c.s.machine + (size_t)b * d.mmax;
     }
-    e.tm = c.s.machine + (size_t)b * d.mmax;
     e.sol = c.s.solution + b * region;
     return e;
 }
@@ -605,7 +610,8 @@ int run(const Call &c, int mode) {
 int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_out) {
     if (!d || !s) return JSS_E_NULL;
     if (!d->ops || !d->inst) return JSS_E_NULL;
-    if (!s->env || !s->env_const || !s->job || !s->machine || !s->solution) return JSS_E_NULL;
+    if (!s->env || !s->env_const || !s->job || !s->solution) return JSS_E_NULL;
+    if (!s->machine && d->record_ints != JSS_NFC) return JSS_E_NULL;   // compact batches keep no machine clocks
     if (need_out && (!o || !o->real_obs || !o->action_mask || !o->reward || !o->done || !o->makespan)) return JSS_E_NULL;
     if (d->batch < 0 || d->jmax < 1 || d->jmax > JSS_MAX_JOBS || d->mmax < 2 || d->mmax > JSS_MAX_MACHINES ||
         d->n_tables < 1)

@@ -19,7 +19,8 @@ using namespace jss;
 int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_out) {
     if (!d || !s) return JSS_E_NULL;
     if (!d->ops || !d->inst) return JSS_E_NULL;
-    if (!s->env || !s->env_const || !s->job || !s->machine || !s->solution) return JSS_E_NULL;
+    if (!s->env || !s->env_const || !s->job || !s->solution) return JSS_E_NULL;
+    if (!s->machine && d->record_ints != JSS_NFC) return JSS_E_NULL;   // compact batches keep no machine clocks
     if (need_out && (!o || !o->real_obs || !o->action_mask || !o->reward || !o->done || !o->makespan)) return JSS_E_NULL;
     if (d->batch < 0 || d->jmax < 1 || d->jmax > JSS_MAX_JOBS || d->mmax < 2 || d->mmax > JSS_MAX_MACHINES ||
         d->n_tables < 1)
@@ -114,6 +115,7 @@ int plan(Params &p, LaunchPlan &lp) {
     } else {
         lp.envs_per_block = kWavesPerBlock;
         p.obs_wave_floats = (p.d.jmax * 7 + 3 + 3) & ~3;               // + up to 3 floats of alignment shift (store_obs)
+        if (p.obs_wave_floats < kWave) p.obs_wave_floats = kWave;      // unpack_env borrows it: one int per machine
         p.mv_off_ints = 0;
         p.norm_off_ints = 0;
         lp.shmem = sizeof(int32_t) * ((size_t)p.table_lds_ints + kWavesPerBlock * p.obs_wave_floats);
@@ -154,7 +156,7 @@ Params sub_batch(const Params &p, int start, int count) {
     q.s.env = p.s.env + s0 * JSS_NH;
     q.s.env_const = p.s.env_const + s0 * JSS_NC;
     q.s.job = p.s.job + s0 * jm * (p.d.record_ints == JSS_NFC ? JSS_NFC : JSS_NF);
-    q.s.machine = p.s.machine + s0 * mm;
+    q.s.machine = p.s.machine ? p.s.machine + s0 * mm : nullptr;
     q.s.solution = p.s.solution + s0 * jm * mm;
     if (p.s.counters) q.s.counters = p.s.counters + s0 * 4;
     q.o.real_obs = p.o.real_obs + s0 * jm * 7;

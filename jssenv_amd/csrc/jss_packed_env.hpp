@@ -532,12 +532,13 @@ __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G, TAB> &c, const Pa
         r.lo = ld_off<int4>(jb, jo);
         r.hi = ld_off<int4>(jb, jo + 16u);
     }
-    r.tm = ld_off<int>(p.s.machine + fe * mm, (c.rel * mm + mc) * 4u);
+    // compact batches keep no machine clocks in memory: a machine is busy for as long as the job on it (p_unpack)
+    r.tm = tab_compact(TAB) ? 0 : ld_off<int>(p.s.machine + fe * mm, (c.rel * mm + mc) * 4u);
     return r;
 }
 
 template <int G, int TAB>
-__device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, const PRaw<G> &r) {
+__device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, const PRaw<G> &r, int32_t *mvtab) {
     e.t = r.h.x;
     e.err = r.h.w & 0xFF;
     e.noop = (r.h.w & JSS_STATUS_NOOP) ? 1 : 0;
@@ -556,6 +557,14 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, c
         e.nxt2 = (v && e.todo + 2 < c.M) ? c.lds_row[e.todo + 2] : -1;
         e.legal = v && (w0 & JSS_FC_FLAG_LEGAL);
         e.blocked = v && (w0 & JSS_FC_FLAG_BLOCKED);
+        // time_until_available_machine[m] == time_until_finish_current_op_jobs[the job running on m] (both are set to
+        // the op's duration at :446-449 and count down together at :521-530), 0 for an idle machine
+        mvtab[c.lane] = 0;
+        wave_lds_sync();
+        if (e.left > 0 && e.cur >= 0) mvtab[c.gbase + (e.cur >> 16)] = e.left;   // (cur < 0: a reset call reading stale memory)
+        wave_lds_sync();
+        e.tm = c.mvalid ? mvtab[c.lane] : 0;
+        wave_lds_sync();
     } else {
         e.todo = v ? (r.lo.x & JSS_TODO_MASK) : 0;
         e.cur = v ? r.lo.y : -1;
@@ -625,7 +634,9 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
             st_off(cp, co + 32u, make_int4(as_int(n.r_sum), as_int(n.r_m), 0, 0));
         }
     }
-    if (fresh ? (unsigned)c.gl < mm : (c.mvalid && e.tm != raw.tm))      // idle machines stay 0
+    if (tab_compact(TAB)) {
+        // no machine clocks in memory (p_unpack)
+    } else if (fresh ? (unsigned)c.gl < mm : (c.mvalid && e.tm != raw.tm))      // idle machines stay 0
         st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
     if (tab_compact(TAB)) {
         if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
@@ -916,7 +927,7 @@ void jss_packed_kernel(Params p) {
     c.lds_row = lds + (c.gl < p.d.jmax ? c.gl : 0) * p.d.mmax;
 
     PEnv<G> e;
-    PHeader hd = p_unpack(e, c, raw);
+    PHeader hd = p_unpack(e, c, raw, mvtab);
     const bool fresh = p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab, scratch, wave_whole);
     if (MODE == kPolicy) return;
     p_store(e, c, p, hd, raw, fresh);

@@ -571,7 +571,8 @@ template <int JPL, int TAB>
 __device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params &p, int jlimit) {
     RawEnv<JPL> r;
     const int32_t *jb = p.s.job + (size_t)b * p.d.jmax * (tab_compact(TAB) ? JSS_NFC : JSS_NF);
-    r.tm = ld_off<int>(p.s.machine + (size_t)b * p.d.mmax, (unsigned)(lane < p.d.mmax ? lane : 0) * 4u);
+    // compact batches keep no machine clocks in memory: a machine is busy for as long as the job on it (unpack_env)
+    r.tm = tab_compact(TAB) ? 0 : ld_off<int>(p.s.machine + (size_t)b * p.d.mmax, (unsigned)(lane < p.d.mmax ? lane : 0) * 4u);
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + lane;
@@ -604,7 +605,7 @@ __device__ __forceinline__ RawEnv<JPL> blank_raw() {                      // res
 }
 
 template <int JPL, int TAB>
-__device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawEnv<JPL> &r, int clock, int status) {
+__device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawEnv<JPL> &r, int clock, int status, int32_t *scr) {
     e.t = clock;
     e.err = status & 0xFF;
     e.noop = (status & JSS_STATUS_NOOP) ? 1 : 0;
@@ -643,6 +644,18 @@ __device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawE
         }
         e.fill[s] = -1;
     }
+    if (tab_compact(TAB)) {
+        // time_until_available_machine[m] == time_until_finish_current_op_jobs[the job running on m] (both are set to
+        // the op's duration at :446-449 and count down together at :521-530), 0 for an idle machine.  scr: kWave ints
+        scr[c.lane] = 0;
+        wave_lds_sync();
+#pragma unroll
+        for (int s = 0; s < JPL; ++s)
+            if (e.left[s] > 0 && e.cur[s] >= 0) scr[e.cur[s] >> 16] = e.left[s];
+        wave_lds_sync();
+        e.tm = c.lane < c.M ? scr[c.lane] : 0;
+        wave_lds_sync();                                                 // scr is the observation image later on
+    }
 }
 
 // action mask row: legal jobs, the NOPE flag at index J, zeros behind it
@@ -674,7 +687,9 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
             *reinterpret_cast<int4 *>(cp + 8) = make_int4(as_int(c.r_sum), as_int(c.r_m), 0, 0);
         }
     }
-    if (all_rows) {
+    if (tab_compact(TAB)) {
+        // no machine clocks in memory (unpack_env)
+    } else if (all_rows) {
         if (c.lane < p.d.mmax) st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
     } else if (c.lane < c.M && e.tm != raw.tm) {                         // idle machines stay 0
         st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
@@ -849,7 +864,8 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
         ctx_table<TAB>(c, p, lds);
         hd.episode = __builtin_amdgcn_readfirstlane(h.episode);
         hd.step = __builtin_amdgcn_readfirstlane(h.step);
-        unpack_env<JPL, TAB>(e, c, raw, __builtin_amdgcn_readfirstlane(h.clock), __builtin_amdgcn_readfirstlane(h.status));
+        unpack_env<JPL, TAB>(e, c, raw, __builtin_amdgcn_readfirstlane(h.clock), __builtin_amdgcn_readfirstlane(h.status),
+                             reinterpret_cast<int32_t *>(scratch));
     }
 
     if (MODE == kStep) {

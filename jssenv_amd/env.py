@@ -368,13 +368,15 @@ class BatchedJssEnv:
             specs = [("env_header", (B, _abi.NH), "int32"),     # clock, episode, step_in_episode, status
                      ("env_const", (B, _abi.NC), "int32"),      # the env's instance constants, written by reset (JSS_C_*)
                      ("job_state", (B, J, self.record_ints), "int32"),   # one 32- (or compact: 16-) byte record per job
-                     ("machine_state", (B, M), "int32"),
+                     ("machine_state", (B, M), "int32"),      # (not with compact records: derived, see machine_state)
                      ("counters", (B, 4), "int64"),
                      ("real_obs", (B, J, 7), "float32"),
                      ("action_mask", (B, J + 1), "uint8"),
                      ("reward", (B,), "float32"), ("done", (B,), "uint8"), ("makespan", (B,), "int32"),
                      ("_actions_out", (B,), "int32"), ("_hole", (B,), "int32"), ("_act_buf", (B,), "int32"),
                      ("_act_in", (B,), "int32"), ("_which_in", (B,), "uint8")]
+            if self.compact:
+                specs = [sp for sp in specs if sp[0] != "machine_state"]
             self._layout, off = {}, 0
             for name, shape, dtype in specs:
                 self._layout[name] = (off, shape, dtype)
@@ -394,7 +396,8 @@ class BatchedJssEnv:
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._rem), p(self._inst), p(self._table_of_env), None,
                                   self.env_id_base, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)),
                                   int(pk.jobs.min()), self.record_ints)
-        self._state = _abi.JssState(p(self.env_header), p(self.env_const), p(self.job_state), p(self.machine_state), p(self.solution),
+        self._state = _abi.JssState(p(self.env_header), p(self.env_const), p(self.job_state),
+                                    None if self.compact else p(self.machine_state), p(self.solution),
                                     p(self.counters))
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
         self._is_reset = False
@@ -718,6 +721,37 @@ class BatchedJssEnv:
     def action_illegal_no_op(self):
         return (self.job_state[:, :, 0] >> (8 if self.compact else 9)) & 1
 
+    def __getattr__(self, name):
+        # compact batches keep no machine clocks in memory: time_until_available_machine[m] is the time left of the job
+        # running on m (both are set to the op's duration at jss_env.py:446-449 and count down together, :521-530)
+        if name == "machine_state" and self.__dict__.get("compact"):
+            return self._clocks_from_records()
+        raise AttributeError(name)
+
+    def _clocks_from_records(self):
+        """(B, M) int32 time_until_available_machine of a compact batch, computed from its job records where they live."""
+        js, M, J = self.job_state, int(self.packed.machines[0]), self.jmax
+        todo, left = js[:, :, _abi.FC_W0] & _abi.FC_TODO_MASK, js[:, :, _abi.FC_LEFT_F4] & 0xFFFF
+        if isinstance(js, np.ndarray):
+            ops = self.packed.ops[0]
+            cur = ops[np.arange(J)[None, :], np.minimum(todo, M - 1)]
+            tm = np.zeros((self.batch, self.mmax), dtype=np.int32)
+            b, j = np.nonzero((todo < M) & (left > 0))
+            tm[b, cur[b, j] >> 16] = left[b, j]
+            return tm
+        import torch
+        cur = self._ops[0][torch.arange(J, device=js.device)[None, :], todo.clamp(max=M - 1).long()]
+        val = torch.where((todo < M) & (left > 0), left, torch.zeros_like(left))
+        return torch.zeros((self.batch, self.mmax), dtype=torch.int32, device=js.device).scatter_add_(1, (cur >> 16).long(), val)
+
+    @staticmethod
+    def clocks_from_jobs(js, M):
+        """time_until_available_machine[M] from one env's decoded job matrix (``decode_jobs``)."""
+        tm = np.zeros(M, dtype=np.int64)
+        run = (js[_abi.F_LEFT] > 0) & (js[_abi.F_CUR] >= 0)
+        tm[js[_abi.F_CUR][run] >> 16] = js[_abi.F_LEFT][run]
+        return tm
+
     def counter_totals(self):
         """Device tensor [4]: env steps, finished episodes, sum of makespans, sum of reward numerators."""
         return self.counters.sum(0)
@@ -734,10 +768,13 @@ class BatchedJssEnv:
     _STATE_TENSORS = ("env_header", "env_const", "job_state", "machine_state", "solution", "counters", "real_obs", "action_mask",
                       "reward", "done", "makespan")
 
+    def _saved_tensors(self):                      # a compact batch has no machine clocks to save: they are derived
+        return tuple(k for k in self._STATE_TENSORS if k != "machine_state" or not self.compact)
+
     def state_dict(self):
         """Host copy of everything needed to resume: state + last outputs + the batch description."""
         n = self.backend.numpy
-        d = {k: n(getattr(self, k)) for k in self._STATE_TENSORS}
+        d = {k: n(getattr(self, k)) for k in self._saved_tensors()}
         d["meta"] = {"abi": _abi.ABI_VERSION, "record_ints": self.record_ints, "batch": self.batch, "jmax": self.jmax, "mmax": self.mmax, "seed": self.seed,
                      "env_id_base": self.env_id_base, "table_of_env": self.table_of_env_host.copy(),
                      "ops": self.packed.ops.copy(),
@@ -759,7 +796,7 @@ class BatchedJssEnv:
             raise ValueError(f"checkpoint was written by envs with other global ids (env_id_base {int(m['env_id_base'])} "
                              f"vs {self.env_id_base}, or different set_env_ids): the RNG streams would not continue")
         with self.backend.on_device():
-            for k in self._STATE_TENSORS:
+            for k in self._saved_tensors():
                 self.backend.copy_into(getattr(self, k), np.asarray(d[k]))
         self.seed, self._is_reset = int(m["seed"]), True
 
@@ -842,7 +879,7 @@ class BatchedJssEnv:
             "job_state": js,
             "next_op": nxt,
             "next2_op": nxt2,
-            "tm": t["machine_state"][:M].astype(np.int64),
+            "tm": self.clocks_from_jobs(js, M) if self.compact else t["machine_state"][:M].astype(np.int64),
             "mask": t["action_mask"][:J + 1].astype(bool),
             "mask_padding": t["action_mask"][J + 1:].copy(),
             "blocked": (js[7] & 2) != 0,
@@ -889,7 +926,8 @@ class _Snap:
             js, nxt, nxt2 = self.decode(t["job_state"][0], 0)
             c.update(job_state=js, next_op=nxt, next2_op=nxt2, blocked=(js[7] & 2) != 0)
         elif k == "tm":
-            c[k] = t["machine_state"][0, :M].astype(np.int64)
+            c[k] = (t["machine_state"][0, :M].astype(np.int64) if "machine_state" in t else
+                    BatchedJssEnv.clocks_from_jobs(self["job_state"], M))
         elif k == "mask":
             c[k] = t["action_mask"][0, :J + 1] != 0
         elif k == "obs":
