@@ -51,8 +51,8 @@ constexpr int kDurMask = 0xffff;
 // one-launch-per-env-step path)
 // kTraj = kRollout that also records every iteration's transition (JssTraj)
 enum Mode { kReset = 0, kStep = 1, kAdvance = 2, kPolicy = 3, kRollout = 4, kRollout1 = 5, kTraj = 6 };
-// where the op table lives: LDS (one instance shared by the batch) or global memory; kTabLdsC = LDS + compact 24-byte
-// job records (the record's three cached ops are re-read from the LDS table instead of being carried in HBM)
+// where the op table lives: LDS (one instance shared by the batch) or global memory; kTabLdsC = LDS + compact 16-byte
+// job records (the three cached ops are re-read from the LDS table, the machine clocks rebuilt from the records)
 enum Tab { kTabLds = 0, kTabGlobal = 1, kTabLdsC = 2 };
 constexpr bool tab_in_lds(int tab) { return tab != kTabGlobal; }
 constexpr bool tab_compact(int tab) { return tab == kTabLdsC; }

@@ -639,7 +639,7 @@ def case_dispatching_on_device(backend, inst="ta01", rules=("SPT", "FIFO", "MWR"
 
 
 def case_compact_equals_full(backend, insts=("ta01", "ta41", "ta51"), batch=7, n_iter=260, seed=23):
-    """A shared-instance batch with compact 24-byte job records (the default) and with full 32-byte records (what an
+    """A shared-instance batch with compact 16-byte job records (the default) and with full 32-byte records (what an
     ABI caller may still pass) are the same simulation: every other tensor bit-identical, the records equal after
     decoding, through rollout, step, advance, partial reset and the trajectory recorder."""
     for inst in insts:
