@@ -678,7 +678,7 @@ def main():
         env = None
         extras = [
             ("batch_x4", dict(workload="shared", batch=4 * B, policy=args.policy, instance=args.instance, modes=("eager", "sub2", "sub3"),
-                              label_extra=" -- 4x the batch: 420 MB working set, beyond the Infinity Cache")),
+                              label_extra=" -- 4x the batch (about 200 MB of state and outputs with compact records, plus the 236 MB solution tensor written one word per env step)")),
             ("synthetic15x15_per_env_tables", dict(workload="synthetic15x15", batch=B, policy=args.policy)),
             ("config2_ta01_batch4096_random", dict(workload="shared", batch=4096, policy="random", modes=("eager", "graph"),
                                                    with_trajectory=True)),
