@@ -673,6 +673,37 @@ def case_compact_equals_full(backend, insts=("ta01", "ta41", "ta51"), batch=7, n
         pass
 
 
+def case_compact_limits(backend, shapes=((3, 64), (4, 32), (16, 16), (33, 8)), seed=5):
+    """The packed words of the compact record at the limits the library accepts: every duration 65 533-65 535 (so
+    `left` and the feature-4 numerator use all 16 bits, total_perform_op_time all 22 on a 64-machine job), one shared
+    instance, played to completion in lock step with the oracle; then the same episode with full records, bit-equal."""
+    rng = np.random.default_rng(seed)
+    for (J, M) in shapes:
+        machine = np.stack([rng.permutation(M) for _ in range(J)]).astype(np.int32)
+        duration = (65535 - rng.integers(0, 3, size=(J, M))).astype(np.int32)
+        duration[0, :] = 65535
+        inst = I.Instance(f"limit_{J}x{M}", machine, duration)
+        env, orcs = case_batch_lockstep(backend, [inst], batch=3, n_steps=J * M + J, kind="random", seed=seed + J,
+                                        nope_every=7, check_every=3)
+        assert env.compact
+        full = BatchedJssEnv(inst, batch=3, seed=seed, env_id_base=9, compact=False, _backend=backend)
+        comp = BatchedJssEnv(inst, batch=3, seed=seed, env_id_base=9, _backend=backend)
+        n = comp.backend.numpy
+        for e in (full, comp):
+            e.reset()
+            e.rollout("random", n_iter=J * M - 1, autoreset=False)       # deep into the episode: the largest values
+        assert int(n(comp.total_perform_op_time_jobs).max()) > (M - 2) * 65533
+        for name in BatchedJssEnv._STATE_TENSORS:
+            if name != "job_state":
+                assert np.array_equal(n(getattr(full, name)), n(getattr(comp, name))), f"{J}x{M}: {name}"
+        for i in range(3):
+            (ja, na, n2a), (jb, nb, n2b) = comp.decode_jobs(n(comp.job_state)[i], i), full.decode_jobs(n(full.job_state)[i], i)
+            assert np.array_equal(ja, jb) and np.array_equal(na, nb) and np.array_equal(n2a, n2b), f"{J}x{M}: records of env {i}"
+        for prop in ("todo_time_step_job", "time_until_finish_current_op_jobs", "total_perform_op_time_jobs",
+                     "total_idle_time_jobs", "idle_time_jobs_last_op", "action_illegal_no_op", "needed_machine_jobs"):
+            assert np.array_equal(np.asarray(n(getattr(full, prop)))[:, :J], np.asarray(n(getattr(comp, prop)))[:, :J]), f"{J}x{M}: {prop}"
+
+
 def case_trajectory(backend, instances="ta01", batch=9, steps=40, kind="random", seed=17, explore=0.0, autoreset=True,
                     warm=0, table_of_env=None):
     """jss_trajectory (K steps per launch, every transition recorded) against K x (jss_policy, jss_step with next-step

@@ -219,3 +219,7 @@ def test_rollout_steps_multi_equals_separate_rollouts(cpu):
 
 def test_compact_records_equal_full_records(cpu):
     P.case_compact_equals_full(cpu)
+
+
+def test_compact_records_at_the_limits(cpu):
+    P.case_compact_limits(cpu)

@@ -247,3 +247,7 @@ def test_dispatching_fused_on_device(hip):
 
 def test_compact_records_equal_full_records(hip):
     P.case_compact_equals_full(hip, batch=70, n_iter=700)
+
+
+def test_compact_records_at_the_limits(hip):
+    P.case_compact_limits(hip)

@@ -125,3 +125,7 @@ def test_dispatching_fused_on_device(emu):
 
 def test_compact_records_equal_full_records(emu):
     P.case_compact_equals_full(emu, insts=("ta01", "ta51"), batch=3, n_iter=120)
+
+
+def test_compact_records_at_the_limits(emu):
+    P.case_compact_limits(emu, shapes=((3, 64), (16, 16)))
