@@ -128,9 +128,9 @@ __device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G, TAB> &c, const
         e.legal = c.jvalid;                                              // :160
         e.blocked = false;                                               // :171-172
         if (c.alive) {                                                   // solution = -1 (:163), the whole padded block
-            int32_t *sol = p.s.solution + ((size_t)c.first_env + c.rel) * p.d.jmax * p.d.mmax;
-            const int n = p.d.jmax * p.d.mmax;
-            for (int i = c.gl; i < n; i += G) sol[i] = -1;
+            const unsigned n = (unsigned)(p.d.jmax * p.d.mmax);         // wave-uniform base + 32-bit lane offset
+            int32_t *sol = p.s.solution + (size_t)c.first_env * n;
+            for (unsigned i = c.gl; i < n; i += G) st_off(sol, (c.rel * n + i) * 4u, -1);
         }
     }
 }
@@ -429,7 +429,8 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G, TAB> &c, const P
         if (c.gl == m) e.tm = d;                                         // :446
         if (mine) {
             e.left = d;                                                  // :447
-            p.s.solution[(((size_t)c.first_env + c.rel) * p.d.jmax + a) * p.d.mmax + e.todo] = e.t;  // :454
+            st_off(p.s.solution + (size_t)c.first_env * p.d.jmax * p.d.mmax,                       // :454
+                   (((unsigned)c.rel * p.d.jmax + a) * p.d.mmax + e.todo) * 4u, e.t);
         }
         if (e.cur >= 0 && (e.cur >> 16) == m) {
             e.legal = false;                                             // :455-463
