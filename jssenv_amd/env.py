@@ -67,7 +67,7 @@ class HipBackend:
         return 0 if x is None else x.data_ptr()
 
     def numpy(self, x):
-        return x.detach().cpu().numpy()
+        return x if isinstance(x, np.ndarray) else x.detach().cpu().numpy()   # (host-derived attributes are NumPy already)
 
     def as_device(self, x, dtype):
         t = self.torch.as_tensor(x, device=self.device)
