@@ -218,7 +218,7 @@ def test_rollout_steps_multi_equals_separate_rollouts(cpu):
 
 
 def test_compact_records_equal_full_records(cpu):
-    P.case_compact_equals_full(cpu)
+    P.case_compact_equals_full(cpu, insts=("ta01", "ta41", "ta51", "ta71"))
 
 
 def test_compact_records_at_the_limits(cpu):
