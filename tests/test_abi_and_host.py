@@ -72,6 +72,31 @@ def test_argument_errors_without_gpu(hip_lib):
     assert hip_lib.jss_rollout_steps(ctypes.byref(d), ctypes.byref(s), ctypes.byref(o), 0, 0, 0, 1, 0, 2, None) == -1
 
 
+@pytest.mark.parametrize("which", ["hip", "cpu"])
+def test_record_layout_is_validated_by_both_libraries(which, hip_lib):
+    """JssDesc.record_ints: 0 / 8 = full records (the machine-clock tensor is required), JSS_NFC = compact records
+    (one shared instance only; no machine-clock tensor needed).  Argument checks run before anything is launched."""
+    if which == "hip":
+        lib = _abi.bind(hip_lib)
+    else:
+        from jssenv_amd.build import build_cpu_twin
+        lib = _abi.bind(ctypes.CDLL(build_cpu_twin()))
+    buf = (ctypes.c_int32 * 4096)()
+    ptr = ctypes.cast(buf, ctypes.c_void_p)
+
+    def call(n_tables, record_ints, machine=ptr, batch=2):
+        d = _abi.JssDesc(batch, 15, 15, n_tables, ptr, ptr, ptr, None, None, 0, 0, 0, 15, record_ints)
+        s = _abi.JssState(ptr, ptr, ptr, machine, ptr, ptr)
+        return lib.jss_policy(ctypes.byref(d), ctypes.byref(s), 99, 0, 0, ptr, None)   # kind 99: E_KIND once the shapes pass
+
+    assert call(2, _abi.NFC) == _abi.E_SHAPE            # compact records need ONE shared instance
+    assert call(1, 5) == _abi.E_SHAPE and call(1, 6) == _abi.E_SHAPE   # (6 was the short-lived 24-byte record)
+    assert call(1, _abi.NF, machine=None) == _abi.E_NULL and call(1, 0, machine=None) == _abi.E_NULL
+    assert call(1, _abi.NFC, machine=None) == _abi.E_KIND   # accepted: no machine clocks with compact records
+    assert call(1, _abi.NFC) == _abi.E_KIND and call(1, 0) == _abi.E_KIND and call(2, _abi.NF) == _abi.E_KIND
+    assert call(3, 0) == _abi.E_SHAPE                   # neither one table, nor one per env, nor a table_of_env map
+
+
 def test_no_silent_cpu_fallback():
     """Without a GPU the default (HIP) path raises; the host-core twin is reachable only by asking for it."""
     import torch
