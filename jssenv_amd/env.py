@@ -683,15 +683,23 @@ class BatchedJssEnv:
 
     @property
     def needed_machine_jobs(self):
-        """(B, J) machine of every job's current op, -1 once the job is finished.  With compact records the op is not
-        stored: it is looked up in the (one) op table -- on the host, as NumPy."""
+        """(B, J) machine of every job's current op, -1 once the job is finished (same kind of array as the state
+        tensors).  With compact records the op is not stored: it is looked up in the batch's one op table."""
         if not self.compact:
             return self.job_state[:, :, _abi.F_CUR] >> 16
-        todo = self.backend.numpy(self.todo_time_step_job).astype(np.int64)
-        ops = self.packed.ops[0].astype(np.int64)
-        M = int(self.packed.machines[0])
-        cur = ops[np.arange(self.jmax)[None, :], np.minimum(todo, M - 1)]
-        return np.where(todo < M, cur >> 16, -1)
+        return self._current_ops() >> 16                      # a finished job's "op" is -1, and -1 >> 16 == -1
+
+    def _current_ops(self):
+        """(B, J) op table entry [j][todo_time_step_job[j]] of a compact batch (machine << 16 | duration), -1 where the
+        job is finished -- what a full record carries as its JSS_F_CUR word."""
+        js, M, J = self.job_state, int(self.packed.machines[0]), self.jmax
+        todo = js[:, :, _abi.FC_W0] & _abi.FC_TODO_MASK
+        if isinstance(js, np.ndarray):
+            cur = self.packed.ops[0][np.arange(J)[None, :], np.minimum(todo, M - 1)]
+            return np.where(todo < M, cur, -1).astype(np.int32)
+        import torch
+        cur = self._ops[0][torch.arange(J, device=js.device)[None, :], todo.clamp(max=M - 1).long()]
+        return torch.where(todo < M, cur, torch.full_like(cur, -1))
 
     @property
     def time_until_finish_current_op_jobs(self):
@@ -730,19 +738,18 @@ class BatchedJssEnv:
 
     def _clocks_from_records(self):
         """(B, M) int32 time_until_available_machine of a compact batch, computed from its job records where they live."""
-        js, M, J = self.job_state, int(self.packed.machines[0]), self.jmax
-        todo, left = js[:, :, _abi.FC_W0] & _abi.FC_TODO_MASK, js[:, :, _abi.FC_LEFT_F4] & 0xFFFF
+        js, cur = self.job_state, self._current_ops()
+        left = js[:, :, _abi.FC_LEFT_F4] & 0xFFFF
         if isinstance(js, np.ndarray):
-            ops = self.packed.ops[0]
-            cur = ops[np.arange(J)[None, :], np.minimum(todo, M - 1)]
             tm = np.zeros((self.batch, self.mmax), dtype=np.int32)
-            b, j = np.nonzero((todo < M) & (left > 0))
+            b, j = np.nonzero((cur >= 0) & (left > 0))
             tm[b, cur[b, j] >> 16] = left[b, j]
             return tm
         import torch
-        cur = self._ops[0][torch.arange(J, device=js.device)[None, :], todo.clamp(max=M - 1).long()]
-        val = torch.where((todo < M) & (left > 0), left, torch.zeros_like(left))
-        return torch.zeros((self.batch, self.mmax), dtype=torch.int32, device=js.device).scatter_add_(1, (cur >> 16).long(), val)
+        run = (cur >= 0) & (left > 0)                          # at most one running job per machine: the sum is a scatter
+        val = torch.where(run, left, torch.zeros_like(left))
+        idx = torch.where(run, cur >> 16, torch.zeros_like(cur)).long()
+        return torch.zeros((self.batch, self.mmax), dtype=torch.int32, device=js.device).scatter_add_(1, idx, val)
 
     @staticmethod
     def clocks_from_jobs(js, M):

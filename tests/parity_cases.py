@@ -958,7 +958,7 @@ def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=
     assert np.array_equal(hdr[:, _abi.H_STATUS] & 0xFF, want["err"]) and not want["err"].any(), f"{label}: error flags"
     J = env.jobs_per_env
     live = np.arange(env.jmax)[None, :] < J[:, None]                    # rows of real jobs
-    need = np.asarray(n(env.needed_machine_jobs) if not isinstance(env.needed_machine_jobs, np.ndarray) else env.needed_machine_jobs)
+    need = np.asarray(n(env.needed_machine_jobs))
     got_fields = [n(env.todo_time_step_job), np.where(live, need, 0), n(env.time_until_finish_current_op_jobs),
                   n(env.total_perform_op_time_jobs), n(env.total_idle_time_jobs), n(env.idle_time_jobs_last_op)]   # either record layout
     for f, (name, got) in enumerate(zip(G.JOB_FIELDS, got_fields)):
