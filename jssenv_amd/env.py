@@ -828,28 +828,25 @@ class BatchedJssEnv:
         with word 0 decoded -- row 0 = todo_time_step_job, row 7 = flags (1 legal, 2 blocked) -- plus the cached next ops
         (which a compact record does not store: they are what the op table says)."""
         J, M = int(self.jobs_per_env[i]), int(self.machines_per_env[i])
-        raw = np.asarray(raw)[:J].astype(np.int64) & 0xFFFFFFFF
-        w0 = raw[:, 0]
+        raw = np.asarray(raw)[:J].astype(np.int64)                 # the record's words, signed
+        u0 = raw[:, 0] & 0xFFFFFFFF                                 # word 0 as the bit field it is
         js = np.zeros((8, J), dtype=np.int64)
         if self.compact:
-            todo, w1 = w0 & _abi.FC_TODO_MASK, raw[:, _abi.FC_LEFT_F4]
-            js[_abi.F_TODO], js[7] = todo, (w0 >> 7) & 3
+            u1 = raw[:, _abi.FC_LEFT_F4] & 0xFFFFFFFF
+            todo = u0 & _abi.FC_TODO_MASK
+            js[_abi.F_TODO], js[7] = todo, (u0 >> 7) & 3
             ops = self.packed.ops[int(self.table_of_env_host[i])][:J].astype(np.int64)
             at = lambda k: np.where(todo + k < M, ops[np.arange(J), np.minimum(todo + k, M - 1)], -1)   # noqa: E731
             js[_abi.F_CUR], nxt, nxt2 = at(0), at(1), at(2)
-            js[_abi.F_LEFT], js[_abi.F_PERF] = w1 & 0xFFFF, w0 >> _abi.FC_PERF_SHIFT
-            js[_abi.F_F4] = np.where(w0 & _abi.FC_FLAG_F4_ONE, _abi.F4_ONE, w1 >> 16)
-            for f, fc in ((_abi.F_IDLE, _abi.FC_IDLE), (_abi.F_IDLE_LAST, _abi.FC_IDLE_LAST)):
-                js[f] = (raw[:, fc] + 2**31) % 2**32 - 2**31   # signed words
+            js[_abi.F_LEFT], js[_abi.F_PERF] = u1 & 0xFFFF, u0 >> _abi.FC_PERF_SHIFT
+            js[_abi.F_F4] = np.where(u0 & _abi.FC_FLAG_F4_ONE, _abi.F4_ONE, u1 >> 16)
+            js[_abi.F_IDLE], js[_abi.F_IDLE_LAST] = raw[:, _abi.FC_IDLE], raw[:, _abi.FC_IDLE_LAST]
         else:
-            raw = (raw + 2**31) % 2**32 - 2**31                 # back to signed words
-            w0 = raw[:, 0]
-            todo = w0 & _abi.TODO_MASK
-            js[_abi.F_TODO], js[7] = todo, (w0 >> 8) & 3
+            js[_abi.F_TODO], js[7] = u0 & _abi.TODO_MASK, (u0 >> 8) & 3
             for f in range(1, 7):
                 js[f] = raw[:, f]
             nxt = raw[:, _abi.F_NEXT]
-            n2 = (w0 & 0xFFFFFFFF) >> _abi.NEXT2_SHIFT
+            n2 = u0 >> _abi.NEXT2_SHIFT
             nxt2 = np.where(n2, n2, -1)
         return js, nxt, nxt2
 
