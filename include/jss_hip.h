@@ -182,8 +182,9 @@ extern "C" {
 #define JSS_ROLLOUT_AUTORESET 1 /* an env found done is reset instead of stepped (iteration not counted) */
 #define JSS_ROLLOUT_FORK_JOIN 2 /* jss_rollout_steps only: the library orders streams[1..] behind streams[0] before its first
                                    launch and streams[0] behind all of them after its last (hipEventRecord /
-                                   hipStreamWaitEvent on events it owns), so that the call is stream-ordered on streams[0]
-                                   like any other -- the caller does not fork / join.  One host thread per device. */
+                                   hipStreamWaitEvent on events it owns, one set per streams[0]), so that the call is
+                                   stream-ordered on streams[0] like any other -- the caller does not fork / join.  Calls
+                                   that share streams[0] must come from one host thread at a time. */
 
 /* argument errors */
 #define JSS_E_NULL (-1)

@@ -134,26 +134,30 @@ class BucketedJssEnv:
             for _, b in self._each():
                 self._run_bucket(b, kind, steps, n_iter, seed, autoreset, explore)
             return
-        if n_iter == 1 and hasattr(self._backend, "stream_array"):
+        each = self._each()
+        # the single-call path passes ONE seed for every bucket and at most 16 env sets: with per-bucket seeds that
+        # differ (seed=None) or more buckets, the per-bucket path below does the same work in more host calls
+        one_seed = seed is not None or len({b.seed for _, b in each}) == 1
+        if n_iter == 1 and hasattr(self._backend, "stream_array") and one_seed and len(each) <= 16:
             # ONE host call for the whole window: the library issues the launches step-major over the buckets and
             # forks / joins the side streams itself (jss_rollout_steps_multi)
             import ctypes as C
             from . import _abi
-            each = self._each()
             be = self._backend
             if not all(b._is_reset for _, b in each):
                 raise RuntimeError("call reset() before rollout_steps()")
             n = len(each)
-            if self._multi is None:
+            ident = tuple(id(b) for _, b in each)
+            if self._multi is None or self._multi[3] != ident:      # (rebuilt if the bucket set ever changes)
                 D, S, O = C.POINTER(_abi.JssDesc), C.POINTER(_abi.JssState), C.POINTER(_abi.JssOut)
                 self._multi = ((D * n)(*[C.pointer(b._desc) for _, b in each]), (S * n)(*[C.pointer(b._state) for _, b in each]),
-                               (O * n)(*[C.pointer(b._out) for _, b in each]))
+                               (O * n)(*[C.pointer(b._out) for _, b in each]), ident)
             k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
             # caller_orders_streams: the device is idle now and the caller synchronises the whole device afterwards
             flags = (_abi.ROLLOUT_AUTORESET if autoreset else 0) | (0 if caller_orders_streams else _abi.ROLLOUT_FORK_JOIN)
             sd = each[0][1].seed if seed is None else int(seed)
             with be.on_device():
-                rc = be.lib.jss_rollout_steps_multi(n, *self._multi, k, sd, int(round(explore * 65536)), int(steps), flags,
+                rc = be.lib.jss_rollout_steps_multi(n, *self._multi[:3], k, sd, int(round(explore * 65536)), int(steps), flags,
                                                     be.stream_array(n))
             _abi.check(be.lib, rc, "jss_rollout_steps_multi")
             return

@@ -6,9 +6,10 @@
 //   * wave flavour (jss_wave_env.hpp): one 64-lane wavefront simulates one env; job j sits on
 //     lane j%64 (slot j/64, JPL = 1 or 2 slots), machine m on lane m.  Packed flavour
 //     (jss_packed_env.hpp): 64/G envs per wavefront, G = 16 or 32 lanes per env.
-//   * everything a step needs to know about its env sits in the env's 64-byte header (clock, J, M, the
-//     observation's normalisers, the op table index: written by reset): no env -> instance -> shape chain
-//     of dependent loads in front of the state, no second fetch behind it.
+//   * everything a step needs to know about its env sits in the env's 16-byte header (clock, episode, step,
+//     status) and its 48-byte constants record (J, M, the observation's normalisers, the op table index:
+//     written by reset, JssState.env_const): no env -> instance -> shape chain of dependent loads in front
+//     of the state, no second fetch behind it.
 //   * the env's whole state lives in registers for the duration of the call: 8 int32 per job,
 //     which include the job's next THREE ops (current, next, and the one after it in the spare
 //     bits of word 0), so that a step touches the op table only when a job moves on to a new op

@@ -6,6 +6,9 @@
 //   jss_packed_env.hpp  64/G envs per wavefront      (J, M <= G, G = 16 or 32)
 //
 // No MFMA anywhere: the path is integer indexing, there is no dense contraction.
+#include <mutex>
+#include <unordered_map>
+
 #include "jss_common.hpp"
 #include "jss_packed_env.hpp"
 #include "jss_wave_env.hpp"
@@ -38,28 +41,47 @@ int check_kind(const JssDesc *d, int kind) {
     return 0;
 }
 
-// events of JSS_ROLLOUT_FORK_JOIN (created on first use; one host thread per device drives the library)
-hipEvent_t g_fork = nullptr, g_join[16] = {};
+// Events of JSS_ROLLOUT_FORK_JOIN: one set per main stream (streams[0]), created on first use on the device that is
+// current then -- the device the caller launches on -- and kept for the life of the process.  Two env objects on two
+// devices, or two host threads driving two streams, never share an event; the registry itself is guarded by a mutex.
+struct ForkJoinEvents {
+    hipEvent_t fork = nullptr;
+    hipEvent_t join[16] = {};
+};
+std::mutex g_events_mutex;
+std::unordered_map<void *, ForkJoinEvents> g_events;
 
-// streams[1..n) start behind everything queued on streams[0] so far ...
-int fork_streams(void *const *streams, int n) {
-    if (!g_fork) {
-        if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+int events_for(void *main_stream, ForkJoinEvents **out) {
+    std::lock_guard<std::mutex> lock(g_events_mutex);
+    ForkJoinEvents &ev = g_events[main_stream];
+    if (!ev.fork) {
+        if (hipEventCreateWithFlags(&ev.fork, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
         for (int i = 0; i < 16; ++i)
-            if (hipEventCreateWithFlags(&g_join[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+            if (hipEventCreateWithFlags(&ev.join[i], hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
     }
-    if (hipEventRecord(g_fork, reinterpret_cast<hipStream_t>(streams[0])) != hipSuccess) return (int)hipGetLastError();
-    for (int i = 1; i < n; ++i)
-        if (hipStreamWaitEvent(reinterpret_cast<hipStream_t>(streams[i]), g_fork, 0) != hipSuccess) return (int)hipGetLastError();
+    *out = &ev;                        // (unordered_map never moves its elements)
     return 0;
 }
-// ... and streams[0] continues behind all of them
-int join_streams(void *const *streams, int n) {
-    for (int i = 1; i < n; ++i) {
-        if (hipEventRecord(g_join[i], reinterpret_cast<hipStream_t>(streams[i])) != hipSuccess) return (int)hipGetLastError();
-        if (hipStreamWaitEvent(reinterpret_cast<hipStream_t>(streams[0]), g_join[i], 0) != hipSuccess) return (int)hipGetLastError();
-    }
+
+// streams[1..n) start behind everything queued on streams[0] so far ...
+int fork_streams(const ForkJoinEvents &ev, void *const *streams, int n) {
+    if (hipEventRecord(ev.fork, reinterpret_cast<hipStream_t>(streams[0])) != hipSuccess) return (int)hipGetLastError();
+    for (int i = 1; i < n; ++i)
+        if (hipStreamWaitEvent(reinterpret_cast<hipStream_t>(streams[i]), ev.fork, 0) != hipSuccess) return (int)hipGetLastError();
     return 0;
+}
+// ... and streams[0] continues behind all of them (every stream is joined even if one of the calls fails: a launch
+// error in the middle of a window must not leave side streams running free of the caller's stream)
+int join_streams(const ForkJoinEvents &ev, void *const *streams, int n) {
+    int rc = 0;
+    for (int i = 1; i < n; ++i) {
+        if (hipEventRecord(ev.join[i], reinterpret_cast<hipStream_t>(streams[i])) != hipSuccess ||
+            hipStreamWaitEvent(reinterpret_cast<hipStream_t>(streams[0]), ev.join[i], 0) != hipSuccess) {
+            const int e = (int)hipGetLastError();
+            if (!rc) rc = e;
+        }
+    }
+    return rc;
 }
 
 #ifdef JSS_PROFILING
@@ -290,11 +312,12 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
         sub[n++] = sub_batch(p, start, desc->batch - start < chunk ? desc->batch - start : chunk);
     }
     const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n > 1;
-    if (fork_join && (rc = fork_streams(streams, n))) return rc;
-    for (int s = 0; s < n_steps; ++s)
-        for (int i = 0; i < n; ++i)
-            if ((rc = fire(sub[i], lp, streams[i]))) return rc;
-    return fork_join ? join_streams(streams, n) : 0;
+    ForkJoinEvents *ev = nullptr;
+    if (fork_join && ((rc = events_for(streams[0], &ev)) || (rc = fork_streams(*ev, streams, n)))) return rc;
+    for (int s = 0; s < n_steps && !rc; ++s)
+        for (int i = 0; i < n && !rc; ++i) rc = fire(sub[i], lp, streams[i]);
+    const int jrc = fork_join ? join_streams(*ev, streams, n) : 0;
+    return rc ? rc : jrc;
 }
 
 int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states,
@@ -315,12 +338,13 @@ int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const J
         if ((rc = plan<kRollout1>(p, lps[i]))) return rc;
     }
     const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n_sets > 1;
-    int rc = fork_join ? fork_streams(streams, n_sets) : 0;
-    if (rc) return rc;
-    for (int s = 0; s < n_steps; ++s)
-        for (int i = 0; i < n_sets; ++i)
-            if ((rc = fire(ps[i], lps[i], streams[i]))) return rc;
-    return fork_join ? join_streams(streams, n_sets) : 0;
+    ForkJoinEvents *ev = nullptr;
+    int rc = 0;
+    if (fork_join && ((rc = events_for(streams[0], &ev)) || (rc = fork_streams(*ev, streams, n_sets)))) return rc;
+    for (int s = 0; s < n_steps && !rc; ++s)
+        for (int i = 0; i < n_sets && !rc; ++i) rc = fire(ps[i], lps[i], streams[i]);
+    const int jrc = fork_join ? join_streams(*ev, streams, n_sets) : 0;
+    return rc ? rc : jrc;
 }
 
 }  // extern "C"

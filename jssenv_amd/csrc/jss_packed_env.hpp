@@ -929,6 +929,9 @@ void jss_packed_kernel(Params p) {
 
     PEnv<G> e;
     PHeader hd = p_unpack(e, c, raw, mvtab);
+    // an env that was never reset (episode counter 0: every reset bumps it) is left alone by the step-type calls, like
+    // the one-wavefront-per-env kernel and the host twin do (J == 0 in its constants record): no stores, no counters
+    if (MODE != kReset && hd.episode == 0) c.alive = false;
     const bool fresh = p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab, scratch, wave_whole);
     if (MODE == kPolicy) return;
     p_store(e, c, p, hd, raw, fresh);

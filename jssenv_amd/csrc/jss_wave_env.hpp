@@ -1022,7 +1022,8 @@ __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel
         wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);   // full width: a reset writes every row of the padded block
     } else {
         // (a restart may hand the env a wider instance: it takes the full-width body)
-        if (JPL == 2 && ragged && !(MODE == kStep && a_in == JSS_ACTION_RESET) && __builtin_amdgcn_readfirstlane(h.J) <= kWave)
+        // (J == 64 stays on the full-width body: the NOPE flag of its mask row lives at index 64, slot 1's first lane)
+        if (JPL == 2 && ragged && !(MODE == kStep && a_in == JSS_ACTION_RESET) && __builtin_amdgcn_readfirstlane(h.J) < kWave)
             wave_main<1, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
         else
             wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);

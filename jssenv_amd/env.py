@@ -79,10 +79,10 @@ class HipBackend:
         device (an int64 tensor, what argmax returns, is converted by the copy kernel)."""
         t = self.torch
         if isinstance(x, t.Tensor):
+            if tuple(x.shape) != tuple(buf.shape):      # checked first: the kernels read buf.numel() elements
+                raise ValueError(f"expected shape {tuple(buf.shape)}, got {tuple(x.shape)}")
             if x.device == buf.device and x.dtype == buf.dtype and x.is_contiguous():
                 return x
-            if tuple(x.shape) != tuple(buf.shape):
-                raise ValueError(f"expected shape {tuple(buf.shape)}, got {tuple(x.shape)}")
             buf.copy_(x)
             return buf
         a = np.ascontiguousarray(np.asarray(x), dtype=np.dtype(str(buf.dtype).split(".")[-1]))
@@ -953,8 +953,20 @@ class _Snap:
         return c[k]
 
 
-class JssEnv:
-    """Drop-in for ``JSSEnv.envs.jss_env.JssEnv``: one env (B = 1) on the GPU.
+def gymnasium_base(which: str = "Env"):
+    """``gymnasium.Env`` (or ``gymnasium.vector.VectorEnv``) when gymnasium is importable and really has that class,
+    ``object`` otherwise: the reference's env IS a ``gym.Env`` (jss_env.py:14) and gymnasium's wrappers assert
+    ``isinstance(env, gymnasium.Env)``; without gymnasium the package works all the same."""
+    try:
+        import gymnasium
+        base = getattr(gymnasium, "Env", None) if which == "Env" else getattr(getattr(gymnasium, "vector", None), "VectorEnv", None)
+        return base if isinstance(base, type) else object
+    except Exception:
+        return object
+
+
+class JssEnv(gymnasium_base("Env")):
+    """Drop-in for ``JSSEnv.envs.jss_env.JssEnv``: one env (B = 1) on the GPU (a ``gymnasium.Env`` when gymnasium exists).
 
     Same constructor argument (``env_config={'instance_path': ...}``, default ta80 as at
     jss_env.py:35-38), same methods and return shapes, same public attributes (NumPy, pulled
@@ -1117,6 +1129,10 @@ class JssEnv:
         """Gantt chart of ``solution`` (jss_env.py:655-693); needs pandas + plotly on the host."""
         from .render import gantt
         return gantt(self)
+
+    def close(self):
+        """gymnasium.Env.close(): waits for the env's outstanding device work."""
+        self._b.synchronize()
 
     def _run_rule(self, kind, explore: float = 0.0, seed=None):
         """One whole episode of a dispatching rule, rule + step fused on the device (dispatching.py:55-75 with the

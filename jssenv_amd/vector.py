@@ -19,10 +19,13 @@ from __future__ import annotations
 
 from typing import Optional
 
-from .env import BatchedJssEnv
+from .env import BatchedJssEnv, gymnasium_base
 
 
-class JssVectorEnv:
+class JssVectorEnv(gymnasium_base("VectorEnv")):
+    """(a ``gymnasium.vector.VectorEnv`` when gymnasium is importable; its attributes are set here directly, the base
+    class's constructor -- whose signature differs between gymnasium 0.29 and 1.x -- is not called)"""
+
     def __init__(self, instances, num_envs: Optional[int] = None, device=None, to_numpy: bool = False, _backend=None):
         self.env = BatchedJssEnv(instances, batch=num_envs, device=device, _backend=_backend)
         self.num_envs = self.env.batch
@@ -36,8 +39,16 @@ class JssVectorEnv:
                 "action_mask": gym.spaces.Box(0, 1, shape=(J + 1,)),
                 "real_obs": gym.spaces.Box(low=0.0, high=1.0, shape=(J, 7), dtype=float),
             })
+            try:      # the batched spaces gymnasium.vector callers look at (real gymnasium only)
+                from gymnasium.vector.utils import batch_space
+                self.action_space = batch_space(self.single_action_space, self.num_envs)
+                self.observation_space = batch_space(self.single_observation_space, self.num_envs)
+            except Exception:
+                self.action_space = self.observation_space = None
         except Exception:  # gymnasium is optional
             self.single_action_space = self.single_observation_space = None
+            self.action_space = self.observation_space = None
+        self.closed = False
 
     def _out(self, x):
         return self.env.backend.numpy(x) if self.to_numpy else x
@@ -65,5 +76,6 @@ class JssVectorEnv:
     def makespan(self):
         return self._out(self.env.makespan)
 
-    def close(self):
+    def close(self, **kwargs):
         self.env.synchronize()
+        self.closed = True

@@ -412,6 +412,42 @@ def case_edge_shapes(backend, shapes=EDGE_SHAPES, steps=40, seed=2024, batch_per
             assert_matches_oracle(env2.host_state(i), o, f"edge {J}x{M} rollout env {i}")
 
 
+def case_ragged_j64_nope_flag(backend, steps=60, seed=3):
+    """A ragged batch padded beyond 64 jobs whose envs include one with EXACTLY 64 jobs: the NOPE flag of that env's
+    mask row sits at index 64 -- the first lane of the second job slot.  Every step, mask[J] must equal the header's
+    NOPE bit and the oracle's legal_actions[J] (NOPEs are taken whenever legal, to visit such states often)."""
+    rng = np.random.default_rng(seed)
+    insts = [random_instance(rng, 64, 6, max_dur=9), random_instance(rng, 70, 6, max_dur=9),
+             random_instance(rng, 63, 5, max_dur=9), random_instance(rng, 65, 4, max_dur=9)]
+    env = BatchedJssEnv(insts, seed=seed, _backend=backend)
+    orcs = [OracleEnv(i, strict=True) for i in insts]
+    env.reset()
+    for o in orcs:
+        o.reset()
+    n_noop = 0
+    for st in range(steps):
+        acts = []
+        for i, o in enumerate(orcs):
+            if o.nb_legal_actions == 0:
+                acts.append(_abi.ACTION_SKIP)
+                continue
+            a = o.jobs if o.legal_actions[o.jobs] else o.policy("random", seed=seed, env_id=i, episode=1, step=st)
+            n_noop += int(a == o.jobs)
+            o.step(a)
+            acts.append(a)
+        env.step(np.asarray(acts, dtype=np.int32))
+        hdr = env.backend.numpy(env.env_header)
+        mask = env.backend.numpy(env.action_mask)
+        for i, o in enumerate(orcs):
+            flag = bool(hdr[i, _abi.H_STATUS] & _abi.STATUS_NOOP)
+            assert bool(mask[i, o.jobs]) == flag == bool(o.legal_actions[o.jobs]), f"step {st} env {i} (J = {o.jobs}): NOPE flag"
+            assert not mask[i, o.jobs + 1:].any(), f"step {st} env {i}: bytes behind the NOPE flag"
+            assert np.array_equal(mask[i, :o.jobs] != 0, o.legal_actions[:o.jobs]), f"step {st} env {i}: mask"
+    for i, o in enumerate(orcs):
+        assert_matches_oracle(env.host_state(i), o, f"ragged J64 env {i}", check_outputs=False)
+    assert n_noop > 0, "the case never took a NOPE"
+
+
 def case_vector_env_features(backend):
     """step(autoreset=True) (gymnasium.vector next-step semantics) and state_dict round trip."""
     inst = I.builtin_instance("ta01")

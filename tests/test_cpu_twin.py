@@ -223,3 +223,7 @@ def test_compact_records_equal_full_records(cpu):
 
 def test_compact_records_at_the_limits(cpu):
     P.case_compact_limits(cpu)
+
+
+def test_ragged_batch_with_a_64_job_env(cpu):
+    P.case_ragged_j64_nope_flag(cpu, steps=200)

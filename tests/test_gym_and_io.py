@@ -29,17 +29,23 @@ _GYM_SCRIPT = textwrap.dedent('''
     def make(id, **kw):
         mod, cls = table[id].split(":")
         return getattr(importlib.import_module(mod), cls)(**kw)
-    gym.spaces, gym.envs, gym.make = spaces, envs, make
+    class Env:                      # gymnasium.Env / gymnasium.vector.VectorEnv: the package subclasses them when present
+        pass
+    class VectorEnv:
+        pass
+    vector = types.ModuleType("gymnasium.vector"); vector.VectorEnv = VectorEnv
+    gym.spaces, gym.envs, gym.make, gym.Env, gym.vector = spaces, envs, make, Env, vector
     spaces.Discrete, spaces.Box, spaces.Dict = Discrete, Box, Dict
     registration.register = register; envs.registration = registration
     sys.modules.update({"gymnasium": gym, "gymnasium.spaces": spaces, "gymnasium.envs": envs,
-                        "gymnasium.envs.registration": registration})
+                        "gymnasium.envs.registration": registration, "gymnasium.vector": vector})
     sys.path.insert(0, %r)
     import gymnasium
     import jssenv_amd
     assert table == {"jss-v1": "jssenv_amd.env:JssEnv"}, table
     env = gymnasium.make("jss-v1", env_config={"instance_path": "ta01"}, device="cpu")
     assert type(env) is jssenv_amd.JssEnv
+    assert isinstance(env, gymnasium.Env)          # the reference: class JssEnv(gym.Env), jss_env.py:14
     assert isinstance(env.action_space, Discrete) and env.action_space.n == 16
     d = env.observation_space.spaces
     assert set(d) == {"action_mask", "real_obs"}
@@ -55,6 +61,8 @@ _GYM_SCRIPT = textwrap.dedent('''
     from jssenv_amd.vector import JssVectorEnv
     v = JssVectorEnv("ta01", num_envs=3, device="cpu")
     assert v.single_action_space.n == 16 and v.single_observation_space.spaces["real_obs"].shape == (15, 7)
+    assert isinstance(v, gymnasium.vector.VectorEnv)
+    env.close(); v.close()
     print("GYM-PATH-OK")
 ''')
 
@@ -62,6 +70,30 @@ _GYM_SCRIPT = textwrap.dedent('''
 def test_gymnasium_registration_and_spaces():
     out = subprocess.run([sys.executable, "-c", _GYM_SCRIPT % ROOT], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "GYM-PATH-OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_real_gymnasium_in_the_loop():
+    """With the real package (the reference's CI pins gymnasium==0.29.1): gym.make, isinstance, spaces, an episode
+    through the registered id.  Skipped where gymnasium is not installed (this image)."""
+    gymnasium = pytest.importorskip("gymnasium")
+    if not hasattr(gymnasium, "__version__"):
+        pytest.skip("a stand-in gymnasium module is installed, not the real package")
+    import jssenv_amd
+    env = gymnasium.make("jss-v1", env_config={"instance_path": "ta01"}, device="cpu", disable_env_checker=True)
+    base = env.unwrapped
+    assert isinstance(base, jssenv_amd.JssEnv) and isinstance(base, gymnasium.Env)
+    assert base.action_space.n == 16 and base.observation_space["real_obs"].shape == (15, 7)
+    obs = base.reset()
+    done, steps = False, 0
+    while not done:
+        a = int(np.flatnonzero(obs["action_mask"])[0])
+        obs, reward, done, truncated, info = base.step(a)
+        steps += 1
+    assert steps >= 225 and base.last_time_step == base.current_time_step
+    from jssenv_amd.vector import JssVectorEnv
+    v = JssVectorEnv("ta01", num_envs=3, device="cpu")
+    assert isinstance(v, gymnasium.vector.VectorEnv) and v.action_space is not None
+    v.close()
 
 
 def test_packed_batch_and_checkpoint_files(tmp_path):
@@ -130,6 +162,29 @@ def test_render_gantt_end_to_end():
         k = [x for x in rows if x["Task"] == r["Task"]].index(r)
         assert (r["Finish"] - r["Start"]).total_seconds() == env.instance.duration[job][k]
         assert r["Resource"] == f"Machine {int(env.instance.machine[job][k])}"
+
+
+def test_schedule_gif_is_written_without_imageio(tmp_path):
+    """The README's GIF recipe (README.md:158-197) as one call: frames of the growing schedule, written by imageio when
+    it exists and by Pillow otherwise; the plotly raster is used when kaleido exists, a Pillow drawing of the same
+    rows otherwise."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    from jssenv_amd import make
+    from jssenv_amd.dispatching import get_rule
+    from jssenv_amd.render import gantt_frame, record_episode_gif
+    env = make("jss-v1", env_config={"instance_path": "ta01"}, device="cpu")
+    env.reset()
+    assert gantt_frame(env) is None
+    rule = get_rule("MOR")
+    np.random.seed(1)
+    out = tmp_path / "ta01.gif"
+    n, makespan = record_episode_gif(env, rule, out, every=25, size=(480, 270))
+    assert makespan == env.current_time_step and n >= 225 // 25
+    with Image.open(out) as im:
+        assert im.format == "GIF" and getattr(im, "n_frames", 1) == n and im.size == (480, 270)
+    frame = gantt_frame(env, size=(480, 270), prefer_plotly=False)
+    assert frame.shape == (270, 480, 3) and frame.dtype == np.uint8 and (frame != 255).any()
 
 
 @pytest.mark.refcheck

@@ -149,6 +149,10 @@ def test_edge_shapes(hip):
     P.case_edge_shapes(hip, steps=300, batch_per_shape=5)
 
 
+def test_ragged_batch_with_a_64_job_env(hip):
+    P.case_ragged_j64_nope_flag(hip, steps=200)
+
+
 def test_vector_env_features(hip):
     P.case_vector_env_features(hip)
 

@@ -80,6 +80,10 @@ def test_edge_shapes(emu):
     P.case_edge_shapes(emu, steps=24, batch_per_shape=2)
 
 
+def test_ragged_batch_with_a_64_job_env(emu):
+    P.case_ragged_j64_nope_flag(emu)
+
+
 def test_vector_env_features(emu):
     P.case_vector_env_features(emu)
 
