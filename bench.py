@@ -220,6 +220,9 @@ def parse_args():
     ap.add_argument("--share-device", action="store_true",
                     help="debug: every rank uses cuda:0 (exercises the multi-process path on a 1-GPU box; use with "
                          "--dist-backend gloo)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="create the process group and run every barrier / all-reduce through it even with one rank "
+                         "(executes the RCCL lines of the multi-GPU path on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     return ap.parse_args()
@@ -262,21 +265,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = args.dist_backend or "nccl"   # "nccl" is RCCL on ROCm
-    if world > 1:
+    use_pg = world > 1 or args.force_process_group
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         kw = {"device_id": dev} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
         assert dist.get_world_size() == world
-    on_host = world > 1 and backend != "nccl"
+    on_host = use_pg and backend != "nccl"
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
 
     def agree_max(values):
         """element-wise MAX over ranks of a list of floats (every rank must take the same decisions)"""
         t = torch.tensor(values, dtype=torch.float64)
-        if world > 1:
+        if use_pg:
             t = t if on_host else t.to(dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t.tolist()]
@@ -410,7 +415,7 @@ def main():
         for _ in range(windows):
             env.zero_counters()
             dt, _ = window(env, policy, steps, n_iter, mode, graph, run, prep)
-            tot = reduce_counters(env.counter_totals().cpu() if on_host else env.counter_totals(), dt)
+            tot = reduce_counters(env.counter_totals().cpu() if on_host else env.counter_totals(), dt, force_collectives=use_pg)
             rows.append({"steps": tot["steps"], "seconds": tot["seconds"], "rate": tot["steps"] / tot["seconds"],
                          "episodes": tot["episodes"], "makespan_sum": tot["makespan_sum"], "reward_num": tot["reward_num_sum"]})
         # the GPU-time view (HIP events on the launch stream around the same K steps): a few extra windows of their own
@@ -715,6 +720,8 @@ def main():
             out["config4_sharded"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.synchronize()
 
+    if use_pg:
+        out["process_group"] = {"backend": backend, "world_size": dist.get_world_size(), "forced_at_world_1": world == 1}
     out["host"] = {"hsa_enable_interrupt": os.environ.get("HSA_ENABLE_INTERRUPT"),
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), **host_cores()}
     out["csrc_sha16"] = csrc_hash()
@@ -740,7 +747,7 @@ def main():
     import gc
     gc.collect()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

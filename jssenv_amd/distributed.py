@@ -21,16 +21,18 @@ def shard_bounds(global_batch: int, world_size: int, rank: int) -> Tuple[int, in
     return start, start + base + (1 if rank < extra else 0)
 
 
-def init_from_env(backend: Optional[str] = None):
+def init_from_env(backend: Optional[str] = None, force: bool = False):
     """Initialise torch.distributed from the torchrun environment (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_*).
-    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    Returns (rank, world_size, local_rank).  No-op for a single process unless ``force`` (a world of one rank still
+    goes through the backend then: how the RCCL lines get executed on a 1-GPU box)."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
         kwargs = {}
@@ -41,15 +43,16 @@ def init_from_env(backend: Optional[str] = None):
     return rank, world, local_rank
 
 
-def reduce_counters(counters, wall_seconds: float) -> Dict[str, float]:
+def reduce_counters(counters, wall_seconds: float, force_collectives: bool = False) -> Dict[str, float]:
     """counters: tensor [4] (or [B,4]) of this rank's window; returns the whole-job totals and the
-    max-over-ranks wall time.  One SUM and one MAX all-reduce."""
+    max-over-ranks wall time.  One SUM and one MAX all-reduce (skipped in a world of one rank unless
+    ``force_collectives``)."""
     import torch
     import torch.distributed as dist
     c = counters.sum(dim=0) if counters.dim() == 2 else counters
     c = c.to(torch.float64)
     t = torch.tensor([wall_seconds], dtype=torch.float64, device=c.device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives):
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     steps, episodes, makespan_sum, reward_num = [float(x) for x in c.tolist()]

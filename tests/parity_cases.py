@@ -975,14 +975,72 @@ FULL_SIZE_CONFIGS = [   # (label, BatchedJssEnv kwargs factory, policy, iteratio
 ]
 
 
-def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=6, env_id_base=123, autoreset=True):
-    """EVERY env of a (full-size) batch against the C oracle itself -- no twin in between: after the same fused
-    rollout from a fresh reset, every integer of the state (clock, the six per-job arrays, machine clocks, solution,
-    mask, blocked flags), the RNG position, the four counters and the error flags are bit-equal on all envs, the
-    float32 observation within 1e-6 of the oracle's float64 on all envs."""
+def drive_steps(env, kind, iters, form="fused", explore=0.0, autoreset=True, window=20, n_sub=2):
+    """`iters` x (policy + step) on `env` through one of the launch forms bench.py times:
+      fused       one jss_rollout(n_iter = iters) launch (state in registers; the kRollout kernels)
+      per_launch  iters x jss_rollout(n_iter = 1) on the current stream (the kRollout1 kernels)
+      free        windows of `window` steps through bind_rollout_steps(caller_orders_streams=True): n_sub sub-batches
+                  on n_sub streams with NO fork / join events, a device-wide synchronize on both sides of every window
+                  -- exactly bench.py's timed region (HIP backend; elsewhere the fork-join form)
+      fork_join   the same windows with the library's fork / join events (stream-ordered on the caller's stream)
+      graph       a captured hipGraph of `window` x jss_rollout(n_iter = 1), replayed iters // window times (+ eager tail)
+    """
+    be = env.backend
+    if form == "fused":
+        env.rollout(kind, n_iter=iters, autoreset=autoreset, explore=explore)
+    elif form == "per_launch":
+        for _ in range(iters):
+            env.rollout(kind, n_iter=1, autoreset=autoreset, explore=explore)
+    elif form in ("free", "fork_join"):
+        torch = getattr(be, "torch", None)
+        done = 0
+        while done < iters:
+            n = min(window, iters - done)
+            issue = env.bind_rollout_steps(kind, steps=n, n_sub=n_sub, autoreset=autoreset, explore=explore,
+                                           caller_orders_streams=(form == "free"))
+            if torch is not None:
+                torch.cuda.synchronize()
+            issue()
+            if torch is not None:
+                torch.cuda.synchronize()
+            done += n
+    elif form == "graph":
+        torch = be.torch
+        dev = be.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        snap = env._arena.clone(), env.solution.clone()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(window):
+                    env.rollout(kind, n_iter=1, autoreset=autoreset, explore=explore)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        # (capture does not execute; put back what a driver that runs warm-up launches inside capture would have changed)
+        env._arena.copy_(snap[0])
+        env.solution.copy_(snap[1])
+        for _ in range(iters // window):
+            graph.replay()
+        for _ in range(iters % window):
+            env.rollout(kind, n_iter=1, autoreset=autoreset, explore=explore)
+        torch.cuda.synchronize()
+        del graph
+    else:
+        raise KeyError(form)
+    env.synchronize()
+
+
+def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=6, env_id_base=123, autoreset=True,
+                             form="fused", n_sub=2):
+    """EVERY env of a (full-size) batch against the C oracle itself -- no twin in between: after the same
+    rollout from a fresh reset (through launch form `form`, see drive_steps), every integer of the state (clock, the six
+    per-job arrays, machine clocks, solution, mask, blocked flags), the RNG position, the four counters and the error
+    flags are bit-equal on all envs, the float32 observation within 1e-6 of the oracle's float64 on all envs."""
     env = BatchedJssEnv(seed=seed, env_id_base=env_id_base, _backend=backend, **kw)
     env.reset()
-    env.rollout(kind, n_iter=iters, autoreset=autoreset, explore=explore)
+    drive_steps(env, kind, iters, form=form, explore=explore, autoreset=autoreset, n_sub=n_sub)
+    label = f"{label} [{form}]"
     n = env.backend.numpy
     toe = None if env.n_tables == 1 or env.n_tables == env.batch and env._table_of_env is None else env.table_of_env_host
     want = rollout_batch(env.packed, env.batch, kind, seed, iters, table_of_env=toe, env_id_base=env_id_base,
@@ -1010,3 +1068,120 @@ def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=
     assert err <= OBS_TOL, f"{label}: observation max |diff| {err}"
     assert want["counters"][:, 0].min() > 0
     return env
+
+
+def _state_snapshot(env):
+    n = env.backend.numpy
+    return {k: n(getattr(env, k)) for k in BatchedJssEnv._STATE_TENSORS if k != "machine_state" or not env.compact}
+
+
+def case_step_graph_replay(backend, inst="ta01", batch=4096, K=40, warm=60, seed=8):
+    """The launch form bench.py's `step_only` figure (and config 2) uses: a captured hipGraph of K x jss_step with the
+    actions resident in HBM, replayed.  The replay -- twice, from the same starting state -- must leave every state and
+    output tensor exactly where K eager jss_step calls leave it, which in turn is where jss_trajectory (the recorder the
+    actions came from) left it."""
+    torch = backend.torch
+    env = BatchedJssEnv(inst, batch=batch, seed=seed, _backend=backend)
+    env.reset()
+    env.rollout("random", n_iter=warm)
+    env.zero_counters()
+    snap = env._arena.clone(), env.solution.clone()
+
+    def restore():
+        env._arena.copy_(snap[0])
+        env.solution.copy_(snap[1])
+        torch.cuda.synchronize()
+
+    acts = env.trajectory("random", steps=K, record=("action",))["action"]      # (K, B); -2 = auto-reset slots
+    env.synchronize()
+    want_traj = _state_snapshot(env)
+    restore()
+    for k in range(K):
+        env.step(acts[k])
+    env.synchronize()
+    want = _state_snapshot(env)
+    for name in want:
+        assert np.array_equal(want[name], want_traj[name]), f"K x jss_step differs from jss_trajectory in {name}"
+    assert want["counters"][:, 0].sum() > 0
+    restore()
+    dev = backend.device
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for k in range(K):
+                env.step(acts[k])
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for rep in range(2):
+        restore()
+        graph.replay()
+        torch.cuda.synchronize()
+        got = _state_snapshot(env)
+        for name in want:
+            assert np.array_equal(got[name], want[name]), f"hipGraph replay {rep} of K x jss_step differs from eager in {name}"
+    del graph
+
+
+def case_render_rows_from_device_solution(backend, inst="ta01", rule="SPT", steps=140):
+    """N4 on the real engine: the Gantt rows render() hands to plotly, built from the env's device-resident `solution`,
+    equal the rows of the oracle's schedule after the same actions (jss_env.py:655-693)."""
+    from jssenv_amd.dispatching import get_rule
+    from jssenv_amd.render import gantt_frame, gantt_rows
+    env = JssEnv({"instance_path": inst}, _backend=backend)
+    orc = OracleEnv(I.builtin_instance(inst), strict=True)
+    env.reset()
+    orc.reset()
+    assert gantt_rows(env.solution, env.instance, 0.0) == []
+    pick = get_rule(rule)
+    np.random.seed(4)
+    for _ in range(steps):
+        a = pick(env)
+        env.step(a)
+        orc.step(a)
+    rows = gantt_rows(env.solution, env.instance, 1000.0)
+    want = gantt_rows(orc.solution, env.instance, 1000.0)
+    assert rows == want and len(rows) == int((orc.solution >= 0).sum()) > 0
+    frame = gantt_frame(env, size=(320, 200), prefer_plotly=False)
+    assert frame.shape == (200, 320, 3) and (frame != 255).any()
+    return env
+
+
+def case_two_streams_two_threads(backend_factory, batch=3000, calls=12, steps=6, seed=2):
+    """Two env objects, each driven from its own host thread on its own stream through the library's fork / join form
+    (JSS_ROLLOUT_FORK_JOIN): the events belong to the main stream of the call, so neither thread records on the other's.
+    Results equal the same calls issued one after the other on one stream."""
+    import threading
+    be = backend_factory()
+    torch = be.torch
+    envs = [BatchedJssEnv("ta01", batch=batch, seed=seed + i, env_id_base=1000 * i, _backend=be) for i in range(2)]
+    refs = [BatchedJssEnv("ta01", batch=batch, seed=seed + i, env_id_base=1000 * i, _backend=be) for i in range(2)]
+    for e in envs + refs:
+        e.reset()
+    for r in refs:
+        for _ in range(calls):
+            r.rollout_steps("random", steps=steps, n_sub=3)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=be.device) for _ in range(2)]
+    errors = []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(calls):
+                    envs[i].rollout_steps("random", steps=steps, n_sub=3)
+            streams[i].synchronize()
+        except Exception as exc:            # surfaced in the main thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for e, r in zip(envs, refs):
+        a, b = _state_snapshot(e), _state_snapshot(r)
+        for name in a:
+            assert np.array_equal(a[name], b[name]), f"two threads / two streams: {name} differs from the serial run"

@@ -227,3 +227,11 @@ def test_compact_records_at_the_limits(cpu):
 
 def test_ragged_batch_with_a_64_job_env(cpu):
     P.case_ragged_j64_nope_flag(cpu, steps=200)
+
+
+def test_launch_form_driver_and_render_rows(cpu):
+    """The launch-form driver of the GPU tests (per-launch and sub-batch forms) and the render rows, on the twin."""
+    label, kw, kind, iters, explore = P.FULL_SIZE_CONFIGS[0]
+    P.case_every_env_vs_oracle(cpu, label, kw(), kind, 120, explore, form="per_launch")
+    P.case_every_env_vs_oracle(cpu, label, kw(), kind, 120, explore, form="fork_join", n_sub=3)
+    P.case_render_rows_from_device_solution(cpu)

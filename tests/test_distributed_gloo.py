@@ -144,3 +144,49 @@ def test_bench_eight_ranks_on_one_gpu():
     c4 = out["config4_sharded"]
     assert c4.get("value"), c4
     assert c4["global_batch"] == 65536 and c4["batch"] == 8192 and c4["n_gpus"] == 8 and c4["scaling"] == "strong"
+
+
+_RCCL_WORLD1 = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=%r)
+import torch, torch.distributed as dist
+from jssenv_amd.distributed import init_from_env, reduce_counters
+r, w, lr = init_from_env("nccl", force=True)           # "nccl" IS RCCL on ROCm
+assert (r, w, lr) == (0, 1, 0) and dist.is_initialized() and dist.get_backend() == "nccl"
+c = torch.tensor([[5, 1, 100, -7], [6, 0, 0, 9]], dtype=torch.int64, device="cuda:0")
+out = reduce_counters(c, 0.5, force_collectives=True)  # SUM + MAX all-reduce on device tensors through RCCL
+assert (out["steps"], out["episodes"], out["makespan_sum"], out["reward_num_sum"]) == (11.0, 1.0, 100.0, 2.0), out
+assert out["seconds"] == 0.5
+t = torch.arange(8, dtype=torch.float64, device="cuda:0")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert t.tolist() == list(range(8))
+dist.destroy_process_group()
+print("RCCL-WORLD1-OK")
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_process_group_of_one_rank():
+    """The lines only a multi-GPU run otherwise reaches -- init_process_group("nccl", device_id=...), all_reduce of
+    device tensors, barrier, teardown -- executed through RCCL with a world of one rank on the 1-GPU box."""
+    import subprocess
+    res = subprocess.run([sys.executable, "-c", _RCCL_WORLD1 % (ROOT, str(_free_port()))], capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0 and "RCCL-WORLD1-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_forced_process_group_over_rccl():
+    """bench.py --force-process-group: the bench's own barrier / agree_max / reduce_counters calls go through RCCL."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-process-group", "--steps", "5", "--warmup", "1",
+           "--batch", "4096", "--no-cpu-baseline", "--no-extras"]
+    res = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["process_group"] == {"backend": "nccl", "world_size": 1, "forced_at_world_1": True}
+    assert out["n_gpus"] == 1 and out["value"] > 0

@@ -255,3 +255,40 @@ def test_compact_records_equal_full_records(hip):
 
 def test_compact_records_at_the_limits(hip):
     P.case_compact_limits(hip)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the launch forms bench.py times: the kRollout1 instantiations <16,5,2> <32,5,2> <1,5,1> <2,5,1>
+# at full size, every env against the oracle, through each benchmarked form
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def hip_auto():
+    from jssenv_amd.env import HipBackend
+    return HipBackend("cuda:0")
+
+
+_FORMS = [(cfg, "free") for cfg in range(len(P.FULL_SIZE_CONFIGS))] + [(0, "graph"), (2, "graph"), (4, "graph"), (4, "fork_join"),
+                                                                      (3, "per_launch")]
+
+
+@pytest.mark.parametrize("cfg,form", _FORMS, ids=[f"{P.FULL_SIZE_CONFIGS[c][0].split(':')[0]}-{f}" for c, f in _FORMS])
+def test_benchmarked_launch_forms_every_env_equals_the_oracle(hip_auto, cfg, form):
+    """free = bind_rollout_steps(caller_orders_streams=True) between device-wide synchronizes (bench.py's timed window);
+    graph = a captured hipGraph of K x jss_rollout(n_iter = 1), replayed; fork_join = the library-ordered sub-batch
+    form; per_launch = K eager launches.  All drive the kRollout1 kernels -- the benchmarked instantiations."""
+    label, kw, kind, iters, explore = P.FULL_SIZE_CONFIGS[cfg]
+    P.case_every_env_vs_oracle(hip_auto, label, kw(), kind, iters, explore, form=form, n_sub=3 if cfg == 4 else 2)
+
+
+def test_step_graph_replay_equals_eager_steps(hip_auto):
+    P.case_step_graph_replay(hip_auto)
+    P.case_step_graph_replay(hip_auto, inst="ta41", batch=2048, K=25, warm=30)
+
+
+def test_render_rows_from_device_solution(hip_auto):
+    P.case_render_rows_from_device_solution(hip_auto)
+
+
+def test_two_envs_two_threads_two_streams():
+    from jssenv_amd.env import HipBackend
+    P.case_two_streams_two_threads(lambda: HipBackend("cuda:0"))
