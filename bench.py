@@ -506,8 +506,81 @@ def main():
             torch.cuda.synchronize()
             return {"value": None, "error": f"{type(exc).__name__}: {exc}"}
 
+    def external_action_forms(env, policy, alg, K):
+        """The step entry points that take the caller's actions, with the actions already resident in HBM (a recorded
+        behaviour trajectory of `policy` from the current state, consumed window after window -- every launch executes
+        real, legal steps and next-step auto-resets): (a) jss_steps, K steps per launch; (b) a step session, K steps
+        posted per wait (the resident kernel runs back to back); (c) the same session in lock step, one fused post + wait
+        launch per step -- the learner-in-the-loop form.  Windows of K steps between device-wide synchronizes, like
+        every other figure; the session is opened once, outside the windows (a learner keeps it open for a whole run)."""
+        out = {}
+        try:
+            B = env.batch
+            K = int(max(5, min(K, 50)))
+            n_win = int(max(6, min(60, 256e6 // (K * B * 4))))
+            env.zero_counters()
+            snap = env._arena.clone(), env.solution.clone()
+
+            def restore():
+                env._arena.copy_(snap[0])
+                env.solution.copy_(snap[1])
+                torch.cuda.synchronize()
+
+            acts = env.trajectory(policy, steps=(n_win + 1) * K, record=("action",))["action"]
+            counts = (acts >= 0).view(n_win + 1, K * B).sum(1).cpu().tolist()
+            restore()
+
+            cur = torch.cuda.current_stream(dev)
+
+            def timed(issue):
+                # (the CALLER's stream is synchronized, not the device: a device-wide synchronize would wait for the
+                # session's resident kernel, which ends when the session is closed)
+                rows = []
+                for w in range(n_win + 1):
+                    cur.synchronize()
+                    t0 = time.perf_counter()
+                    issue(w)
+                    cur.synchronize()
+                    rows.append(counts[w] / (time.perf_counter() - t0))
+                rows = sorted(rows[1:])                   # window 0 warms the path up
+                med = rows[len(rows) // 2]
+                return {"value": med, "unit": "env steps/s", "min": rows[0], "max": rows[-1], "windows": len(rows),
+                        "steps_each": K, "us_per_step": 1e6 * (sum(counts[1:]) / len(rows)) / med / K,
+                        "roofline_frac": med * alg / 1e9 / HBM_PEAK_GBS}
+
+            out["steps_per_launch"] = timed(lambda w: env.steps(acts[w * K:(w + 1) * K]))
+            out["steps_per_launch"]["launch"] = f"jss_steps: {K} x jss_step per launch, actions resident, state in registers in between"
+            restore()
+            with env.session(depth=K) as sess:
+                out["session_posted_ahead"] = timed(lambda w: (sess.post(acts[w * K:(w + 1) * K]), sess.wait()))
+            st = sess.host_status()
+            out["session_posted_ahead"].update(launch=f"step session: {K} steps posted per wait (one post + one wait kernel per window), "
+                                                      f"state resident on the chip", env_sets_per_wavefront=st["env_sets_per_wavefront"],
+                                               timeouts=st["session_timeouts"] + st["wait_timeouts"])
+            restore()
+
+            def lockstep(w):
+                for k in range(K):
+                    sess.step(acts[w * K + k])
+            with env.session(depth=1) as sess:
+                out["session_lockstep"] = timed(lockstep)
+            st = sess.host_status()
+            out["session_lockstep"].update(launch="step session: one fused post + wait launch per step (the caller's policy would run "
+                                                  "between two of them; its cost is not in the figure)",
+                                           env_sets_per_wavefront=st["env_sets_per_wavefront"],
+                                           timeouts=st["session_timeouts"] + st["wait_timeouts"])
+            restore()
+            del snap, acts
+        except Exception as exc:
+            out["error"] = f"{type(exc).__name__}: {exc}"
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+        return out
+
     def side_run(workload, batch, policy, label_extra="", instance="ta01", bucketed=False, modes=("eager", "graph", "sub2", "sub3"),
-                 first_env=None, keep=False, with_trajectory=False):
+                 first_env=None, keep=False, with_trajectory=False, with_external=False):
         """One extra workload on this GPU, same timing discipline as the headline."""
         alg, label, key = describe(workload, instance)
         env = make_env(workload, batch, first_env if first_env is not None else rank * batch, policy, instance=instance,
@@ -526,6 +599,8 @@ def main():
                "traffic": rf["traffic"], "mean_makespan": med["makespan_sum"] / med["episodes"] if med["episodes"] else None}
         if with_trajectory and not bucketed:
             out["trajectory"] = traj_measure(env, policy, alg)
+        if with_external and not bucketed:
+            out["external_actions"] = external_action_forms(env, policy, alg, args.steps)
         if keep:
             return out, env
         if hasattr(env, "close"):
@@ -624,6 +699,7 @@ def main():
             out["step_only"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.synchronize()
         out["trajectory"] = traj_measure(env, args.policy, alg_per_step)
+        out["external_actions"] = external_action_forms(env, args.policy, alg_per_step, args.steps)
         # the un-fused path: jss_policy (stand-in for a policy network) then jss_step(actions) with next-step auto-reset --
         # two launches + the action select per env step, hipGraph replay
         try:
@@ -686,13 +762,15 @@ def main():
                               label_extra=" -- 4x the batch (about 200 MB of state and outputs with compact records, plus the 236 MB solution tensor written one word per env step)")),
             ("synthetic15x15_per_env_tables", dict(workload="synthetic15x15", batch=B, policy=args.policy)),
             ("config2_ta01_batch4096_random", dict(workload="shared", batch=4096, policy="random", modes=("eager", "graph"),
-                                                   with_trajectory=True)),
-            ("config3_ta41_spt_batch16384", dict(workload="shared", batch=16384, policy="SPT", instance="ta41")),
-            ("config4_synthetic50x20_batch8192", dict(workload="synthetic50x20", batch=8192, policy="random", with_trajectory=True)),
+                                                   with_trajectory=True, with_external=True)),
+            ("config3_ta41_spt_batch16384", dict(workload="shared", batch=16384, policy="SPT", instance="ta41", with_trajectory=True,
+                                                 with_external=True)),
+            ("config4_synthetic50x20_batch8192", dict(workload="synthetic50x20", batch=8192, policy="random", with_trajectory=True,
+                                                      with_external=True)),
             ("config4_synthetic50x20_batch65536_one_gpu", dict(workload="synthetic50x20", batch=65536, policy="random",
                                                                label_extra=" -- all of config 4 on one GPU")),
             ("config5_mixed_padded_batch32768", dict(workload="mixed", batch=32768, policy="random", label_extra=", padded 100x20",
-                                                     with_trajectory=True)),
+                                                     with_trajectory=True, with_external=True)),
             ("config5_mixed_bucketed_batch32768", dict(workload="mixed", batch=32768, policy="random", bucketed=True,
                                                        label_extra=", shape-bucketed (no padding)")),
         ]

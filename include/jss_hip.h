@@ -28,6 +28,12 @@
  *                   reward and done flag it got -- the (s, a, r, d) stream a behaviour
  *                   policy (random, a dispatching rule) collects for a learner, K steps
  *                   per launch with the env state held in registers in between
+ *   jss_steps    <- K consecutive JssEnv.step(action) calls per env with the K actions given up front ([K][B], e.g. a
+ *                   recorded or planned action trace): ONE launch, the env state in registers in between, every
+ *                   step's (obs, mask, reward, done) optionally written step-major
+ *   jss_session_* <- the interactive loop `obs, r, done, _, _ = env.step(policy(obs))` (README.md:53-64) with the env
+ *                   state RESIDENT on the chip between steps: a kernel that lives across steps takes each step's
+ *                   actions from a device mailbox the caller's stream posts to, and writes that step's outputs
  *   jss_rollout_steps <- the same loop issued as n_sub independent sub-batches on
  *                   n_sub streams, so that consecutive steps of different sub-batches
  *                   overlap on the device (env instances are independent)
@@ -70,7 +76,7 @@
 extern "C" {
 #endif
 
-#define JSS_ABI_VERSION 7
+#define JSS_ABI_VERSION 8
 
 #define JSS_MAX_JOBS 128
 #define JSS_MAX_MACHINES 64
@@ -166,6 +172,8 @@ extern "C" {
                                 are left as they were (observation and mask are rewritten unchanged) */
 #define JSS_ACTION_RESET (-2) /* batched step: this env is reset() instead of stepped (reward 0, done 0, episode + 1):
                                  gymnasium.vector "next-step" auto-reset in the same launch as the other envs' steps */
+#define JSS_ACTION_CLOSE (-3) /* step-session mailbox only (posted by jss_session_close): the resident kernel stores the env
+                                 state and exits.  Anywhere else it is an out-of-range action (JSS_ERR_BAD_ACTION) */
 
 /* policies */
 #define JSS_POLICY_RANDOM 0
@@ -191,6 +199,9 @@ extern "C" {
 #define JSS_E_SHAPE (-2)
 #define JSS_E_KIND (-3)
 #define JSS_E_LDS (-4) /* the batch shape needs more LDS per workgroup than the device has */
+#define JSS_E_RESIDENT (-5) /* jss_session_open: the batch does not fit the chip as ONE round of resident workgroups (with
+                               room left for the caller's own kernels), even with 8 env sets per wavefront */
+#define JSS_E_SESSION (-6)  /* jss_session_post / wait / close: bad step range (ring overrun, not the next step, closed) */
 
 /* JssDesc.kernel: JSS_KERNEL_AUTO packs 64/G envs per wavefront when every env of the batch fits a 16- or
  * 32-lane group (jmax, mmax <= 32) and uses one wavefront per env otherwise; JSS_KERNEL_WAVE forces one
@@ -278,6 +289,61 @@ int jss_rollout(const JssDesc *desc, const JssState *state, const JssOut *out, i
  * episode's first observation) or JSS_ACTION_SKIP, reward 0.  State is read and written once per call. */
 int jss_trajectory(const JssDesc *desc, const JssState *state, const JssOut *out, const JssTraj *traj, int kind,
                    uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, void *stream);
+
+/* n_steps x jss_step per launch: actions[k * B + i] = the action of env i in step k (the codes of jss_step: job, J = NOPE,
+ * JSS_ACTION_SKIP, JSS_ACTION_RESET).  State, `out` and the counters end exactly as after n_steps jss_step calls with
+ * actions + k * B; the state is read and written ONCE.  With `traj` (may be NULL; any of its streams may be NULL) slot k
+ * holds what the k-th jss_step call would have left in `out`: real_obs / action_mask AFTER step k, reward and done of step
+ * k (envs skipped in step k: their unchanged values); traj->action is not written. */
+int jss_steps(const JssDesc *desc, const JssState *state, const JssOut *out, const JssTraj *traj, const int32_t *actions,
+              int32_t n_steps, void *stream);
+
+/* ---- step session: the env state stays on the chip between steps -----------------------------------------------
+ * jss_session_open launches ONE resident kernel on `stream` -- a stream of its own AND of a priority of its own
+ * (hipStreamCreateWithPriority): HIP maps the streams of one priority onto a small pool of hardware queues, and a kernel
+ * queued behind the resident one in the same queue would never start; everything else the caller does goes to streams
+ * of another priority.  Its wavefronts load their envs' state once and then, step after step, wait for the step's actions
+ * in the mailbox, execute jss_step's semantics on registers (env sets parked in LDS when a wavefront owns several), and
+ * write that step's real_obs / action_mask / reward / done / makespan / solution entry to `out` write-through, followed
+ * by a per-wavefront progress word.  Nothing of the state is read from or written to memory between open and close: a
+ * step moves the action in (8 bytes per env) and the outputs out.
+ *   mailbox    mail[(step % depth) * B + i] = (uint64_t)(step + 1) << 32 | (uint32_t)action of env i in `step`: the tag
+ *              makes a granule self-validating (one 8-byte store, no separate flag, no fence)
+ *   post       jss_session_post (a small kernel on the CALLER's stream, e.g. behind its policy network) writes the granules
+ *              of steps [first_step, first_step + n_steps) from an int32 [n_steps][B] action buffer
+ *   wait       jss_session_wait (a one-workgroup kernel on the caller's stream) returns once every wavefront has
+ *              published `steps_done` steps: kernels enqueued behind it see those steps' outputs
+ *   close      jss_session_close posts JSS_ACTION_CLOSE for step `next_step`: the resident kernel writes the state back
+ *              (job records, header, machine clocks) and adds its counters; after the session's stream has drained the
+ *              batch is an ordinary batch again.  State tensors and counters are NOT current while a session is open.
+ * The ring holds `depth` steps: the caller must not post step s before it has waited for step s - depth (the host
+ * functions check `first_step + n_steps - waited <= depth` from the numbers they are given; JSS_E_SESSION otherwise).
+ * While a session is open the caller synchronises its own streams, never the device (hipDeviceSynchronize would wait for
+ * the resident kernel).  Every device-side wait is bounded: a wavefront that sees no mail for timeout_ms stores its state, bumps status[0] and
+ * exits (the session is then dead: close it); a wait that times out bumps status[1].
+ * Residency: the grid must fit the chip in ONE round with a workgroup slot per CU to spare for the caller's kernels;
+ * jss_session_open picks the smallest number of env sets per wavefront (1, 2, 4, 8) that does, JSS_E_RESIDENT if none. */
+typedef struct JssSession {
+    uint64_t *mail;      /* [depth][B] action granules; zero-filled by the caller before open                          */
+    int32_t *progress;   /* [B] (one word per wavefront is used): steps published; zero-filled by the caller          */
+    int32_t *status;     /* [4]: wavefronts that timed out, waits that timed out, wavefronts that exited, env sets per
+                            wavefront chosen by open; zero-filled by the caller                                       */
+    int32_t depth;       /* steps the mailbox ring holds (>= 1)                                                       */
+    int32_t timeout_ms;  /* bound of every device-side wait (0 = 2000)                                                */
+    int32_t slots;       /* env sets per wavefront: 0 = the smallest of 1, 2, 4, 8 that fits; otherwise exactly this many
+                            (JSS_E_RESIDENT if that does not fit)                                                     */
+    int32_t reserved;
+} JssSession;
+
+int jss_session_open(const JssDesc *desc, const JssState *state, const JssOut *out, const JssSession *session, void *stream);
+/* `waited` = the number of steps the caller has already waited for (flow control of the ring, see above) */
+int jss_session_post(const JssDesc *desc, const JssSession *session, const int32_t *actions, int32_t first_step,
+                     int32_t n_steps, int32_t waited, void *stream);
+int jss_session_wait(const JssDesc *desc, const JssSession *session, int32_t steps_done, void *stream);
+/* post of ONE step + wait for it in a single launch on the caller's stream (the kernel's first workgroup stays until the step
+ * is finished): `obs, r, done = step(actions)` as one call.  step = the step's number (== steps posted so far == waited). */
+int jss_session_step(const JssDesc *desc, const JssSession *session, const int32_t *actions, int32_t step, void *stream);
+int jss_session_close(const JssDesc *desc, const JssSession *session, int32_t next_step, void *stream);
 
 /* Debug aid: waits for everything queued on `stream` and returns the first asynchronous error (0 = none).  The
  * launching calls above only report what the launch itself reports; a fault inside a kernel surfaces here.  The

@@ -9,7 +9,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 7
+ABI_VERSION = 8
+STATE_LAYOUT = 7     # version of the state tensors' layout (checkpoints): unchanged since ABI v7
 MAX_JOBS, MAX_MACHINES = 128, 64
 F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_NEXT, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
 TODO_MASK, FLAG_LEGAL, FLAG_BLOCKED, NEXT2_SHIFT = 255, 256, 512, 10
@@ -25,15 +26,16 @@ F4_ONE = -1
 I_JOBS, I_MACHINES, I_MAX_TIME_OP, I_MAX_TIME_JOBS, I_SUM_OP = 0, 1, 2, 3, 4
 I_RCP_MAX_TIME_OP, I_RCP_MAX_TIME_JOBS, I_RCP_SUM_OP, I_RCP_MACHINES, NI = 5, 6, 7, 8, 12
 ERR_ILLEGAL_ACTION, ERR_NOPE_IDLE, ERR_BAD_ACTION = 1, 2, 4
-ACTION_SKIP, ACTION_RESET = -1, -2
+ACTION_SKIP, ACTION_RESET, ACTION_CLOSE = -1, -2, -3
 POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6, "CR": 7}
 ROLLOUT_AUTORESET, ROLLOUT_FORK_JOIN = 1, 2
 KERNEL = {"auto": 0, "wave": 1}
-E_NULL, E_SHAPE, E_KIND, E_LDS = -1, -2, -3, -4
+E_NULL, E_SHAPE, E_KIND, E_LDS, E_RESIDENT, E_SESSION = -1, -2, -3, -4, -5, -6
 MAX_SUB_BATCHES = 16
 
 SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_backend", "jss_reset", "jss_step", "jss_advance", "jss_policy",
-           "jss_rollout", "jss_rollout_steps", "jss_rollout_steps_multi", "jss_trajectory", "jss_sync_check")
+           "jss_rollout", "jss_rollout_steps", "jss_rollout_steps_multi", "jss_trajectory", "jss_sync_check",
+           "jss_steps", "jss_session_open", "jss_session_post", "jss_session_wait", "jss_session_step", "jss_session_close")
 
 _p = C.c_void_p
 
@@ -55,6 +57,11 @@ class JssOut(C.Structure):
 
 class JssTraj(C.Structure):
     _fields_ = [("real_obs", _p), ("action_mask", _p), ("action", _p), ("reward", _p), ("done", _p)]
+
+
+class JssSession(C.Structure):
+    _fields_ = [("mail", _p), ("progress", _p), ("status", _p), ("depth", C.c_int32), ("timeout_ms", C.c_int32),
+                ("slots", C.c_int32), ("reserved", C.c_int32)]
 
 
 def library_path(name: str = "libjss_hip.so") -> str:
@@ -88,6 +95,14 @@ def bind(lib):
     lib.jss_trajectory.restype = C.c_int
     lib.jss_trajectory.argtypes = [D, S, O, C.POINTER(JssTraj), C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, _p]
     lib.jss_sync_check.restype, lib.jss_sync_check.argtypes = C.c_int, [_p]
+    SS = C.POINTER(JssSession)
+    lib.jss_steps.restype, lib.jss_steps.argtypes = C.c_int, [D, S, O, C.POINTER(JssTraj), _p, C.c_int32, _p]
+    lib.jss_session_open.restype, lib.jss_session_open.argtypes = C.c_int, [D, S, O, SS, _p]
+    lib.jss_session_post.restype = C.c_int
+    lib.jss_session_post.argtypes = [D, SS, _p, C.c_int32, C.c_int32, C.c_int32, _p]
+    lib.jss_session_wait.restype, lib.jss_session_wait.argtypes = C.c_int, [D, SS, C.c_int32, _p]
+    lib.jss_session_close.restype, lib.jss_session_close.argtypes = C.c_int, [D, SS, C.c_int32, _p]
+    lib.jss_session_step.restype, lib.jss_session_step.argtypes = C.c_int, [D, SS, _p, C.c_int32, _p]
     if lib.jss_abi_version() != ABI_VERSION:
         raise RuntimeError(f"library ABI {lib.jss_abi_version()} != expected {ABI_VERSION}")
     return lib

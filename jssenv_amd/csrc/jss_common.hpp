@@ -51,7 +51,10 @@ constexpr int kDurMask = 0xffff;
 // kRollout1 = kRollout with n_iter == 1 compiled loop-free (fewer live registers: the benchmarked
 // one-launch-per-env-step path)
 // kTraj = kRollout that also records every iteration's transition (JssTraj)
-enum Mode { kReset = 0, kStep = 1, kAdvance = 2, kPolicy = 3, kRollout = 4, kRollout1 = 5, kTraj = 6 };
+// kSteps = n_iter x kStep per launch with the actions given up front ([K][B]), optionally recording every step (JssTraj)
+// kSession = kStep's semantics inside the resident step-session kernel (outputs write-through, counters tallied in
+//            registers until the session closes); only the session kernels are instantiated with it
+enum Mode { kReset = 0, kStep = 1, kAdvance = 2, kPolicy = 3, kRollout = 4, kRollout1 = 5, kTraj = 6, kSteps = 7, kSession = 8 };
 // where the op table lives: LDS (one instance shared by the batch) or global memory; kTabLdsC = LDS + compact 16-byte
 // job records (the three cached ops are re-read from the LDS table, the machine clocks rebuilt from the records)
 enum Tab { kTabLds = 0, kTabGlobal = 1, kTabLdsC = 2 };
@@ -78,6 +81,15 @@ struct Params {
     int32_t mv_off_ints;     // packed kernel: LDS offset (ints) of the per-lane max_horizon_machine table
     int32_t norm_off_ints;   // packed kernel, kTabGlobal: LDS offset (ints) of the per-group observation normalisers
     int32_t ablate;          // JSS_PROFILING builds: JSS_PROF_ABLATE mask; 0 otherwise
+    // step session (jss_session_open)
+    const unsigned long long *mail;   // [depth][B] action granules: (step + 1) << 32 | action
+    int32_t *progress;                // one word per wavefront: steps published
+    int32_t *status;                  // [4] JssSession.status
+    long long timeout_ticks;          // bound of a mail wait, in ticks of the 100 MHz wall clock
+    int32_t depth;                    // ring depth in steps
+    int32_t slots;                    // env sets per wavefront (1, 2, 4, 8)
+    int32_t park_off_ints;            // LDS offset (ints) of the parked env sets: [wave][slot][kParkInt4][64 lanes] int4
+    int32_t norm_slot_ints;           // packed kernel, kTabGlobal: ints between two slots' normaliser tables
 };
 
 #ifdef JSS_PROFILING
@@ -201,6 +213,38 @@ __device__ __forceinline__ void add_counters(int64_t *cn, int steps, int episode
     if (episodes) atomicAdd(u + 1, (unsigned long long)(long long)episodes);
     if (makespan_sum) atomicAdd(u + 2, (unsigned long long)(long long)makespan_sum);
     if (reward_num) atomicAdd(u + 3, (unsigned long long)(long long)reward_num);   // two's complement: negative adds wrap correctly
+}
+
+// Write-through ("sc1") stores: the store leaves the XCD's L2 for memory as it is executed, so that a kernel of ANOTHER
+// launch (or another XCD's L2) finds it without this kernel ending or fencing -- how the resident step-session kernel
+// publishes a step's outputs (MI355X_MICROARCH.md, inter-workgroup visibility: 16-byte sc1 stores cost what plain ones
+// do).  <= 8 bytes: a relaxed agent-scope atomic store IS an sc1 store; 16 bytes: the instruction itself.  The wave
+// orders them before its progress word with wt_drain().
+// (16 bytes go out as a buffer store with the sc1 bit -- a builtin, so that the compiler's s_waitcnt bookkeeping counts
+//  it: an inline-asm store is invisible to it, and every later wait for a LOAD then also drained the newest stores, one
+//  memory round trip per step in the session kernels)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned jss_wt_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wt_store16(void *uniform_base, unsigned byte_off, float4 v) {
+    const jss_wt_v4u x = {(unsigned)as_int(v.x), (unsigned)as_int(v.y), (unsigned)as_int(v.z), (unsigned)as_int(v.w)};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_base, (short)0, -1, 0x00020000);   // raw, unbounded
+    __builtin_amdgcn_raw_buffer_store_b128(x, rsrc, (int)byte_off, 0, 16);                                             // aux 16 = sc1
+}
+__device__ __forceinline__ void wt_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
+__device__ __forceinline__ void wt_store16(void *uniform_base, unsigned byte_off, float4 v) {
+    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(uniform_base) + byte_off) = v;
+}
+__device__ __forceinline__ void wt_drain() {}
+#endif
+template <class T>
+__device__ __forceinline__ void wt_store(T *p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a word another launch writes while this kernel runs (mailbox granules, progress words): never from L1, never cached in a register
+template <class T>
+__device__ __forceinline__ T fresh_load(const T *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // LDS writes of one wave consumed by other lanes of the same wave

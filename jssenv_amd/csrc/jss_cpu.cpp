@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include "jss_hip.h"
 
@@ -484,7 +486,7 @@ void add_counters(const Call &c, int b, int steps, int episodes, long long makes
 
 uint64_t env_id_of(const Call &c, int b) { return (uint64_t)(c.d.env_ids ? c.d.env_ids[b] : c.d.env_id_base + b); }
 
-enum Mode { kReset, kStep, kAdvance, kPolicy, kRollout, kTraj };
+enum Mode { kReset, kStep, kAdvance, kPolicy, kRollout, kTraj, kSteps };
 
 void restart(const Env &e, const Call &c, int b) {                       // reset() + the bookkeeping around it
     const int episode = e.hdr[JSS_H_EPISODE];
@@ -493,6 +495,26 @@ void restart(const Env &e, const Call &c, int b) {                       // rese
     e.hdr[JSS_H_STEP] = 0;
     c.o.reward[b] = 0.f;
     c.o.done[b] = 0;
+}
+
+// One jss_step call of env b: a = job, J (NOPE), JSS_ACTION_SKIP or JSS_ACTION_RESET.  called = the env was stepped.
+void step_call(Env &e, const Call &c, int b, int a, bool &called, int &rn) {
+    called = false;
+    rn = 0;
+    if (a == JSS_ACTION_SKIP) return;                                     // untouched: reward / done / makespan stay
+    if (a == JSS_ACTION_RESET) {                                          // reset() instead of a step; the env may have been
+        e = env_of(c, b, true);                                           // given another instance since (table_of_env)
+        restart(e, c, b);
+        return;
+    }
+    rn = step_env(e, a);
+    called = true;
+    const bool done = n_legal(e) == 0;                                    // :639-653
+    e.hdr[JSS_H_STEP] += 1;
+    c.o.reward[b] = reward_of(e, rn);                                     // :483-493
+    c.o.done[b] = done ? 1 : 0;
+    if (done) c.o.makespan[b] = e.t();                                    // :650
+    add_counters(c, b, 1, done ? 1 : 0, done ? e.t() : 0, rn);
 }
 
 void run_env(const Call &c, int mode, int b) {
@@ -508,20 +530,23 @@ void run_env(const Call &c, int mode, int b) {
     if (e.J == 0) return;                                                 // never reset: nothing to step
     switch (mode) {
     case kStep: {
-        const int a = c.actions[b];
-        if (a == JSS_ACTION_SKIP) break;                                  // untouched: reward / done / makespan stay
-        if (a == JSS_ACTION_RESET) {                                      // reset() instead of a step; the env may have been
-            e = env_of(c, b, true);                                       // given another instance since (table_of_env)
-            restart(e, c, b);
-            break;
+        bool called;
+        int rn;
+        step_call(e, c, b, c.actions[b], called, rn);
+        break;
+    }
+    case kSteps: {                                                        // n_iter x kStep, actions [n_iter][B], every step optionally recorded
+        const int jm = c.d.jmax;
+        for (int it = 0; it < c.n_iter; ++it) {
+            const size_t slot = (size_t)it * c.d.batch + b;
+            bool called;
+            int rn;
+            step_call(e, c, b, c.actions[slot], called, rn);
+            write_obs_mask(e, jm, c.t.real_obs ? c.t.real_obs + slot * jm * 7 : nullptr,
+                           c.t.action_mask ? c.t.action_mask + slot * (jm + 1) : nullptr, false);
+            if (c.t.reward) c.t.reward[slot] = called ? reward_of(e, rn) : 0.f;
+            if (c.t.done) c.t.done[slot] = n_legal(e) == 0 ? 1 : 0;
         }
-        const int rn = step_env(e, a);
-        const bool done = n_legal(e) == 0;                                // :639-653
-        e.hdr[JSS_H_STEP] += 1;
-        c.o.reward[b] = reward_of(e, rn);                                 // :483-493
-        c.o.done[b] = done ? 1 : 0;
-        if (done) c.o.makespan[b] = e.t();                                // :650
-        add_counters(c, b, 1, done ? 1 : 0, done ? e.t() : 0, rn);
         break;
     }
     case kAdvance:
@@ -650,6 +675,8 @@ const char *jss_error_string(int code) {
     case JSS_E_SHAPE: return "bad shape (batch/jmax/mmax/n_tables/n_sub)";
     case JSS_E_KIND: return "unknown policy kind or kernel flavour";
     case JSS_E_LDS: return "batch shape needs more LDS per workgroup than the device provides";
+    case JSS_E_RESIDENT: return "the batch does not fit the chip as one round of resident workgroups (step session)";
+    case JSS_E_SESSION: return "step session: bad step range (mailbox ring overrun, or the session was never opened)";
     default: return "unknown error";
     }
 }
@@ -713,6 +740,94 @@ int jss_trajectory(const JssDesc *desc, const JssState *state, const JssOut *out
     c.d = *desc; c.s = *state; c.o = *out; c.t = *traj; c.kind = kind; c.seed = seed; c.explore_q16 = explore_q16;
     c.n_iter = n_steps; c.flags = flags;
     return run(c, kTraj);
+}
+
+int jss_steps(const JssDesc *desc, const JssState *state, const JssOut *out, const JssTraj *traj, const int32_t *actions,
+              int32_t n_steps, void *) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if (!actions) return JSS_E_NULL;
+    if (n_steps < 0) return JSS_E_SHAPE;
+    Call c;
+    c.d = *desc; c.s = *state; c.o = *out; c.actions = actions; c.n_iter = n_steps;
+    if (traj) c.t = *traj;
+    c.t.action = nullptr;
+    return run(c, kSteps);
+}
+
+// Step session on the host cores: nothing is resident between calls here (the "chip" is the cache hierarchy), so an open
+// session is a record of what it steps; post executes its steps on the spot -- the same jss_step semantics, one step
+// after the other -- and publishes the mailbox and progress words the way the device does; wait and close have nothing
+// left to wait for.
+struct HostSession {
+    JssDesc d;
+    JssState s;
+    JssOut o;
+    int next_step;
+};
+static std::mutex g_sessions_mutex;
+static std::unordered_map<const void *, HostSession> g_sessions;
+
+int jss_session_open(const JssDesc *desc, const JssState *state, const JssOut *out, const JssSession *session, void *) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if (!session || !session->mail || !session->progress || !session->status) return JSS_E_NULL;
+    if (session->depth < 1 || session->timeout_ms < 0 || desc->batch < 1) return JSS_E_SHAPE;
+    const int want = session->slots;
+    if (want != 0 && want != 1 && want != 2 && want != 4 && want != 8) return JSS_E_SHAPE;
+    std::lock_guard<std::mutex> lock(g_sessions_mutex);
+    g_sessions[session->progress] = HostSession{*desc, *state, *out, 0};
+    session->status[3] = want ? want : 1;
+    return 0;
+}
+
+int jss_session_post(const JssDesc *desc, const JssSession *session, const int32_t *actions, int32_t first_step,
+                     int32_t n_steps, int32_t waited, void *) {
+    if (!desc || !session || !session->mail || !actions) return JSS_E_NULL;
+    if (first_step < 0 || n_steps < 1 || waited < 0 || waited > first_step || first_step + n_steps - waited > session->depth)
+        return JSS_E_SESSION;
+    HostSession hs;
+    {
+        std::lock_guard<std::mutex> lock(g_sessions_mutex);
+        const auto it = g_sessions.find(session->progress);
+        if (it == g_sessions.end() || it->second.next_step != first_step) return JSS_E_SESSION;   // not open / not the next step
+        it->second.next_step += n_steps;
+        hs = it->second;
+    }
+    const size_t B = (size_t)desc->batch;
+    for (int k = 0; k < n_steps; ++k) {
+        const int step = first_step + k;
+        for (size_t i = 0; i < B; ++i)
+            session->mail[(size_t)(step % session->depth) * B + i] =
+                ((uint64_t)(uint32_t)(step + 1) << 32) | (uint32_t)actions[(size_t)k * B + i];
+        const int rc = jss_step(&hs.d, &hs.s, actions + (size_t)k * B, &hs.o, nullptr);
+        if (rc) return rc;
+        for (size_t i = 0; i < B; ++i) session->progress[i] = step + 1;
+    }
+    return 0;
+}
+
+int jss_session_wait(const JssDesc *desc, const JssSession *session, int32_t steps_done, void *) {
+    if (!desc || !session || !session->progress || !session->status) return JSS_E_NULL;
+    if (steps_done < 0) return JSS_E_SESSION;
+    std::lock_guard<std::mutex> lock(g_sessions_mutex);
+    const auto it = g_sessions.find(session->progress);
+    if (it == g_sessions.end()) return JSS_E_SESSION;
+    if (it->second.next_step < steps_done) session->status[1] += 1;       // would never arrive: report it like a timed-out wait
+    return 0;
+}
+
+int jss_session_step(const JssDesc *desc, const JssSession *session, const int32_t *actions, int32_t step, void *) {
+    return jss_session_post(desc, session, actions, step, 1, step, nullptr);
+}
+
+int jss_session_close(const JssDesc *desc, const JssSession *session, int32_t next_step, void *) {
+    if (!desc || !session || !session->mail) return JSS_E_NULL;
+    if (next_step < 0) return JSS_E_SESSION;
+    std::lock_guard<std::mutex> lock(g_sessions_mutex);
+    g_sessions.erase(session->progress);
+    session->status[2] += 1;
+    return 0;
 }
 
 int jss_sync_check(void *) { return 0; }                                  // every call of this library is synchronous

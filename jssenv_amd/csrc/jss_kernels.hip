@@ -151,6 +151,139 @@ int plan(Params &p, LaunchPlan &lp) {
     return 0;
 }
 
+// ---- step session ---------------------------------------------------------------------------------------
+template <int TAB>
+KernelFn pick_session_tab(int G, int jpl) {
+    if (G == 16) return jss_packed_session_kernel<16, TAB>;
+    if (G == 32) return jss_packed_session_kernel<32, TAB>;
+    if (jpl == 1) return jss_session_kernel<1, TAB>;
+    return jss_session_kernel<2, TAB>;
+}
+KernelFn pick_session(int G, int jpl, bool shared, bool compact) {
+    if (!shared) return pick_session_tab<kTabGlobal>(G, jpl);
+    return compact ? pick_session_tab<kTabLdsC>(G, jpl) : pick_session_tab<kTabLds>(G, jpl);
+}
+
+struct SessionInfo {          // what jss_session_wait needs to know about an open session (keyed by its progress pointer)
+    int active_waves;         // wavefronts that own at least one env set: the progress words the waiter sweeps
+    int slots;
+    long long timeout_ticks;
+};
+std::mutex g_sessions_mutex;
+std::unordered_map<const void *, SessionInfo> g_sessions;
+
+constexpr size_t kMaxSessionLds = 96 * 1024;       // per workgroup
+constexpr size_t kSessionLdsPerCu = 96 * 1024;     // of a CU's 160 KB, all resident workgroups of the session together
+constexpr long long kTicksPerMs = 100000;        // the wall clock of the device counts at 100 MHz
+
+// LDS layout, grid and residency of a session over the batch `p` describes with `slots` env sets per wavefront.
+// Fits = every workgroup is resident at once AND the chip keeps room for the caller's own kernels (post, wait, the
+// policy network): see the two budgets at the end.
+int plan_session(Params &p, LaunchPlan &lp, int slots, int *blocks_out, int *active_out) {
+    const bool shared = p.d.n_tables == 1, compact = p.d.record_ints == JSS_NFC;
+    const int G = packed_group(p.d);
+    const int jpl = p.d.jmax <= kWave ? 1 : 2;
+    p.region_ints = p.d.jmax * p.d.mmax;
+    p.table_lds_ints = shared ? ((p.region_ints + 3) & ~3) : 0;
+    p.slots = slots;
+    int envs_per_wave, park4;                        // park4: int4 per parked env set of one wavefront
+    if (G) {
+        envs_per_wave = kWave / G;
+        p.obs_wave_floats = ((kWave / G) * p.d.jmax * 7 + 3) & ~3;
+        p.mv_off_ints = p.table_lds_ints + kWavesPerBlock * p.obs_wave_floats;
+        p.norm_off_ints = p.mv_off_ints + kBlock;
+        p.norm_slot_ints = shared ? 0 : kBlock;
+        p.park_off_ints = p.norm_off_ints + (shared ? 0 : slots * kBlock);
+        park4 = (compact ? 1 : 3) * kWave + 8;
+    } else {
+        envs_per_wave = 1;
+        p.obs_wave_floats = (p.d.jmax * 7 + 3 + 3) & ~3;
+        if (p.obs_wave_floats < kWave) p.obs_wave_floats = kWave;
+        p.mv_off_ints = p.norm_off_ints = p.norm_slot_ints = 0;
+        p.park_off_ints = p.table_lds_ints + kWavesPerBlock * p.obs_wave_floats;
+        park4 = (compact ? jpl : 2 * jpl) * kWave + kWave / 4 + 1;
+    }
+    lp.shmem = sizeof(int32_t) * ((size_t)p.park_off_ints + (slots > 1 ? (size_t)kWavesPerBlock * slots * park4 * 4 : 0));
+    if (lp.shmem > kMaxSessionLds) return JSS_E_RESIDENT;
+    lp.fn = pick_session(G, jpl, shared, compact);
+    lp.envs_per_block = envs_per_wave * kWavesPerBlock * slots;
+    const int sets = (p.d.batch + envs_per_wave - 1) / envs_per_wave;
+    const int waves = (sets + slots - 1) / slots;
+    const int blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (lp.shmem > kMaxDynamicLds &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(lp.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.shmem) != hipSuccess) {
+        (void)hipGetLastError();
+        return JSS_E_LDS;
+    }
+    int dev = 0, n_cu = 0, occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(lp.fn), kBlock, 0) != hipSuccess)
+        return (int)hipGetLastError();
+    // Registers / wave slots: the occupancy query overstates what the hardware admits when a kernel uses more than 80
+    // SGPRs (these do: 6 workgroups per CU at most, MI355X_MICROARCH.md "Residency"); two workgroup slots per CU stay
+    // free.  LDS: the session takes at most kSessionLdsPerCu of a CU's 160 KB, so that a kernel of the caller that
+    // asks for up to 64 KB always finds room next to it.
+    if (occ > 6) occ = 6;
+    int usable = occ - 2;
+    const int by_lds = (int)(kSessionLdsPerCu / (lp.shmem ? lp.shmem : 1));
+    if (by_lds < usable) usable = by_lds;
+    if (usable < 1 || blocks > usable * n_cu) return JSS_E_RESIDENT;
+    *blocks_out = blocks;
+    *active_out = blocks * kWavesPerBlock < sets ? blocks * kWavesPerBlock : sets;
+    return 0;
+}
+
+// mail[(step % depth) * B + i] = (step + 1) << 32 | action, steps [first, first + n): one thread per env
+__global__ void jss_session_post_kernel(unsigned long long *mail, const int32_t *actions, int batch, int depth, int first, int n) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= batch) return;
+    for (int k = 0; k < n; ++k) {
+        const int step = first + k;
+        const int a = actions ? actions[(size_t)k * batch + i] : JSS_ACTION_CLOSE;
+        wt_store(mail + (size_t)(step % depth) * batch + i, ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned)a);
+    }
+}
+
+// returns once every active wavefront has published `steps_done` steps (one workgroup sweeps the progress words);
+// bounded: gives up -- status[1] += 1 -- after the session's timeout or as soon as a wavefront of the session has
+__device__ __forceinline__ void session_wait(const int32_t *progress, int32_t *status, int active, int steps_done, long long timeout_ticks) {
+    __shared__ int behind;
+    long long t0 = 0;
+    for (unsigned spins = 0;; ++spins) {
+        if (threadIdx.x == 0) behind = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int i = (int)threadIdx.x; i < active; i += (int)blockDim.x) mine |= fresh_load(progress + i) < steps_done ? 1 : 0;
+        if (mine) behind = 1;
+        __syncthreads();
+        const int b = behind;
+        __syncthreads();
+        if (!b) return;
+        __builtin_amdgcn_s_sleep(1);
+        bool give_up = fresh_load(status + 0) != 0;                          // a wavefront of the session timed out: it is dead
+        if ((spins & 63u) == 63u) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > timeout_ticks) give_up = true;
+        }
+        if (give_up) {                                                       // (uniform: every thread reads the same words)
+            if (threadIdx.x == 0) atomicAdd(status + 1, 1);
+            return;
+        }
+    }
+}
+__global__ void jss_session_wait_kernel(const int32_t *progress, int32_t *status, int active, int steps_done, long long timeout_ticks) {
+    session_wait(progress, status, active, steps_done, timeout_ticks);
+}
+// post of one step, and the first workgroup waits for it
+__global__ void jss_session_step_kernel(unsigned long long *mail, const int32_t *actions, int batch, int depth, int step,
+                                        const int32_t *progress, int32_t *status, int active, long long timeout_ticks) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < batch)
+        wt_store(mail + (size_t)(step % depth) * batch + i, ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned)actions[i]);
+    if (blockIdx.x == 0) session_wait(progress, status, active, step + 1, timeout_ticks);
+}
+
 int fire(const Params &p, const LaunchPlan &lp, void *stream) {
     if (p.d.batch == 0) return 0;
     const int blocks = (p.d.batch + lp.envs_per_block - 1) / lp.envs_per_block;
@@ -218,6 +351,8 @@ const char *jss_error_string(int code) {
     case JSS_E_SHAPE: return "bad shape (batch/jmax/mmax/n_tables/n_sub)";
     case JSS_E_KIND: return "unknown policy kind or kernel flavour";
     case JSS_E_LDS: return "batch shape needs more LDS per workgroup than the device provides";
+    case JSS_E_RESIDENT: return "the batch does not fit the chip as one round of resident workgroups (step session)";
+    case JSS_E_SESSION: return "step session: bad step range (mailbox ring overrun, or the session was never opened)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -282,6 +417,101 @@ int jss_trajectory(const JssDesc *desc, const JssState *state, const JssOut *out
     p.d = *desc; p.s = *state; p.o = *out; p.t = *traj; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
     p.n_iter = n_steps; p.flags = flags;
     return launch<kTraj>(p, stream);
+}
+
+int jss_steps(const JssDesc *desc, const JssState *state, const JssOut *out, const JssTraj *traj, const int32_t *actions,
+              int32_t n_steps, void *stream) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if (!actions) return JSS_E_NULL;
+    if (n_steps < 0) return JSS_E_SHAPE;
+    Params p = {};
+    p.d = *desc; p.s = *state; p.o = *out; p.actions = actions; p.n_iter = n_steps;
+    if (traj) p.t = *traj;
+    p.t.action = nullptr;
+    return launch<kSteps>(p, stream);
+}
+
+int jss_session_open(const JssDesc *desc, const JssState *state, const JssOut *out, const JssSession *session, void *stream) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if (!session || !session->mail || !session->progress || !session->status) return JSS_E_NULL;
+    if (session->depth < 1 || session->timeout_ms < 0 || desc->batch < 1) return JSS_E_SHAPE;
+    const int want = session->slots;
+    if (want != 0 && want != 1 && want != 2 && want != 4 && want != 8) return JSS_E_SHAPE;
+    Params p = {};
+    p.d = *desc; p.s = *state; p.o = *out;
+    p.mail = reinterpret_cast<const unsigned long long *>(session->mail);
+    p.progress = session->progress;
+    p.status = session->status;
+    p.depth = session->depth;
+    p.timeout_ticks = (long long)(session->timeout_ms ? session->timeout_ms : 2000) * kTicksPerMs;
+    LaunchPlan lp;
+    int blocks = 0, active = 0;
+    rc = JSS_E_RESIDENT;
+    for (int slots = want ? want : 1; slots <= (want ? want : 8); slots *= 2) {
+        rc = plan_session(p, lp, slots, &blocks, &active);
+        if (rc != JSS_E_RESIDENT) break;
+    }
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lock(g_sessions_mutex);
+        g_sessions[session->progress] = SessionInfo{active, p.slots, p.timeout_ticks};
+    }
+    hipLaunchKernelGGL(lp.fn, dim3(blocks), dim3(kBlock), lp.shmem, reinterpret_cast<hipStream_t>(stream), p);
+    return (int)hipGetLastError();
+}
+
+int jss_session_post(const JssDesc *desc, const JssSession *session, const int32_t *actions, int32_t first_step,
+                     int32_t n_steps, int32_t waited, void *stream) {
+    if (!desc || !session || !session->mail || !actions) return JSS_E_NULL;
+    if (first_step < 0 || n_steps < 1 || waited < 0 || waited > first_step || first_step + n_steps - waited > session->depth)
+        return JSS_E_SESSION;
+    hipLaunchKernelGGL(jss_session_post_kernel, dim3((desc->batch + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<unsigned long long *>(session->mail), actions,
+                       desc->batch, session->depth, first_step, n_steps);
+    return (int)hipGetLastError();
+}
+
+int jss_session_wait(const JssDesc *desc, const JssSession *session, int32_t steps_done, void *stream) {
+    if (!desc || !session || !session->progress || !session->status) return JSS_E_NULL;
+    if (steps_done < 0) return JSS_E_SESSION;
+    SessionInfo info;
+    {
+        std::lock_guard<std::mutex> lock(g_sessions_mutex);
+        const auto it = g_sessions.find(session->progress);
+        if (it == g_sessions.end()) return JSS_E_SESSION;                    // never opened
+        info = it->second;
+    }
+    hipLaunchKernelGGL(jss_session_wait_kernel, dim3(1), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream),
+                       session->progress, session->status, info.active_waves, steps_done, info.timeout_ticks);
+    return (int)hipGetLastError();
+}
+
+int jss_session_step(const JssDesc *desc, const JssSession *session, const int32_t *actions, int32_t step, void *stream) {
+    if (!desc || !session || !session->mail || !session->progress || !session->status || !actions) return JSS_E_NULL;
+    if (step < 0) return JSS_E_SESSION;
+    SessionInfo info;
+    {
+        std::lock_guard<std::mutex> lock(g_sessions_mutex);
+        const auto it = g_sessions.find(session->progress);
+        if (it == g_sessions.end()) return JSS_E_SESSION;
+        info = it->second;
+    }
+    hipLaunchKernelGGL(jss_session_step_kernel, dim3((desc->batch + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<unsigned long long *>(session->mail), actions,
+                       desc->batch, session->depth, step, session->progress, session->status, info.active_waves, info.timeout_ticks);
+    return (int)hipGetLastError();
+}
+
+int jss_session_close(const JssDesc *desc, const JssSession *session, int32_t next_step, void *stream) {
+    if (!desc || !session || !session->mail) return JSS_E_NULL;
+    if (next_step < 0) return JSS_E_SESSION;
+    // (the caller has waited for every step it posted: the slot of next_step is free)
+    hipLaunchKernelGGL(jss_session_post_kernel, dim3((desc->batch + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<unsigned long long *>(session->mail),
+                       static_cast<const int32_t *>(nullptr), desc->batch, session->depth, next_step, 1);
+    return (int)hipGetLastError();
 }
 
 int jss_sync_check(void *stream) {

@@ -38,6 +38,13 @@ __device__ __forceinline__ void st_nt(void *base, unsigned byte_off, float4 v) {
     __builtin_nontemporal_store(x, reinterpret_cast<jss_v4f *>(reinterpret_cast<char *>(base) + byte_off));
 }
 
+// an output store: plain, or write-through in the resident step-session kernel (jss_common.hpp wt_store)
+template <bool WT, class T>
+__device__ __forceinline__ void st_out(void *base, unsigned byte_off, T v) {
+    if (WT) wt_store(reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off), v);
+    else st_off<T>(base, byte_off, v);
+}
+
 template <int G, int TAB>
 struct PCtx {                 // per-lane view of "my env"
     int lane, gl, gbase;      // gl = lane within the group, gbase = first lane of the group
@@ -112,7 +119,7 @@ __device__ __forceinline__ int grp_sum(int v) {
 // ---------------------------------------------------------------------------------------
 // reset(): jss_env.py:145-181 (registers only; `on` = groups being reset)
 // ---------------------------------------------------------------------------------------
-template <int G, int TAB>
+template <int G, int TAB, bool WT = false>
 __device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, bool on) {
     if (on) {
         e.t = 0;                                                         // :154
@@ -130,7 +137,7 @@ __device__ __forceinline__ void p_reset(PEnv<G> &e, const PCtx<G, TAB> &c, const
         if (c.alive) {                                                   // solution = -1 (:163), the whole padded block
             const unsigned n = (unsigned)(p.d.jmax * p.d.mmax);         // wave-uniform base + 32-bit lane offset
             int32_t *sol = p.s.solution + (size_t)c.first_env * n;
-            for (unsigned i = c.gl; i < n; i += G) st_off(sol, (c.rel * n + i) * 4u, -1);
+            for (unsigned i = c.gl; i < n; i += G) st_out<WT, int>(sol, (c.rel * n + i) * 4u, -1);
         }
     }
 }
@@ -412,7 +419,7 @@ __device__ __forceinline__ void p_check_no_op(PEnv<G> &e, const PCtx<G, TAB> &c,
 // ---------------------------------------------------------------------------------------
 // step(): jss_env.py:403-481.  `a` is group-uniform.  Returns the reward numerator.
 // ---------------------------------------------------------------------------------------
-template <int G, int TAB>
+template <int G, int TAB, bool WT = false>
 __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, int a, int32_t *mvtab) {
     const bool is_nope = c.alive && a == c.J;                            // :419
     const bool is_job = c.alive && a >= 0 && a < c.J;
@@ -429,8 +436,8 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G, TAB> &c, const P
         if (c.gl == m) e.tm = d;                                         // :446
         if (mine) {
             e.left = d;                                                  // :447
-            st_off(p.s.solution + (size_t)c.first_env * p.d.jmax * p.d.mmax,                       // :454
-                   (((unsigned)c.rel * p.d.jmax + a) * p.d.mmax + e.todo) * 4u, e.t);
+            st_out<WT, int>(p.s.solution + (size_t)c.first_env * p.d.jmax * p.d.mmax,               // :454
+                            (((unsigned)c.rel * p.d.jmax + a) * p.d.mmax + e.todo) * 4u, e.t);
         }
         if (e.cur >= 0 && (e.cur >> 16) == m) {
             e.legal = false;                                             // :455-463
@@ -586,14 +593,14 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, c
 }
 
 // action mask rows of jmax + 1 bytes at `mk` (first env of the wave): legal jobs, the NOPE flag at index J, zeros behind it
-template <int G, int TAB>
+template <int G, int TAB, bool WT = false>
 __device__ __forceinline__ void p_store_mask(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, uint8_t *mk) {
     if (!c.alive) return;
     const unsigned jm = (unsigned)p.d.jmax;
     const unsigned mo = c.rel * (jm + 1);
     if ((unsigned)c.gl <= jm)
-        st_off<uint8_t>(mk, mo + c.gl, (uint8_t)(c.jvalid ? (e.legal ? 1 : 0) : (c.gl == c.J ? e.noop : 0)));
-    if (jm == (unsigned)G && c.gl == 0) st_off<uint8_t>(mk, mo + jm, (uint8_t)(c.J == G ? e.noop : 0));
+        st_out<WT, uint8_t>(mk, mo + c.gl, (uint8_t)(c.jvalid ? (e.legal ? 1 : 0) : (c.gl == c.J ? e.noop : 0)));
+    if (jm == (unsigned)G && c.gl == 0) st_out<WT, uint8_t>(mk, mo + jm, (uint8_t)(c.J == G ? e.noop : 0));
 }
 
 // the observation's normalisers of my env (see PCtx)
@@ -614,6 +621,26 @@ __device__ __forceinline__ PNorm p_norm(const PCtx<G, TAB> &c) {
     return n;
 }
 
+// The record words of my job as they are stored (the inverse of p_unpack; PRaw.h = the env's header)
+template <int G, int TAB>
+__device__ __forceinline__ PRaw<G> p_pack(const PEnv<G> &e, const PCtx<G, TAB> &c, const PHeader &hd) {
+    PRaw<G> r;
+    r.h = make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
+    r.tm = e.tm;
+    if (tab_compact(TAB)) {
+        const bool one = e.f4 == JSS_F4_ONE;
+        r.lo = make_int4((int)((unsigned)e.todo | (e.legal ? JSS_FC_FLAG_LEGAL : 0u) | (e.blocked ? JSS_FC_FLAG_BLOCKED : 0u) |
+                               (one ? JSS_FC_FLAG_F4_ONE : 0u) | ((unsigned)e.perf << JSS_FC_PERF_SHIFT)),
+                         (int)((unsigned)e.left | ((unsigned)(one ? 0 : e.f4) << 16)), e.idle, e.idle_last);
+        r.hi = make_int4(0, 0, 0, 0);
+    } else {
+        r.lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0) |
+                             (e.nxt2 >= 0 ? (int)((unsigned)e.nxt2 << JSS_NEXT2_SHIFT) : 0), e.cur, e.left, e.perf);
+        r.hi = make_int4(e.idle, e.idle_last, e.f4, e.nxt);
+    }
+    return r;
+}
+
 // State back to HBM.  fresh = my env was (re)initialised by this call: every row of its padded block is written (rows
 // behind J(env) as "no job") together with the instance constants in its header; otherwise rows < J(env), and of
 // those only the halves that changed.
@@ -623,9 +650,9 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
     if (!c.alive) return;
     const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
     const size_t fe = (size_t)c.first_env;
+    const PRaw<G> now = p_pack(e, c, hd);
     if (c.gl == 0) {
-        st_off(p.s.env + fe * JSS_NH, c.rel * (JSS_NH * 4u),
-               make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0)));
+        st_off(p.s.env + fe * JSS_NH, c.rel * (JSS_NH * 4u), now.h);
         if (fresh) {   // the instance constants of the env travel with it from here on (include/jss_hip.h JSS_C_*)
             const PNorm n = p_norm(c);
             int32_t *cp = p.s.env_const + fe * JSS_NC;
@@ -641,10 +668,7 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
         st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
     if (tab_compact(TAB)) {
         if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
-            const bool one = e.f4 == JSS_F4_ONE;
-            const int4 lo = make_int4((int)((unsigned)e.todo | (e.legal ? JSS_FC_FLAG_LEGAL : 0u) | (e.blocked ? JSS_FC_FLAG_BLOCKED : 0u) |
-                                            (one ? JSS_FC_FLAG_F4_ONE : 0u) | ((unsigned)e.perf << JSS_FC_PERF_SHIFT)),
-                                      (int)((unsigned)e.left | ((unsigned)(one ? 0 : e.f4) << 16)), e.idle, e.idle_last);
+            const int4 lo = now.lo;
             // an unchanged record is not rewritten (steps without a time advance touch few jobs)
             if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w)
                 st_off(p.s.job + fe * jm * JSS_NFC, (c.rel * jm + c.gl) * (JSS_NFC * 4u), lo);
@@ -652,9 +676,7 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
     } else if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
         int32_t *jb = p.s.job + fe * jm * JSS_NF;
         const unsigned jo = (c.rel * jm + c.gl) * 32u;
-        const int4 lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0) |
-                                      (e.nxt2 >= 0 ? (int)((unsigned)e.nxt2 << JSS_NEXT2_SHIFT) : 0), e.cur, e.left, e.perf);
-        const int4 hi = make_int4(e.idle, e.idle_last, e.f4, e.nxt);
+        const int4 lo = now.lo, hi = now.hi;
         // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
         if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
         if (fresh || hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) st_off(jb, jo + 16u, hi);
@@ -664,7 +686,7 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
 // (J,7) float32 observation (jss_env.py:102-111).  Each lane writes its job's row into an LDS
 // image of the wave's E consecutive envs ([E][jmax][7], padding rows zero), which then goes out as
 // one linear copy -- dwordx4 per lane when the wave's block is whole and 16-byte sized.
-template <int G, int TAB>
+template <int G, int TAB, bool WT = false>
 __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, float *dst,
                                             float *scratch, bool wave_whole) {   // dst: block of the wave's first env
     constexpr int E = kWave / G;
@@ -687,10 +709,12 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G, TAB>
     wave_lds_sync();
     const int n = E * row_floats;
     if (wave_whole && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-        for (int i = c.lane; i < (n >> 2); i += kWave)
-            st_nt(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+        for (int i = c.lane; i < (n >> 2); i += kWave) {
+            if (WT) wt_store16(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+            else st_nt(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+        }
     } else if (c.alive) {
-        for (int i = c.gl; i < row_floats; i += G) st_off<float>(dst, (c.rel * row_floats + i) * 4u, mine[i]);
+        for (int i = c.gl; i < row_floats; i += G) st_out<WT, float>(dst, (c.rel * row_floats + i) * 4u, mine[i]);
     }
     wave_lds_sync();
 }
@@ -721,6 +745,37 @@ __device__ __forceinline__ void p_reload_instance(PCtx<G, TAB> &c, const Params 
     wave_lds_sync();
 }
 
+// One jss_step call on the registers: the JSS_ACTION_RESET restart, step(), the header's step count, reward / done /
+// makespan / counters (a skipped env keeps them).  WT = the stores are write-through (step session).  rn = the reward
+// numerator, called = the env was stepped (not skipped, not restarted).  Returns "my env was re-initialised".
+template <int G, int TAB, bool WT>
+__device__ __forceinline__ bool p_step_call(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c, const Params &p, int a_in,
+                                            int32_t *mvtab, int &rn, bool &called) {
+    const size_t fe = (size_t)c.first_env;
+    const bool restart = c.alive && a_in == JSS_ACTION_RESET;           // reset() this env instead of stepping it
+    p_reload_instance(c, p, restart);
+    p_reset<G, TAB, WT>(e, c, p, restart);
+    if (restart) {
+        hd.episode += 1;
+        hd.step = 0;
+        if (c.gl == 0) {
+            st_out<WT, float>(p.o.reward + fe, c.rel * 4u, 0.f);
+            st_out<WT, uint8_t>(p.o.done + fe, c.rel, (uint8_t)0);
+        }
+    }
+    rn = p_step<G, TAB, WT>(e, c, p, a_in, mvtab);
+    called = a_in != JSS_ACTION_SKIP && !restart;
+    const bool done = !grp_any<G>(e.legal, c.gbase);
+    if (called) hd.step += 1;
+    if (c.alive && c.gl == 0 && called) {             // a skipped env keeps its reward / done / makespan
+        st_out<WT, float>(p.o.reward + fe, c.rel * 4u, div_by((float)rn, (float)c.max_time_op, p_norm(c).r_op));   // :483-493
+        st_out<WT, uint8_t>(p.o.done + fe, c.rel, (uint8_t)(done ? 1 : 0));                        // :639-653
+        if (done) st_out<WT, int>(p.o.makespan + fe, c.rel * 4u, e.t);                             // :650
+        if (p.s.counters) add_counters(p.s.counters + (fe + c.rel) * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
+    }
+    return restart;
+}
+
 template <int G, int MODE, int TAB>
 __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c, const Params &p, int a_in, bool selected,
                                        int32_t *mvtab, float *scratch, bool wave_whole) {
@@ -739,27 +794,24 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
             }
         }
     } else if (MODE == kStep) {
-        const bool restart = c.alive && a_in == JSS_ACTION_RESET;       // reset() this env instead of stepping it
-        p_reload_instance(c, p, restart);
-        p_reset(e, c, p, restart);
-        if (restart) {
-            fresh = true;
-            hd.episode += 1;
-            hd.step = 0;
-            if (c.gl == 0) {
-                st_off<float>(p.o.reward + fe, c.rel * 4u, 0.f);
-                st_off<uint8_t>(p.o.done + fe, c.rel, 0);
+        int rn;
+        bool called;
+        fresh = p_step_call<G, TAB, false>(e, hd, c, p, a_in, mvtab, rn, called);
+    } else if (MODE == kSteps) {
+        // n_iter x jss_step with the actions given up front: the state stays in registers, every step optionally recorded
+        for (int it = 0; it < p.n_iter; ++it) {
+            const size_t slot0 = (size_t)it * p.d.batch + fe;            // [it][first env of the wave]
+            const int a = ld_off<int>(p.actions + slot0, c.rel * 4u);
+            int rn;
+            bool called;
+            fresh |= p_step_call<G, TAB, false>(e, hd, c, p, a, mvtab, rn, called);
+            if (p.t.real_obs) p_store_obs<G, TAB>(e, c, p, p.t.real_obs + slot0 * p.d.jmax * 7, scratch, wave_whole);
+            if (p.t.action_mask) p_store_mask<G, TAB>(e, c, p, p.t.action_mask + slot0 * (p.d.jmax + 1));
+            const bool done = !grp_any<G>(e.legal, c.gbase);
+            if (c.alive && c.gl == 0) {
+                if (p.t.reward) p.t.reward[slot0 + c.rel] = called ? div_by((float)rn, (float)c.max_time_op, p_norm(c).r_op) : 0.f;
+                if (p.t.done) p.t.done[slot0 + c.rel] = done ? 1 : 0;
             }
-        }
-        const int rn = p_step(e, c, p, a_in, mvtab);
-        const bool called = a_in != JSS_ACTION_SKIP && !restart;
-        const bool done = !grp_any<G>(e.legal, c.gbase);
-        if (called) hd.step += 1;
-        if (c.alive && c.gl == 0 && called) {         // a skipped env keeps its reward / done / makespan
-            st_off<float>(p.o.reward + fe, c.rel * 4u, div_by((float)rn, (float)c.max_time_op, p_norm(c).r_op));   // :483-493
-            st_off<uint8_t>(p.o.done + fe, c.rel, done ? 1 : 0);                            // :639-653
-            if (done) st_off<int>(p.o.makespan + fe, c.rel * 4u, e.t);                      // :650
-            if (p.s.counters) add_counters(p.s.counters + (fe + c.rel) * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
         }
     } else if (MODE == kAdvance) {
         const bool on = c.alive && selected;
@@ -845,7 +897,7 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
 #define JSS_PACKED_GLOBAL_MIN_BLOCKS 7
 #endif
 template <int G, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, MODE == kTraj ? (TAB == kTabGlobal ? JSS_PTRAJ_GLOBAL_MIN_BLOCKS : JSS_PTRAJ_LDS_MIN_BLOCKS)
+__global__ __launch_bounds__(kBlock, (MODE == kTraj || MODE == kSteps) ? (TAB == kTabGlobal ? JSS_PTRAJ_GLOBAL_MIN_BLOCKS : JSS_PTRAJ_LDS_MIN_BLOCKS)
                                      : MODE == kRollout ? (TAB == kTabGlobal ? 4 : 5)
                                      : ((TAB == kTabGlobal && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
 void jss_packed_kernel(Params p) {
@@ -938,6 +990,252 @@ void jss_packed_kernel(Params p) {
     p_store_mask<G, TAB>(e, c, p, p.o.action_mask + fe * (p.d.jmax + 1));
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
         p_store_obs<G, TAB>(e, c, p, p.o.real_obs + fe * p.d.jmax * 7, scratch, wave_whole);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// The resident step-session kernel (include/jss_hip.h, jss_session_*), packed flavour.
+//
+// A wavefront owns `slots` env sets (E = 64/G envs each): set = wave index + slot * waves in the grid.  With one set
+// the state lives in registers from open to close; with several, each set is parked in LDS between its visits as the
+// records it would be stored as (p_pack / p_unpack: 2 int4 per lane with compact records, 5 with full ones).  A step:
+// wait for the set's action granules (prefetched one (step, set) pair ahead), jss_step's semantics on the registers
+// (p_step_call), outputs write-through, and -- once per step, as late as possible -- the wavefront's progress word
+// behind a drain of those stores.  Nothing of the state touches memory between the loads up front and the stores at
+// the end.  Every wait is bounded by the wall clock.
+// ---------------------------------------------------------------------------------------
+// LDS footprint of one parked env set, in int4: per lane the job record (compact: 1 int4; full: lo, hi and the machine
+// clock), then per env (<= 4 of them) the header and -- per-env tables -- the instance constants
+template <int TAB>
+constexpr int park_lane_int4() { return tab_compact(TAB) ? 1 : 3; }
+template <int TAB>
+constexpr int park_int4() { return park_lane_int4<TAB>() * kWave + 8; }
+
+template <int G, int TAB>
+struct PSlot {            // what distinguishes one env set of the wavefront from another
+    int first_env;
+    bool live, whole;
+};
+
+template <int G, int TAB>
+__device__ __forceinline__ PSlot<G, TAB> p_enter_slot(PCtx<G, TAB> &c, const Params &p, int32_t *lds, int wave, int gw,
+                                                      int n_waves, int slot) {
+    constexpr int E = kWave / G;
+    PSlot<G, TAB> sl;
+    sl.first_env = (gw + slot * n_waves) * E;                            // wave-uniform
+    sl.live = sl.first_env < p.d.batch;
+    sl.whole = sl.first_env + E <= p.d.batch;
+    c.first_env = sl.live ? sl.first_env : 0;
+    const int e_in_wave = c.lane / G;
+    c.alive = sl.live && sl.first_env + e_in_wave < p.d.batch;
+    c.rel = (unsigned)(c.alive ? e_in_wave : (sl.live ? p.d.batch - 1 - sl.first_env : 0));
+    c.norm = lds + p.norm_off_ints + slot * p.norm_slot_ints + wave * kWave + c.gbase;
+    return sl;
+}
+
+template <int G, int TAB>
+__device__ __forceinline__ void p_park(int4 *park, int slot, int lane, const PRaw<G> &r, const PCtx<G, TAB> &c) {
+    int4 *q = park + (size_t)slot * park_int4<TAB>();
+    q[lane] = r.lo;
+    if (!tab_compact(TAB)) {
+        q[kWave + lane] = r.hi;
+        q[2 * kWave + lane] = make_int4(r.tm, 0, 0, 0);
+    }
+    if (c.gl == 0) {                                   // per env: its header, its instance constants
+        int4 *g = q + park_lane_int4<TAB>() * kWave + 2 * (lane / G);
+        g[0] = r.h;
+        if (TAB == kTabGlobal) g[1] = make_int4(c.J, c.M, c.max_time_op, c.tid);
+    }
+    wave_lds_sync();                                   // the group's lanes read what its lane 0 wrote
+}
+template <int G, int TAB>
+__device__ __forceinline__ PRaw<G> p_unpark(const int4 *park, int slot, int lane, PCtx<G, TAB> &c) {
+    const int4 *q = park + (size_t)slot * park_int4<TAB>();
+    const int4 *g = q + park_lane_int4<TAB>() * kWave + 2 * (lane / G);
+    PRaw<G> r;
+    r.h = g[0];
+    r.lo = q[lane];
+    r.hi = make_int4(0, 0, 0, 0);
+    r.tm = 0;
+    if (!tab_compact(TAB)) {
+        r.hi = q[kWave + lane];
+        r.tm = q[2 * kWave + lane].x;
+    }
+    if (TAB == kTabGlobal) {                           // the set's instance constants (an env's restart may change them)
+        const int4 k = g[1];
+        c.J = k.x;
+        c.M = k.y;
+        c.max_time_op = k.z;
+        c.tid = k.w;
+        c.jvalid = c.gl < c.J;
+        c.mvalid = c.gl < c.M;
+    }
+    return r;
+}
+
+template <int G, int TAB>
+__global__ __launch_bounds__(kBlock, 6) void jss_packed_session_kernel(Params p) {
+    HIP_DYNAMIC_SHARED(int32_t, lds)
+    constexpr int E = kWave / G;
+    constexpr int MODE = kSession;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;
+    int32_t *mvtab = lds + p.mv_off_ints + wave * kWave;
+    const int slots = p.slots;
+    int4 *park = reinterpret_cast<int4 *>(lds + p.park_off_ints) + (size_t)wave * slots * park_int4<TAB>();
+    const int n_waves = (int)gridDim.x * kWavesPerBlock;
+    const int gw = (int)blockIdx.x * kWavesPerBlock + wave;
+
+    PCtx<G, TAB> c;
+    c.lane = lane;
+    c.gl = lane & (G - 1);
+    c.gbase = lane & ~(G - 1);
+    c.tid = 0;
+    c.lds_row = lds + (c.gl < p.d.jmax ? c.gl : 0) * p.d.mmax;
+    if (tab_in_lds(TAB)) {
+        stage_shared_table(lds, p.d.ops, p.d.jmax * p.d.mmax, (int)threadIdx.x);
+        __syncthreads();
+        const int32_t *ir = p.d.inst;
+        c.J = ir[JSS_I_JOBS];
+        c.M = ir[JSS_I_MACHINES];
+        c.max_time_op = ir[JSS_I_MAX_TIME_OP];
+        c.max_time_jobs = ir[JSS_I_MAX_TIME_JOBS];
+        c.sum_op = ir[JSS_I_SUM_OP];
+        c.r_op = as_float(ir[JSS_I_RCP_MAX_TIME_OP]);
+        c.r_jobs = as_float(ir[JSS_I_RCP_MAX_TIME_JOBS]);
+        c.r_sum = as_float(ir[JSS_I_RCP_SUM_OP]);
+        c.r_m = as_float(ir[JSS_I_RCP_MACHINES]);
+        c.jvalid = c.gl < c.J;
+        c.mvalid = c.gl < c.M;
+    }
+    if (gw * E >= p.d.batch) return;                 // a wavefront without a single env set (only in the last workgroup)
+    if (gw == 0 && lane == 0) wt_store(p.status + 3, slots);
+
+    PEnv<G> e;
+    PHeader hd;
+    bool never = false;                               // my env was never reset: the session leaves it alone
+    // ---- the state of every env set of this wavefront: loaded once ----
+    for (int slot = 0; slot < slots; ++slot) {
+        const PSlot<G, TAB> sl = p_enter_slot(c, p, lds, wave, gw, n_waves, slot);
+        if (!sl.live) break;
+        const size_t fe = (size_t)c.first_env;
+        PRaw<G> raw = p_issue_loads<G, TAB>(c, p);
+        if (TAB == kTabGlobal) {
+            const int4 hx = ld_off<int4>(p.s.env_const + fe * JSS_NC, c.rel * (JSS_NC * 4u));
+            if (c.gl < 6) c.norm[c.gl] = ld_off<int>(p.s.env_const + fe * JSS_NC, c.rel * (JSS_NC * 4u) + 16u + (unsigned)c.gl * 4u);
+            c.J = hx.x;
+            c.M = hx.y;
+            c.max_time_op = hx.z;
+            c.tid = hx.w;
+            c.jvalid = c.gl < c.J;
+            c.mvalid = c.gl < c.M;
+            wave_lds_sync();
+        }
+        if (slots > 1) p_park(park, slot, lane, raw, c);
+        else {
+            hd = p_unpack(e, c, raw, mvtab);
+            never = hd.episode == 0;
+        }
+    }
+
+    // ---- step after step ----
+    const unsigned long long *mail = p.mail;
+    const size_t B = (size_t)p.d.batch;
+    auto granule = [&](int step, int slot) -> const unsigned long long * {     // my env's granule of (step, slot)
+        const int fe = (gw + slot * n_waves) * E;
+        const int live = fe < p.d.batch;
+        int env = fe + lane / G;
+        if (!live || env >= p.d.batch) env = live ? p.d.batch - 1 : 0;          // dead lanes poll a neighbour's word
+        return mail + (size_t)(step % p.depth) * B + env;
+    };
+    int my_slots = 0;
+    for (int slot = 0; slot < slots; ++slot) my_slots += (gw + slot * n_waves) * E < p.d.batch ? 1 : 0;
+    int step = 0;
+    int pending = 0;                                  // steps finished whose progress word is not out yet (value to publish)
+    bool closing = false, timed_out = false;
+    unsigned long long x = fresh_load(granule(0, 0));
+    while (!closing) {
+        for (int slot = 0; slot < my_slots; ++slot) {
+            // the next (step, set) pair's granule is requested before this pair is waited for and computed
+            const int nslot = slot + 1 < my_slots ? slot + 1 : 0;
+            const int nstep = step + (nslot == 0 ? 1 : 0);
+            unsigned long long xn = fresh_load(granule(nstep, nslot));
+            const unsigned want = (unsigned)step + 1u;
+            long long t0 = 0;
+            unsigned spins = 0;
+            while (__ballot((unsigned)(x >> 32) != want) != 0) {
+                if (pending) {                        // nothing to do anyway: publish the finished step now
+                    wt_drain();
+                    if (lane == 0) wt_store(p.progress + gw, pending);
+                    pending = 0;
+                }
+                if (spins < 32u) __builtin_amdgcn_s_sleep(2);       // a few quick looks, then back off: thousands of wavefronts
+                else __builtin_amdgcn_s_sleep(16);                  // polling flat out would flood the fabric
+                if ((++spins & 63u) == 0) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > p.timeout_ticks) {
+                        timed_out = true;
+                        break;
+                    }
+                }
+                x = fresh_load(granule(step, slot));
+            }
+            const int a = (int)(unsigned)x;           // group-uniform: every lane of a group reads its env's granule
+            if (timed_out || __ballot(a == JSS_ACTION_CLOSE) != 0) {
+                closing = true;
+                break;
+            }
+            const PSlot<G, TAB> sl = p_enter_slot(c, p, lds, wave, gw, n_waves, slot);
+            if (slots > 1) {
+                const PRaw<G> raw = p_unpark(park, slot, lane, c);
+                hd = p_unpack(e, c, raw, mvtab);
+                never = hd.episode == 0;
+            }
+            if (never) c.alive = false;
+            int rn;
+            bool called;
+            p_step_call<G, TAB, true>(e, hd, c, p, a, mvtab, rn, called);
+            if (pending) {                            // the previous step's stores have had this step's compute to drain
+                wt_drain();
+                if (lane == 0) wt_store(p.progress + gw, pending);
+                pending = 0;
+            }
+            const size_t fe = (size_t)c.first_env;
+            p_store_mask<G, TAB, true>(e, c, p, p.o.action_mask + fe * (p.d.jmax + 1));
+            p_store_obs<G, TAB, true>(e, c, p, p.o.real_obs + fe * p.d.jmax * 7, scratch, sl.whole);
+            if (slots > 1) p_park(park, slot, lane, p_pack(e, c, hd), c);
+            x = xn;
+        }
+        if (!closing) {
+            ++step;
+            pending = step;
+        }
+    }
+    if (pending) {
+        wt_drain();
+        if (lane == 0) wt_store(p.progress + gw, pending);
+    }
+    // ---- the state goes back to memory (every row: nothing was loaded to compare with) ----
+    for (int slot = 0; slot < my_slots; ++slot) {
+        p_enter_slot(c, p, lds, wave, gw, n_waves, slot);
+        PRaw<G> raw;
+        raw.h = raw.lo = raw.hi = make_int4(0, 0, 0, 0);
+        raw.tm = 0;
+        if (slots > 1) {
+            raw = p_unpark(park, slot, lane, c);
+            hd = p_unpack(e, c, raw, mvtab);
+            never = hd.episode == 0;
+        }
+        if (never) c.alive = false;
+        p_store(e, c, p, hd, raw, true);
+    }
+    if (lane == 0) {
+        if (timed_out) atomicAdd(p.status + 0, 1);
+        atomicAdd(p.status + 2, 1);
+    }
+    (void)MODE;
 }
 
 }  // namespace jss

@@ -81,7 +81,7 @@ __device__ __forceinline__ void settle(Env<JPL> &e) {
 // ---------------------------------------------------------------------------------------
 // reset(): jss_env.py:145-181
 // ---------------------------------------------------------------------------------------
-template <int JPL>
+template <int JPL, bool WT = false>
 __device__ __forceinline__ void reset_env(Env<JPL> &e, const Ctx &c, const Params &p) {
     e.t = 0;                                                             // :154
     e.tm = 0;                                                            // :164
@@ -105,7 +105,7 @@ __device__ __forceinline__ void reset_env(Env<JPL> &e, const Ctx &c, const Param
     // that nothing of a previous, larger instance of this env survives a reset)
     int32_t *sol = p.s.solution + (size_t)c.b * p.d.jmax * p.d.mmax;
     const int n = p.d.jmax * p.d.mmax;
-    for (int i = c.lane; i < n; i += kWave) st_off<int>(sol, (unsigned)i * 4u, -1);
+    for (int i = c.lane; i < n; i += kWave) st_out<WT, int>(sol, (unsigned)i * 4u, -1);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -416,7 +416,7 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
 // step(): jss_env.py:403-481.  `a` is wave-uniform.  Returns the reward numerator
 // (reward * max_time_op, an exact integer: scheduled duration minus idle-machine time).
 // ---------------------------------------------------------------------------------------
-template <int JPL>
+template <int JPL, bool WT = false>
 __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params &p, int a) {
     if (a == JSS_ACTION_SKIP || a == JSS_ACTION_RESET) return 0;         // RESET is handled by the caller
     if (a < 0 || a > c.J) {
@@ -448,7 +448,7 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
 #pragma unroll
         for (int s = 0; s < JPL; ++s)
             if (s == sa && c.lane == la) e.left[s] = d;                  // :447
-        if (c.lane == 0) p.s.solution[((size_t)c.b * p.d.jmax + a) * p.d.mmax + k] = e.t;  // :454
+        if (c.lane == 0) st_out<WT, int>(p.s.solution + ((size_t)c.b * p.d.jmax + a) * p.d.mmax + k, 0u, e.t);  // :454
 #pragma unroll
         for (int s = 0; s < JPL; ++s) {
             const uint64_t same = __ballot(e.cur[s] >= 0 && (e.cur[s] >> 16) == m);   // padding lanes hold cur = -1
@@ -659,15 +659,38 @@ __device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawE
 }
 
 // action mask row: legal jobs, the NOPE flag at index J, zeros behind it
-template <int JPL>
+template <int JPL, bool WT = false>
 __device__ __forceinline__ void store_mask(const Env<JPL> &e, const Ctx &c, uint8_t *mk, int jm) {
-    if (c.lane == 0) st_off<uint8_t>(mk, (unsigned)jm, (uint8_t)(c.J == jm ? e.noop : 0));   // last byte of the row
+    if (c.lane == 0) st_out<WT, uint8_t>(mk, (unsigned)jm, (uint8_t)(c.J == jm ? e.noop : 0));   // last byte of the row
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         const int lg = (int)((e.legal[s] >> c.lane) & 1);
-        if (j < jm) st_off<uint8_t>(mk, (unsigned)j, (uint8_t)(j < c.J ? lg : (j == c.J ? e.noop : 0)));
+        if (j < jm) st_out<WT, uint8_t>(mk, (unsigned)j, (uint8_t)(j < c.J ? lg : (j == c.J ? e.noop : 0)));
     }
+}
+
+// The record words of my jobs as they are stored (the inverse of unpack_env)
+template <int JPL, int TAB>
+__device__ __forceinline__ RawEnv<JPL> pack_env(const Env<JPL> &e, const Ctx &c) {
+    RawEnv<JPL> r;
+    r.tm = e.tm;
+#pragma unroll
+    for (int s = 0; s < JPL; ++s) {
+        const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = e.blocked[s] ? 1 : 0;
+        if (tab_compact(TAB)) {
+            const bool one = e.f4[s] == JSS_F4_ONE;
+            r.lo[s] = make_int4((int)((unsigned)e.todo[s] | (lg ? JSS_FC_FLAG_LEGAL : 0u) | (bl ? JSS_FC_FLAG_BLOCKED : 0u) |
+                                      (one ? JSS_FC_FLAG_F4_ONE : 0u) | ((unsigned)e.perf[s] << JSS_FC_PERF_SHIFT)),
+                                (int)((unsigned)e.left[s] | ((unsigned)(one ? 0 : e.f4[s]) << 16)), e.idle[s], e.idle_last[s]);
+            r.hi[s] = make_int4(0, 0, 0, 0);
+        } else {
+            r.lo[s] = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0) |
+                                    (e.nxt2[s] >= 0 ? (int)((unsigned)e.nxt2[s] << JSS_NEXT2_SHIFT) : 0), e.cur[s], e.left[s], e.perf[s]);
+            r.hi[s] = make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]);
+        }
+    }
+    return r;
 }
 
 // State back to HBM.  all_rows = the env was (re)initialised: every row of the padded block is written (rows behind
@@ -694,23 +717,17 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
     } else if (c.lane < c.M && e.tm != raw.tm) {                         // idle machines stay 0
         st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
     }
+    const RawEnv<JPL> now = pack_env<JPL, TAB>(e, c);
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
-        const int lg = (int)((e.legal[s] >> c.lane) & 1), bl = e.blocked[s] ? 1 : 0;
+        const int4 lo = now.lo[s], hi = now.hi[s];
         if (tab_compact(TAB)) {
             const unsigned jo = (unsigned)j * (JSS_NFC * 4u);
-            const bool one = e.f4[s] == JSS_F4_ONE;
-            const int4 lo = make_int4((int)((unsigned)e.todo[s] | (lg ? JSS_FC_FLAG_LEGAL : 0u) | (bl ? JSS_FC_FLAG_BLOCKED : 0u) |
-                                            (one ? JSS_FC_FLAG_F4_ONE : 0u) | ((unsigned)e.perf[s] << JSS_FC_PERF_SHIFT)),
-                                      (int)((unsigned)e.left[s] | ((unsigned)(one ? 0 : e.f4[s]) << 16)), e.idle[s], e.idle_last[s]);
             const int4 lo0 = raw.lo[s];
             if (all_rows ? j < jm : (j < c.J && (lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w))) st_off<int4>(jb, jo, lo);
             continue;
         }
-        const int4 lo = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0) |
-                                      (e.nxt2[s] >= 0 ? (int)((unsigned)e.nxt2[s] << JSS_NEXT2_SHIFT) : 0), e.cur[s], e.left[s], e.perf[s]);
-        const int4 hi = make_int4(e.idle[s], e.idle_last[s], e.f4[s], e.nxt[s]);
         if (all_rows) {
             if (j < jm) {
                 st_off<int4>(jb, (unsigned)j * 32u, lo);
@@ -730,7 +747,7 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
 // shifted by the block's misalignment so that 16-byte lines of the image are 16-byte lines of the destination
 // (a 50-job block is 1400 bytes: every other env starts 8 bytes past a line) and everything but the first and
 // last line leaves as streaming dwordx4 stores.
-template <int JPL>
+template <int JPL, bool WT = false>
 __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, float *dst, float *scratch, int rows) {
     // rows = jmax when the env is (re)initialised by a reset call, J(env) otherwise: the rows behind J are zeros
     // from that reset on and nothing ever changes them, so a step does not rewrite them (ragged, padded batches)
@@ -758,11 +775,13 @@ __device__ __forceinline__ void store_obs(const Env<JPL> &e, const Ctx &c, float
     // whole 16-byte lines [i0, i1) as streaming dwordx4 stores (whole lines, never read back: see st_nt); the <= 3
     // floats in front of the first line and behind the last one as single dwords
     const int i0 = (sh + 3) >> 2, i1 = end >> 2;
-    for (int i = i0 + c.lane; i < i1; i += kWave)
-        st_nt(dst0, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+    for (int i = i0 + c.lane; i < i1; i += kWave) {
+        if (WT) wt_store16(dst0, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+        else st_nt(dst0, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
+    }
     const int head_end = imin(i0 << 2, end), tail_begin = imax(i1 << 2, head_end);
-    if (sh + c.lane < head_end) st_off<float>(dst0, (unsigned)(sh + c.lane) * 4u, scratch[sh + c.lane]);
-    if (tail_begin + c.lane < end) st_off<float>(dst0, (unsigned)(tail_begin + c.lane) * 4u, scratch[tail_begin + c.lane]);
+    if (sh + c.lane < head_end) st_out<WT, float>(dst0, (unsigned)(sh + c.lane) * 4u, scratch[sh + c.lane]);
+    if (tail_begin + c.lane < end) st_out<WT, float>(dst0, (unsigned)(tail_begin + c.lane) * 4u, scratch[tail_begin + c.lane]);
     wave_lds_sync();
 }
 
@@ -831,6 +850,40 @@ __device__ __forceinline__ void ctx_from_header(Ctx &c, const HeaderWords &h) {
     c.r_m = as_float(in_vgpr(__builtin_amdgcn_readfirstlane(h.r_m)));
 }
 
+// One jss_step call on the registers: the JSS_ACTION_RESET restart, step(), the header's step count, reward / done /
+// makespan / counters (a skipped env keeps them).  WT = the stores are write-through (step session).  rn = the reward
+// numerator, called = the env was stepped (not skipped, not restarted).  Returns "the env was re-initialised".
+template <int JPL, int TAB, bool WT>
+__device__ __forceinline__ bool step_call(Env<JPL> &e, Header &hd, Ctx &c, const Params &p, const int32_t *lds, int a_in,
+                                          int &rn, bool &called) {
+    const int b = c.b;
+    const bool restart = a_in == JSS_ACTION_RESET;                       // reset() this env instead of stepping it
+    if (restart) {
+        // the env may have been given another instance since its last reset (table_of_env)
+        const int tid = tab_in_lds(TAB) ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : c.tid);
+        ctx_from_instance(c, p, tid);
+        ctx_table<TAB>(c, p, lds);
+        hd.episode += 1;
+        hd.step = 0;
+        reset_env<JPL, WT>(e, c, p);
+        if (c.lane == 0) {
+            st_out<WT, float>(p.o.reward + b, 0u, 0.f);
+            st_out<WT, uint8_t>(p.o.done + b, 0u, (uint8_t)0);
+        }
+    }
+    rn = step_env<JPL, WT>(e, c, p, a_in);
+    called = a_in != JSS_ACTION_SKIP && !restart;
+    const bool done = !any_legal(e);
+    if (called) hd.step += 1;
+    if (c.lane == 0 && called) {                                         // a skipped env keeps its reward / done / makespan
+        st_out<WT, float>(p.o.reward + b, 0u, reward_of(rn, c));         // :483-493 (0 for ignored actions)
+        st_out<WT, uint8_t>(p.o.done + b, 0u, (uint8_t)(done ? 1 : 0));  // :639-653
+        if (done) st_out<WT, int>(p.o.makespan + b, 0u, e.t);            // last_time_step :650
+        if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
+    }
+    return restart;
+}
+
 // ---------------------------------------------------------------------------------------
 // one env, one mode: everything behind "the header words are on their way"
 // ---------------------------------------------------------------------------------------
@@ -869,30 +922,23 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
     }
 
     if (MODE == kStep) {
-        const bool restart = a_in == JSS_ACTION_RESET;                   // reset() this env instead of stepping it
-        if (restart) {
-            // the env may have been given another instance since its last reset (table_of_env)
-            const int tid = tab_in_lds(TAB) ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : c.tid);
-            ctx_from_instance(c, p, tid);
-            ctx_table<TAB>(c, p, lds);
-            hd.episode += 1;
-            hd.step = 0;
-            reset_env(e, c, p);
-            fresh = true;
+        int rn;
+        bool called;
+        fresh = step_call<JPL, TAB, false>(e, hd, c, p, lds, a_in, rn, called);
+    } else if (MODE == kSteps) {
+        // n_iter x jss_step with the actions given up front: the state stays in registers, every step optionally recorded
+        for (int it = 0; it < p.n_iter; ++it) {
+            const size_t slot = (size_t)it * p.d.batch + b;              // [it][b]
+            const int a = __builtin_amdgcn_readfirstlane(p.actions[slot]);
+            int rn;
+            bool called;
+            fresh |= step_call<JPL, TAB, false>(e, hd, c, p, lds, a, rn, called);
+            if (p.t.real_obs) store_obs(e, c, p.t.real_obs + slot * p.d.jmax * 7, scratch, c.J);
+            if (p.t.action_mask) store_mask(e, c, p.t.action_mask + slot * (p.d.jmax + 1), p.d.jmax);
             if (lane == 0) {
-                p.o.reward[b] = 0.f;
-                p.o.done[b] = 0;
+                if (p.t.reward) p.t.reward[slot] = called ? reward_of(rn, c) : 0.f;
+                if (p.t.done) p.t.done[slot] = any_legal(e) ? 0 : 1;
             }
-        }
-        const int rn = step_env(e, c, p, a_in);
-        const bool called = a_in != JSS_ACTION_SKIP && !restart;
-        const bool done = !any_legal(e);
-        if (called) hd.step += 1;
-        if (lane == 0 && called) {                                       // a skipped env keeps its reward / done / makespan
-            p.o.reward[b] = reward_of(rn, c);                            // :483-493 (0 for ignored actions)
-            p.o.done[b] = done ? 1 : 0;                                  // :639-653
-            if (done) p.o.makespan[b] = e.t;                             // last_time_step :650
-            if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
         }
     } else if (MODE == kAdvance) {
         int hole = 0;
@@ -988,6 +1034,7 @@ constexpr int wave_min_blocks(int jpl, int mode) {
     return mode == kTraj ? (jpl == 2 ? JSS_TRAJ2_MIN_BLOCKS : JSS_TRAJ1_MIN_BLOCKS)
          : mode == kRollout ? (jpl == 2 ? 5 : 7)
          : mode == kStep ? (jpl == 2 ? 5 : 8)
+         : mode == kSteps ? (jpl == 2 ? 4 : 6)
          : mode == kRollout1 ? (jpl == 2 ? JSS_WAVE2_MIN_BLOCKS : JSS_WAVE_MIN_BLOCKS)
          : (jpl == 2 ? 7 : 8);
 }
@@ -1023,10 +1070,192 @@ __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel
     } else {
         // (a restart may hand the env a wider instance: it takes the full-width body)
         // (J == 64 stays on the full-width body: the NOPE flag of its mask row lives at index 64, slot 1's first lane)
-        if (JPL == 2 && ragged && !(MODE == kStep && a_in == JSS_ACTION_RESET) && __builtin_amdgcn_readfirstlane(h.J) < kWave)
+        if (JPL == 2 && ragged && MODE != kSteps && !(MODE == kStep && a_in == JSS_ACTION_RESET) && __builtin_amdgcn_readfirstlane(h.J) < kWave)
             wave_main<1, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
         else
             wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// The resident step-session kernel (include/jss_hip.h, jss_session_*), one wavefront per env.  Same protocol as
+// jss_packed_session_kernel (jss_packed_env.hpp): a wavefront owns `slots` envs (env = wave index + slot * waves in
+// the grid); with one env the state lives in registers from open to close, with several each env is parked in LDS
+// between its visits as the records it would be stored as (pack_env / unpack_env) plus its header words.
+// ---------------------------------------------------------------------------------------
+// LDS footprint of one parked env, in int4: the job records per lane, the machine clocks (one int per lane), the header
+template <int JPL, int TAB>
+constexpr int wave_park_rows() { return tab_compact(TAB) ? JPL : 2 * JPL; }
+template <int JPL, int TAB>
+constexpr int wave_park_int4() { return wave_park_rows<JPL, TAB>() * kWave + kWave / 4 + 1; }
+
+template <int JPL, int TAB>
+__device__ __forceinline__ void park_env(int4 *park, int slot, int lane, const RawEnv<JPL> &r, int clock, int episode, int step, int status) {
+    int4 *q = park + (size_t)slot * wave_park_int4<JPL, TAB>();
+    int k = 0;
+#pragma unroll
+    for (int s = 0; s < JPL; ++s) {
+        q[(k++) * kWave + lane] = r.lo[s];
+        if (!tab_compact(TAB)) q[(k++) * kWave + lane] = r.hi[s];
+    }
+    int4 *t = q + wave_park_rows<JPL, TAB>() * kWave;
+    reinterpret_cast<int *>(t)[lane] = r.tm;
+    if (lane == 0) t[kWave / 4] = make_int4(clock, episode, step, status);
+}
+template <int JPL, int TAB>
+__device__ __forceinline__ RawEnv<JPL> unpark_env(const int4 *park, int slot, int lane, int &clock, int &episode, int &step, int &status) {
+    const int4 *q = park + (size_t)slot * wave_park_int4<JPL, TAB>();
+    RawEnv<JPL> r;
+    int k = 0;
+#pragma unroll
+    for (int s = 0; s < JPL; ++s) {
+        r.lo[s] = q[(k++) * kWave + lane];
+        r.hi[s] = make_int4(0, 0, 0, 0);
+        if (!tab_compact(TAB)) r.hi[s] = q[(k++) * kWave + lane];
+    }
+    const int4 *t = q + wave_park_rows<JPL, TAB>() * kWave;
+    r.tm = reinterpret_cast<const int *>(t)[lane];
+    const int4 w = t[kWave / 4];
+    clock = __builtin_amdgcn_readfirstlane(w.x);
+    episode = __builtin_amdgcn_readfirstlane(w.y);
+    step = __builtin_amdgcn_readfirstlane(w.z);
+    status = __builtin_amdgcn_readfirstlane(w.w);
+    return r;
+}
+
+template <int JPL, int TAB>
+__global__ __launch_bounds__(kBlock, JPL == 1 ? 6 : 4) void jss_session_kernel(Params p) {
+    HIP_DYNAMIC_SHARED(int32_t, lds)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;
+    const int slots = p.slots;
+    int4 *park = reinterpret_cast<int4 *>(lds + p.park_off_ints) + (size_t)wave * slots * wave_park_int4<JPL, TAB>();
+    const int n_waves = (int)gridDim.x * kWavesPerBlock;
+    const int gw = (int)blockIdx.x * kWavesPerBlock + wave;
+    if (tab_in_lds(TAB)) {
+        stage_shared_table(lds, p.d.ops, p.d.jmax * p.d.mmax, (int)threadIdx.x);
+        __syncthreads();
+    }
+    if (gw >= p.d.batch) return;
+    if (gw == 0 && lane == 0) wt_store(p.status + 3, slots);
+    const bool ragged = p.d.jmin > 0 && p.d.jmin < p.d.jmax;
+    int my_slots = 0;
+    for (int slot = 0; slot < slots; ++slot) my_slots += gw + slot * n_waves < p.d.batch ? 1 : 0;
+
+    Ctx c;
+    c.lane = lane;
+    Env<JPL> e;
+    Header hd;
+    hd.episode = hd.step = 0;
+    // the env's constants record is read-only while the session is open: it is re-read (scalar loads, cached) at every
+    // visit of a parked env; the header words travel with the parked records
+    auto enter = [&](int slot) {
+        c.b = gw + slot * n_waves;
+        const HeaderWords h = load_header(p, c.b);
+        ctx_from_header(c, h);
+        ctx_table<TAB>(c, p, lds);
+        return h;
+    };
+    // ---- the state of every env of this wavefront: loaded once ----
+    for (int slot = 0; slot < my_slots; ++slot) {
+        const HeaderWords h = enter(slot);
+        const RawEnv<JPL> raw = issue_loads<JPL, TAB>(c.b, lane, p, ragged ? c.J : p.d.jmax);
+        const int clock = __builtin_amdgcn_readfirstlane(h.clock), status = __builtin_amdgcn_readfirstlane(h.status);
+        hd.episode = __builtin_amdgcn_readfirstlane(h.episode);
+        hd.step = __builtin_amdgcn_readfirstlane(h.step);
+        if (slots > 1) park_env<JPL, TAB>(park, slot, lane, raw, clock, hd.episode, hd.step, status);
+        else unpack_env<JPL, TAB>(e, c, raw, clock, status, reinterpret_cast<int32_t *>(scratch));
+    }
+    if (slots > 1) wave_lds_sync();
+
+    // ---- step after step ----
+    const size_t B = (size_t)p.d.batch;
+    auto granule = [&](int step, int slot) -> const unsigned long long * {
+        return p.mail + (size_t)(step % p.depth) * B + (gw + slot * n_waves);
+    };
+    int step = 0, pending = 0;
+    bool closing = false, timed_out = false;
+    unsigned long long x = fresh_load(granule(0, 0));
+    while (!closing) {
+        for (int slot = 0; slot < my_slots; ++slot) {
+            const int nslot = slot + 1 < my_slots ? slot + 1 : 0;
+            const int nstep = step + (nslot == 0 ? 1 : 0);
+            const unsigned long long xn = fresh_load(granule(nstep, nslot));   // the next (step, env) pair's granule
+            const unsigned want = (unsigned)step + 1u;
+            long long t0 = 0;
+            unsigned spins = 0;
+            while ((unsigned)(__builtin_amdgcn_readfirstlane((int)(x >> 32))) != want) {
+                if (pending) {
+                    wt_drain();
+                    if (lane == 0) wt_store(p.progress + gw, pending);
+                    pending = 0;
+                }
+                if (spins < 32u) __builtin_amdgcn_s_sleep(2);       // a few quick looks, then back off: thousands of wavefronts
+                else __builtin_amdgcn_s_sleep(16);                  // polling flat out would flood the fabric
+                if ((++spins & 63u) == 0) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > p.timeout_ticks) {
+                        timed_out = true;
+                        break;
+                    }
+                }
+                x = fresh_load(granule(step, slot));
+            }
+            const int a = __builtin_amdgcn_readfirstlane((int)(unsigned)x);
+            if (timed_out || a == JSS_ACTION_CLOSE) {
+                closing = true;
+                break;
+            }
+            if (slots > 1) {
+                enter(slot);
+                int clock, status;
+                const RawEnv<JPL> raw = unpark_env<JPL, TAB>(park, slot, lane, clock, hd.episode, hd.step, status);
+                unpack_env<JPL, TAB>(e, c, raw, clock, status, reinterpret_cast<int32_t *>(scratch));
+            }
+            if (c.J != 0) {                           // (J == 0: the env was never reset -- the session leaves it alone)
+                int rn;
+                bool called;
+                const bool fresh = step_call<JPL, TAB, true>(e, hd, c, p, lds, a, rn, called);
+                if (pending) {                        // the previous step's stores have had this step's compute to drain
+                    wt_drain();
+                    if (lane == 0) wt_store(p.progress + gw, pending);
+                    pending = 0;
+                }
+                store_mask<JPL, true>(e, c, p.o.action_mask + (size_t)c.b * (p.d.jmax + 1), p.d.jmax);
+                store_obs<JPL, true>(e, c, p.o.real_obs + (size_t)c.b * p.d.jmax * 7, scratch, fresh ? p.d.jmax : c.J);
+            }
+            if (slots > 1) {
+                park_env<JPL, TAB>(park, slot, lane, pack_env<JPL, TAB>(e, c), e.t, hd.episode, hd.step,
+                                   (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
+                wave_lds_sync();
+            }
+            x = xn;
+        }
+        if (!closing) {
+            ++step;
+            pending = step;
+        }
+    }
+    if (pending) {
+        wt_drain();
+        if (lane == 0) wt_store(p.progress + gw, pending);
+    }
+    // ---- the state goes back to memory (every row: nothing was kept to compare with) ----
+    for (int slot = 0; slot < my_slots; ++slot) {
+        if (slots > 1) {
+            enter(slot);
+            int clock, status;
+            const RawEnv<JPL> raw = unpark_env<JPL, TAB>(park, slot, lane, clock, hd.episode, hd.step, status);
+            unpack_env<JPL, TAB>(e, c, raw, clock, status, reinterpret_cast<int32_t *>(scratch));
+        }
+        if (c.J != 0) store_env<JPL, TAB>(e, c, p, hd, blank_raw<JPL, TAB>(), true);
+    }
+    if (lane == 0) {
+        if (timed_out) atomicAdd(p.status + 0, 1);
+        atomicAdd(p.status + 2, 1);
     }
 }
 

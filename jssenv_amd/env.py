@@ -401,6 +401,7 @@ class BatchedJssEnv:
                                     p(self.counters))
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
         self._is_reset = False
+        self._session = None                                     # an open StepSession: every other call raises meanwhile
 
     def assign_instances(self, env_indices, table_indices):
         """Give envs ``env_indices`` the instances ``table_indices`` (indices into the ``instances`` this batch
@@ -458,6 +459,8 @@ class BatchedJssEnv:
         return w
 
     def _refs(self):
+        if self._session is not None and not self._session.closed:
+            raise RuntimeError("a step session is open on this env: the state is resident in its kernel -- close() it first")
         return C.byref(self._desc), C.byref(self._state), C.byref(self._out)
 
     # -- API -----------------------------------------------------------------------------
@@ -627,6 +630,42 @@ class BatchedJssEnv:
                        "jss_trajectory")
         return out
 
+    def steps(self, actions, record=(), buffers: Optional[dict] = None):
+        """K consecutive ``step()`` calls per env in ONE launch (``jss_steps``): ``actions`` is a (K, B) int32 array of
+        action codes as ``step`` takes them (job, J = NOPE, -1 = skip, -2 = reset) -- a recorded trace, a planned
+        open-loop sequence.  The state is read and written once.  ``record`` names the per-step streams to keep,
+        step-major: ``real_obs`` (K, B, J, 7) and ``action_mask`` (K, B, J + 1) AFTER each step, ``reward`` / ``done``
+        (K, B).  Returns the dict of recorded buffers (reusable through ``buffers``); the env's own outputs hold the
+        last step."""
+        if not self._is_reset:
+            raise RuntimeError("call reset() before steps()")
+        be = self.backend
+        shape = tuple(actions.shape)
+        if len(shape) != 2 or shape[1] != self.batch:
+            raise ValueError(f"expected actions of shape (K, {self.batch}), got {shape}")
+        K, B, J = shape[0], self.batch, self.jmax
+        shapes = {"real_obs": ((K, B, J, 7), "float32"), "action_mask": ((K, B, J + 1), "uint8"),
+                  "reward": ((K, B), "float32"), "done": ((K, B), "uint8")}
+        out = {}
+        with be.on_device():
+            a = be.as_device(actions, "int32")
+            for name in record:
+                shp, dtype = shapes[name]
+                t = None if buffers is None else buffers.get(name)
+                out[name] = t if t is not None and tuple(t.shape) == shp else be.zeros(shp, dtype)
+            traj = _abi.JssTraj(be.ptr(out.get("real_obs")), be.ptr(out.get("action_mask")), None, be.ptr(out.get("reward")),
+                                be.ptr(out.get("done")))
+            d, s, o = self._refs()
+            _abi.check(be.lib, be.lib.jss_steps(d, s, o, C.byref(traj), be.ptr(a), K, be.stream()), "jss_steps")
+        self._steps_keep = a                  # alive until the launch has read it
+        return out
+
+    def session(self, depth: int = 16, timeout_ms: int = 2000, slots: int = 0):
+        """Open a step session (``jssenv_amd.session.StepSession``): the env state stays on the chip between steps, the
+        caller posts actions and waits for outputs.  Use as a context manager."""
+        from .session import StepSession
+        return StepSession(self, depth=depth, timeout_ms=timeout_ms, slots=slots)
+
     def sync_check(self):
         """Wait for the env's stream and raise if a kernel faulted (the launching calls only report launch errors)."""
         be = self.backend
@@ -782,7 +821,7 @@ class BatchedJssEnv:
         """Host copy of everything needed to resume: state + last outputs + the batch description."""
         n = self.backend.numpy
         d = {k: n(getattr(self, k)) for k in self._saved_tensors()}
-        d["meta"] = {"abi": _abi.ABI_VERSION, "record_ints": self.record_ints, "batch": self.batch, "jmax": self.jmax, "mmax": self.mmax, "seed": self.seed,
+        d["meta"] = {"abi": _abi.STATE_LAYOUT, "record_ints": self.record_ints, "batch": self.batch, "jmax": self.jmax, "mmax": self.mmax, "seed": self.seed,
                      "env_id_base": self.env_id_base, "table_of_env": self.table_of_env_host.copy(),
                      "ops": self.packed.ops.copy(),
                      # the global env ids key the per-env RNG streams: a resumed run continues them only on the same ids
@@ -791,8 +830,8 @@ class BatchedJssEnv:
 
     def load_state_dict(self, d):
         m = d["meta"]
-        if int(m.get("abi", 0)) != _abi.ABI_VERSION:
-            raise ValueError(f"checkpoint was written with state layout v{m.get('abi')}, this build is v{_abi.ABI_VERSION}")
+        if int(m.get("abi", 0)) != _abi.STATE_LAYOUT:
+            raise ValueError(f"checkpoint was written with state layout v{m.get('abi')}, this build is v{_abi.STATE_LAYOUT}")
         if int(m.get("record_ints", _abi.NF)) != self.record_ints:
             raise ValueError("checkpoint uses the other job-record layout (compact vs full)")
         if (int(m["batch"]), int(m["jmax"]), int(m["mmax"])) != (self.batch, self.jmax, self.mmax) or \

@@ -52,6 +52,8 @@ static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 #define hipDeviceAttributeMultiprocessorCount 0
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
 static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 2; return 0; }  // a 2-CU "device"
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+static inline hipError_t hipFuncSetAttribute(const void *, int, int) { return 0; }
 
 struct dim3 {
     unsigned x, y, z;
@@ -357,6 +359,24 @@ inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)
     *p = old + v;
     return old;
 }
+
+inline int atomicAdd(int *p, int v) {
+    int old = *p;
+    *p = old + v;
+    return old;
+}
+// agent-scope atomics of the step-session protocol: one fibre runs at a time, plain accesses are exact
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(p))
+inline void __builtin_amdgcn_s_sleep(int) {}
+// the 100 MHz wall clock: here a counter that advances 1 ms per reading, so that every bounded wait of the kernels
+// runs out after a few thousand polls instead of seconds
+inline long long wall_clock64() {
+    static long long t = 0;
+    return t += 100000;
+}
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 8; return 0; }
 
 // ---- scalar helpers that hip_runtime.h provides as device functions --------------------
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

@@ -984,6 +984,9 @@ def drive_steps(env, kind, iters, form="fused", explore=0.0, autoreset=True, win
                   -- exactly bench.py's timed region (HIP backend; elsewhere the fork-join form)
       fork_join   the same windows with the library's fork / join events (stream-ordered on the caller's stream)
       graph       a captured hipGraph of `window` x jss_rollout(n_iter = 1), replayed iters // window times (+ eager tail)
+      steps       the recorded actions of the same policy through jss_steps, `window` steps per launch
+      session     the same actions through a step session (state resident on the chip), `window` steps posted per wait;
+      session_lockstep: one step per post / wait (mailbox depth 1)
     """
     be = env.backend
     if form == "fused":
@@ -1026,6 +1029,28 @@ def drive_steps(env, kind, iters, form="fused", explore=0.0, autoreset=True, win
             env.rollout(kind, n_iter=1, autoreset=autoreset, explore=explore)
         torch.cuda.synchronize()
         del graph
+    elif form in ("steps", "session", "session_lockstep"):
+        # external actions: the behaviour trajectory of the same policy, recorded from the same state and replayed (slots
+        # where an episode had ended carry JSS_ACTION_RESET, so the replay IS the auto-restarting rollout)
+        start, sol0 = _state_snapshot(env), be.numpy(env.solution)
+        acts = env.trajectory(kind, steps=iters, record=("action",), explore=explore, autoreset=autoreset)["action"]
+        env.synchronize()
+        _restore(env, start, sol0)
+        if form == "steps":
+            done = 0
+            while done < iters:
+                n = min(window, iters - done)
+                env.steps(acts[done:done + n])
+                done += n
+        else:
+            depth = 1 if form == "session_lockstep" else window
+            with env.session(depth=depth) as s:
+                done = 0
+                while done < iters:
+                    n = min(depth, iters - done)
+                    s.post(acts[done:done + n] if n > 1 else acts[done])
+                    s.wait()
+                    done += n
     else:
         raise KeyError(form)
     env.synchronize()
@@ -1185,3 +1210,162 @@ def case_two_streams_two_threads(backend_factory, batch=3000, calls=12, steps=6,
         a, b = _state_snapshot(e), _state_snapshot(r)
         for name in a:
             assert np.array_equal(a[name], b[name]), f"two threads / two streams: {name} differs from the serial run"
+
+
+# -----------------------------------------------------------------------------------------
+# jss_steps (K x jss_step per launch, actions given up front) and the step session (state resident on the chip)
+# -----------------------------------------------------------------------------------------
+def recorded_actions(backend, kw, K, kind="random", seed=3, warm=0, explore=0.0, mutate=True):
+    """(K, B) int32 action codes of a behaviour trajectory on a fresh batch (-2 where an episode ended: next-step
+    auto-reset), optionally salted with what a careless caller sends: skips, out-of-mask jobs, NOPEs against the mask."""
+    env = BatchedJssEnv(seed=seed, _backend=backend, **kw)
+    env.reset()
+    if warm:
+        env.rollout(kind, n_iter=warm)
+    start = _state_snapshot(env)
+    sol0 = env.backend.numpy(env.solution)
+    acts = np.array(env.backend.numpy(env.trajectory(kind, steps=K, record=("action",), explore=explore)["action"]), dtype=np.int32)
+    if mutate:
+        rng = np.random.default_rng(seed)
+        B = env.batch
+        for k in range(2, K, 5):
+            b = rng.integers(0, B, size=max(1, B // 7))
+            acts[k, b] = _abi.ACTION_SKIP
+        for k in range(3, K, 11):
+            b = rng.integers(0, B, size=max(1, B // 9))
+            acts[k, b] = rng.integers(0, env.jobs_per_env[b] + 1)              # whatever: job or NOPE, legal or not
+        for k in range(7, K, 13):
+            acts[k, rng.integers(0, B)] = 1000                                  # out of range
+    return env, start, sol0, acts
+
+
+def _restore(env, start, sol0):
+    be = env.backend
+    for name, v in start.items():
+        if name != "solution":
+            be.copy_into(getattr(env, name), v)
+    be.copy_into(env.solution, sol0)
+
+
+def case_steps(backend, kw=None, K=40, kind="random", seed=3, warm=30):
+    """jss_steps == K x jss_step: every state and output tensor at the end, and the recorded per-step streams equal
+    what each jss_step call leaves in the env's outputs."""
+    kw = kw or dict(instances="ta01", batch=70)
+    env, start, sol0, acts = recorded_actions(backend, kw, K, kind, seed, warm)
+    n = env.backend.numpy
+    _restore(env, start, sol0)
+    per_step = []
+    for k in range(K):
+        env.step(acts[k])
+        per_step.append({"real_obs": n(env.real_obs), "action_mask": n(env.action_mask), "reward": n(env.reward), "done": n(env.done)})
+    want = _state_snapshot(env)
+    _restore(env, start, sol0)
+    rec = env.steps(acts, record=("real_obs", "action_mask", "reward", "done"))
+    env.synchronize()
+    got = _state_snapshot(env)
+    for name in want:
+        assert np.array_equal(got[name], want[name]), f"jss_steps differs from {K} x jss_step in {name}"
+    J = env.jobs_per_env
+    for k in range(K):
+        stepped = acts[k] >= 0
+        for i in range(env.batch):                                           # rows < J(env): the padding of a slot is never written
+            assert np.array_equal(n(rec["real_obs"][k])[i, :J[i]], per_step[k]["real_obs"][i, :J[i]]), f"step {k} env {i}: recorded obs"
+        assert np.array_equal(n(rec["action_mask"][k]), per_step[k]["action_mask"]), f"step {k}: recorded mask"
+        r = n(rec["reward"][k])
+        assert np.array_equal(r[stepped].view(np.int32), per_step[k]["reward"][stepped].view(np.int32)), f"step {k}: recorded reward"
+        assert not r[~stepped].any(), f"step {k}: reward of a skipped / reset slot must be 0"
+        assert np.array_equal(n(rec["done"][k])[stepped], per_step[k]["done"][stepped]), f"step {k}: recorded done"
+    assert int(np.asarray(n(env.err)).max()) != 0            # the salted trace did raise error flags (and both paths agree on them)
+    # no recording: same state
+    _restore(env, start, sol0)
+    env.steps(acts)
+    env.synchronize()
+    got = _state_snapshot(env)
+    for name in want:
+        assert np.array_equal(got[name], want[name]), f"jss_steps (nothing recorded) differs in {name}"
+    return env
+
+
+def case_session(backend, kw=None, K=36, kind="random", seed=5, warm=20, depth=8, slots=0, pattern=(1, 1, 3, 8, 2)):
+    """A step session == K x jss_step: after every wait the env's outputs equal what the jss_step calls leave, and
+    after close every state and output tensor does; posts run ahead of waits by up to `depth` steps."""
+    kw = kw or dict(instances="ta01", batch=150)
+    env, start, sol0, acts = recorded_actions(backend, kw, K, kind, seed, warm)
+    n = env.backend.numpy
+    _restore(env, start, sol0)
+    ref_out = []
+    for k in range(K):
+        env.step(acts[k])
+        ref_out.append({"real_obs": n(env.real_obs), "action_mask": n(env.action_mask), "reward": n(env.reward),
+                        "done": n(env.done), "makespan": n(env.makespan), "solution": n(env.solution)})
+    want = _state_snapshot(env)
+    _restore(env, start, sol0)
+    dev_acts = env.backend.as_device(acts, "int32") if hasattr(env.backend, "torch") else acts
+    with env.session(depth=depth, slots=slots) as s:
+        try:
+            env.step(acts[0])
+            raise AssertionError("other calls must be refused while a session is open")
+        except RuntimeError:
+            pass
+        k, i = 0, 0
+        while k < K:
+            m = min(pattern[i % len(pattern)], K - k, depth)
+            i += 1
+            if m == 1:
+                s.step(dev_acts[k])
+            else:
+                s.post(dev_acts[k:k + m])
+                s.wait()
+            k += m
+            env.backend.sync()
+            last = ref_out[k - 1]
+            for name in ("real_obs", "action_mask", "reward", "done", "makespan", "solution"):
+                assert np.array_equal(n(getattr(env, name)), last[name]), f"session: {name} after step {k - 1} differs from jss_step"
+        try:
+            s.post(np.repeat(acts[:1], depth + 1, axis=0))
+            raise AssertionError("a post beyond the ring depth must be refused")
+        except RuntimeError:
+            pass
+    st = s.host_status()
+    assert st["session_timeouts"] == 0 and st["wait_timeouts"] == 0 and st["wavefronts_exited"] > 0, st
+    got = _state_snapshot(env)
+    for name in want:
+        assert np.array_equal(got[name], want[name]), f"after the session closed: {name} differs from {K} x jss_step"
+    env.step(acts[0] * 0 - 1)                                # an ordinary call works again
+    return env, st
+
+
+def case_session_emulator(backend, kw=None, K=14, kind="random", seed=5, warm=20, slots=0, timeout_only=False):
+    """The resident kernel under the SIMT emulator, where a launch runs to completion: the mailbox is filled first
+    (post, then close), then the session is opened -- the kernel consumes every step and leaves.  Same comparison."""
+    import ctypes as C
+    kw = kw or dict(instances="ta01", batch=9)
+    env, start, sol0, acts = recorded_actions(backend, kw, K, kind, seed, warm)
+    be, lib, B = env.backend, env.backend.lib, env.batch
+    _restore(env, start, sol0)
+    for k in range(K):
+        env.step(acts[k])
+    want = _state_snapshot(env)
+    _restore(env, start, sol0)
+    mail, progress, status = np.zeros((K + 1, B), dtype=np.int64), np.zeros(B, dtype=np.int32), np.zeros(4, dtype=np.int32)
+    sess = _abi.JssSession(mail.ctypes.data, progress.ctypes.data, status.ctypes.data, K + 1, 5 if timeout_only else 2000, slots, 0)
+    d, s, o = env._refs()
+    a = np.ascontiguousarray(acts, dtype=np.int32)
+    if not timeout_only:
+        _abi.check(lib, lib.jss_session_post(d, C.byref(sess), a.ctypes.data, 0, K, 0, 0), "post")
+        assert lib.jss_session_post(d, C.byref(sess), a.ctypes.data, K, 2, 0, 0) == _abi.E_SESSION       # ring overrun
+        _abi.check(lib, lib.jss_session_close(d, C.byref(sess), K, 0), "close")
+    _abi.check(lib, lib.jss_session_open(d, s, o, C.byref(sess), 0), "open")
+    _abi.check(lib, lib.jss_session_wait(d, C.byref(sess), 0 if timeout_only else K, 0), "wait")
+    if timeout_only:       # nothing was ever posted: every wavefront gives up after the timeout, the state is as it was
+        assert status[0] > 0 and status[0] == status[2] and status[1] == 0, status
+        got = _state_snapshot(env)
+        for name, v in start.items():
+            assert np.array_equal(got[name], v), f"a timed-out session changed {name}"
+        return status
+    assert status[0] == 0 and status[1] == 0 and status[2] > 0 and status[3] in (1, 2, 4, 8), status
+    assert (progress[:status[2]] == K).all(), progress
+    got = _state_snapshot(env)
+    for name in want:
+        assert np.array_equal(got[name], want[name]), f"session (emulator, slots {status[3]}): {name} differs from {K} x jss_step"
+    return status

@@ -235,3 +235,10 @@ def test_launch_form_driver_and_render_rows(cpu):
     P.case_every_env_vs_oracle(cpu, label, kw(), kind, 120, explore, form="per_launch")
     P.case_every_env_vs_oracle(cpu, label, kw(), kind, 120, explore, form="fork_join", n_sub=3)
     P.case_render_rows_from_device_solution(cpu)
+
+
+def test_steps_and_step_session(cpu):
+    P.case_steps(cpu, dict(instances="ta01", batch=70), K=60, warm=200)
+    P.case_steps(cpu, dict(instances=["ta01", "ta31", "ta71"], batch=11), K=40, kind="SPT", warm=5)
+    P.case_session(cpu, dict(instances="ta01", batch=50), K=36)
+    P.case_session(cpu, dict(instances=["ta02", "ta51"], batch=7), K=20, kind="FIFO")

@@ -268,7 +268,9 @@ def hip_auto():
 
 
 _FORMS = [(cfg, "free") for cfg in range(len(P.FULL_SIZE_CONFIGS))] + [(0, "graph"), (2, "graph"), (4, "graph"), (4, "fork_join"),
-                                                                      (3, "per_launch")]
+                                                                      (3, "per_launch")] + \
+         [(cfg, "session") for cfg in (0, 1, 2, 4)] + [(0, "session_lockstep"), (2, "session_lockstep")] + \
+         [(cfg, "steps") for cfg in range(len(P.FULL_SIZE_CONFIGS))]
 
 
 @pytest.mark.parametrize("cfg,form", _FORMS, ids=[f"{P.FULL_SIZE_CONFIGS[c][0].split(':')[0]}-{f}" for c, f in _FORMS])
@@ -292,3 +294,57 @@ def test_render_rows_from_device_solution(hip_auto):
 def test_two_envs_two_threads_two_streams():
     from jssenv_amd.env import HipBackend
     P.case_two_streams_two_threads(lambda: HipBackend("cuda:0"))
+
+
+def test_steps_equal_repeated_step(hip):
+    """jss_steps: K x jss_step per launch with the actions given up front, every step recorded."""
+    P.case_steps(hip, dict(instances="ta01", batch=700), K=80, warm=180)                            # crosses episode ends
+    P.case_steps(hip, dict(instances=["ta01", "ta31", "ta51", "ta71"], batch=21), K=50, kind="SPT", warm=5)
+    P.case_steps(hip, dict(instances=["ta02", "ta03", "ta04"], batch=130), K=40)                    # env -> instance map
+
+
+def test_step_session_equals_repeated_step(hip):
+    """jss_session_*: the state resident in a kernel that lives across steps; outputs after every wait and the state
+    after close equal K x jss_step.  Env sets in registers (one per wavefront) and parked in LDS (2, 4 per wavefront)."""
+    P.case_session(hip, dict(instances="ta01", batch=4096), K=60, warm=200)
+    P.case_session(hip, dict(instances="ta01", batch=1000), K=40, warm=20, slots=4, depth=3)
+    P.case_session(hip, dict(instances="ta41", batch=700), K=40, kind="SPT", warm=580, slots=2)
+    P.case_session(hip, dict(instances=["ta02", "ta03", "ta04"], batch=300), K=30, slots=2)
+    P.case_session(hip, dict(instances=["ta01", "ta31", "ta51", "ta71"], batch=40), K=40, kind="FIFO", slots=2)
+    P.case_session(hip, dict(instances=["ta61"], batch=100), K=30, depth=1, pattern=(1,))
+
+
+def test_step_session_fits_the_baseline_batches(hip_auto):
+    """Residency: configs 2, 3 and config 4's share open as ONE round of resident workgroups (1, 2, 2 env sets per
+    wavefront) with room left for the caller's kernels; the whole headline batch needs 8."""
+    from jssenv_amd import BatchedJssEnv
+    from jssenv_amd import instances as I
+    for kw, want in ((dict(instances="ta01", batch=4096), 1), (dict(instances="ta41", batch=16384), 2),
+                     (dict(instances=I.synthetic_packed(8192, 50, 20)), 2), (dict(instances="ta01", batch=65536), 8)):
+        env = BatchedJssEnv(_backend=hip_auto, **kw)
+        env.reset()
+        with env.session(depth=2) as s:
+            s.step(env.backend.torch.zeros(env.batch, dtype=env.backend.torch.int32, device=env.backend.device))
+        st = s.host_status()
+        assert st["env_sets_per_wavefront"] == want and st["session_timeouts"] == 0 and st["wait_timeouts"] == 0, (kw.get("batch"), st)
+
+
+def test_step_session_gives_up_instead_of_hanging(hip_auto):
+    """Nothing is posted: every wavefront of the resident kernel gives up after timeout_ms, stores its (unchanged) state
+    and leaves; close() reports it."""
+    import time
+    from jssenv_amd import BatchedJssEnv
+    env = BatchedJssEnv("ta01", batch=2000, _backend=hip_auto)
+    env.reset()
+    env.rollout("random", n_iter=33)
+    env.synchronize()
+    before = P._state_snapshot(env)
+    s = env.session(depth=2, timeout_ms=50)
+    time.sleep(0.3)
+    with pytest.raises(RuntimeError, match="timed out"):
+        s.close()
+    st = s.host_status()
+    assert st["session_timeouts"] > 0 and st["session_timeouts"] == st["wavefronts_exited"]
+    after = P._state_snapshot(env)
+    for name in before:
+        assert np.array_equal(before[name], after[name]), name

@@ -133,3 +133,21 @@ def test_compact_records_equal_full_records(emu):
 
 def test_compact_records_at_the_limits(emu):
     P.case_compact_limits(emu, shapes=((3, 64), (16, 16)))
+
+
+def test_steps_equal_repeated_step(emu):
+    P.case_steps(emu, dict(instances="ta01", batch=9), K=30, warm=200)                           # crosses episode ends
+    P.case_steps(emu, dict(instances=["ta01", "ta31", "ta71"], batch=5), K=16, kind="SPT", warm=5)   # ragged, two jobs per lane
+
+
+def test_step_session_resident_kernel(emu):
+    """jss_session_*: every env set in registers (slots 1) and parked in LDS between visits (slots 2, 4)."""
+    P.case_session_emulator(emu, dict(instances="ta01", batch=9), K=14, warm=215)                 # shared table, compact records
+    P.case_session_emulator(emu, dict(instances="ta01", batch=21), K=10, warm=40, slots=2)
+    P.case_session_emulator(emu, dict(instances="ta41", batch=9), K=8, warm=30, slots=4)          # 32-lane groups
+    P.case_session_emulator(emu, dict(instances=["ta02", "ta03"], batch=11), K=8, slots=2)        # env -> instance map, full records
+    P.case_session_emulator(emu, dict(instances=["ta01", "ta31", "ta71"], batch=7), K=8, kind="SPT", slots=2)   # ragged
+
+
+def test_step_session_times_out_instead_of_hanging(emu):
+    P.case_session_emulator(emu, dict(instances="ta01", batch=9), K=3, timeout_only=True)
