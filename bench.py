@@ -548,8 +548,17 @@ def main():
                         "steps_each": K, "us_per_step": 1e6 * (sum(counts[1:]) / len(rows)) / med / K,
                         "roofline_frac": med * alg / 1e9 / HBM_PEAK_GBS}
 
-            out["steps_per_launch"] = timed(lambda w: env.steps(acts[w * K:(w + 1) * K]))
-            out["steps_per_launch"]["launch"] = f"jss_steps: {K} x jss_step per launch, actions resident, state in registers in between"
+            rec_all = ("real_obs", "action_mask", "reward", "done")
+            bufs = env.steps(acts[:K], record=rec_all)
+            restore()
+            out["steps_per_launch"] = timed(lambda w: env.steps(acts[w * K:(w + 1) * K], record=rec_all, buffers=bufs))
+            out["steps_per_launch"]["launch"] = (f"jss_steps: {K} x jss_step per launch, actions resident, state in registers in between, "
+                                                 f"EVERY step's real_obs / action_mask / reward / done written ([K][B] buffers)")
+            del bufs
+            restore()
+            out["steps_per_launch_last_obs_only"] = timed(lambda w: env.steps(acts[w * K:(w + 1) * K]))
+            out["steps_per_launch_last_obs_only"]["launch"] = (f"jss_steps: {K} x jss_step per launch, reward / done per step, observation and "
+                                                               f"mask of the last step only")
             restore()
             with env.session(depth=K) as sess:
                 out["session_posted_ahead"] = timed(lambda w: (sess.post(acts[w * K:(w + 1) * K]), sess.wait()))

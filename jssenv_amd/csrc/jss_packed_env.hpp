@@ -745,35 +745,53 @@ __device__ __forceinline__ void p_reload_instance(PCtx<G, TAB> &c, const Params 
     wave_lds_sync();
 }
 
-// One jss_step call on the registers: the JSS_ACTION_RESET restart, step(), the header's step count, reward / done /
-// makespan / counters (a skipped env keeps them).  WT = the stores are write-through (step session).  rn = the reward
-// numerator, called = the env was stepped (not skipped, not restarted).  Returns "my env was re-initialised".
+// One jss_step call on the registers, in two halves: the computation -- the JSS_ACTION_RESET restart, step(), the
+// header's step count -- and the per-env scalar outputs: reward / done / makespan / counters (a skipped env keeps them).
+// WT = the stores are write-through (step session, which puts its progress word between the two halves: see there).
+// rn = the reward numerator, called = the env was stepped (not skipped, not restarted).  Returns "re-initialised".
+struct PStepResult {
+    int rn;
+    bool called, restart, done;
+};
+template <int G, int TAB, bool WT>
+__device__ __forceinline__ PStepResult p_step_compute(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c, const Params &p, int a_in, int32_t *mvtab) {
+    PStepResult r;
+    r.restart = c.alive && a_in == JSS_ACTION_RESET;                    // reset() this env instead of stepping it
+    p_reload_instance(c, p, r.restart);
+    p_reset<G, TAB, WT>(e, c, p, r.restart);
+    if (r.restart) {
+        hd.episode += 1;
+        hd.step = 0;
+    }
+    r.rn = p_step<G, TAB, WT>(e, c, p, a_in, mvtab);
+    r.called = a_in != JSS_ACTION_SKIP && !r.restart;
+    r.done = !grp_any<G>(e.legal, c.gbase);
+    if (r.called) hd.step += 1;
+    return r;
+}
+template <int G, int TAB, bool WT>
+__device__ __forceinline__ void p_step_outputs(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, const PStepResult &r) {
+    const size_t fe = (size_t)c.first_env;
+    if (!c.alive || c.gl != 0) return;
+    if (r.restart) {
+        st_out<WT, float>(p.o.reward + fe, c.rel * 4u, 0.f);
+        st_out<WT, uint8_t>(p.o.done + fe, c.rel, (uint8_t)0);
+    }
+    if (r.called) {                                   // a skipped env keeps its reward / done / makespan
+        st_out<WT, float>(p.o.reward + fe, c.rel * 4u, div_by((float)r.rn, (float)c.max_time_op, p_norm(c).r_op));   // :483-493
+        st_out<WT, uint8_t>(p.o.done + fe, c.rel, (uint8_t)(r.done ? 1 : 0));                      // :639-653
+        if (r.done) st_out<WT, int>(p.o.makespan + fe, c.rel * 4u, e.t);                           // :650
+        if (p.s.counters) add_counters(p.s.counters + (fe + c.rel) * 4, 1, r.done ? 1 : 0, r.done ? e.t : 0, r.rn);
+    }
+}
 template <int G, int TAB, bool WT>
 __device__ __forceinline__ bool p_step_call(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c, const Params &p, int a_in,
                                             int32_t *mvtab, int &rn, bool &called) {
-    const size_t fe = (size_t)c.first_env;
-    const bool restart = c.alive && a_in == JSS_ACTION_RESET;           // reset() this env instead of stepping it
-    p_reload_instance(c, p, restart);
-    p_reset<G, TAB, WT>(e, c, p, restart);
-    if (restart) {
-        hd.episode += 1;
-        hd.step = 0;
-        if (c.gl == 0) {
-            st_out<WT, float>(p.o.reward + fe, c.rel * 4u, 0.f);
-            st_out<WT, uint8_t>(p.o.done + fe, c.rel, (uint8_t)0);
-        }
-    }
-    rn = p_step<G, TAB, WT>(e, c, p, a_in, mvtab);
-    called = a_in != JSS_ACTION_SKIP && !restart;
-    const bool done = !grp_any<G>(e.legal, c.gbase);
-    if (called) hd.step += 1;
-    if (c.alive && c.gl == 0 && called) {             // a skipped env keeps its reward / done / makespan
-        st_out<WT, float>(p.o.reward + fe, c.rel * 4u, div_by((float)rn, (float)c.max_time_op, p_norm(c).r_op));   // :483-493
-        st_out<WT, uint8_t>(p.o.done + fe, c.rel, (uint8_t)(done ? 1 : 0));                        // :639-653
-        if (done) st_out<WT, int>(p.o.makespan + fe, c.rel * 4u, e.t);                             // :650
-        if (p.s.counters) add_counters(p.s.counters + (fe + c.rel) * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
-    }
-    return restart;
+    const PStepResult r = p_step_compute<G, TAB, WT>(e, hd, c, p, a_in, mvtab);
+    p_step_outputs<G, TAB, WT>(e, c, p, r);
+    rn = r.rn;
+    called = r.called;
+    return r.restart;
 }
 
 template <int G, int MODE, int TAB>
@@ -1194,14 +1212,13 @@ __global__ __launch_bounds__(kBlock, 6) void jss_packed_session_kernel(Params p)
                 never = hd.episode == 0;
             }
             if (never) c.alive = false;
-            int rn;
-            bool called;
-            p_step_call<G, TAB, true>(e, hd, c, p, a, mvtab, rn, called);
-            if (pending) {                            // the previous step's stores have had this step's compute to drain
-                wt_drain();
+            const PStepResult res = p_step_compute<G, TAB, true>(e, hd, c, p, a, mvtab);
+            if (pending) {                            // the previous step's stores have had this step's compute to drain: the
+                wt_drain();                           // progress word goes out BEFORE any output store of this step is issued
                 if (lane == 0) wt_store(p.progress + gw, pending);
                 pending = 0;
             }
+            p_step_outputs<G, TAB, true>(e, c, p, res);
             const size_t fe = (size_t)c.first_env;
             p_store_mask<G, TAB, true>(e, c, p, p.o.action_mask + fe * (p.d.jmax + 1));
             p_store_obs<G, TAB, true>(e, c, p, p.o.real_obs + fe * p.d.jmax * 7, scratch, sl.whole);

@@ -850,38 +850,55 @@ __device__ __forceinline__ void ctx_from_header(Ctx &c, const HeaderWords &h) {
     c.r_m = as_float(in_vgpr(__builtin_amdgcn_readfirstlane(h.r_m)));
 }
 
-// One jss_step call on the registers: the JSS_ACTION_RESET restart, step(), the header's step count, reward / done /
-// makespan / counters (a skipped env keeps them).  WT = the stores are write-through (step session).  rn = the reward
-// numerator, called = the env was stepped (not skipped, not restarted).  Returns "the env was re-initialised".
+// One jss_step call on the registers, in two halves: the computation -- the JSS_ACTION_RESET restart, step(), the
+// header's step count -- and the env's scalar outputs: reward / done / makespan / counters (a skipped env keeps them).
+// WT = the stores are write-through (step session, which puts its progress word between the two halves).
+struct StepResult {
+    int rn;
+    bool called, restart, done;
+};
 template <int JPL, int TAB, bool WT>
-__device__ __forceinline__ bool step_call(Env<JPL> &e, Header &hd, Ctx &c, const Params &p, const int32_t *lds, int a_in,
-                                          int &rn, bool &called) {
-    const int b = c.b;
-    const bool restart = a_in == JSS_ACTION_RESET;                       // reset() this env instead of stepping it
-    if (restart) {
+__device__ __forceinline__ StepResult step_compute(Env<JPL> &e, Header &hd, Ctx &c, const Params &p, const int32_t *lds, int a_in) {
+    StepResult r;
+    r.restart = a_in == JSS_ACTION_RESET;                                // reset() this env instead of stepping it
+    if (r.restart) {
         // the env may have been given another instance since its last reset (table_of_env)
-        const int tid = tab_in_lds(TAB) ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : c.tid);
+        const int tid = tab_in_lds(TAB) ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[c.b] : c.tid);
         ctx_from_instance(c, p, tid);
         ctx_table<TAB>(c, p, lds);
         hd.episode += 1;
         hd.step = 0;
         reset_env<JPL, WT>(e, c, p);
-        if (c.lane == 0) {
-            st_out<WT, float>(p.o.reward + b, 0u, 0.f);
-            st_out<WT, uint8_t>(p.o.done + b, 0u, (uint8_t)0);
-        }
     }
-    rn = step_env<JPL, WT>(e, c, p, a_in);
-    called = a_in != JSS_ACTION_SKIP && !restart;
-    const bool done = !any_legal(e);
-    if (called) hd.step += 1;
-    if (c.lane == 0 && called) {                                         // a skipped env keeps its reward / done / makespan
-        st_out<WT, float>(p.o.reward + b, 0u, reward_of(rn, c));         // :483-493 (0 for ignored actions)
-        st_out<WT, uint8_t>(p.o.done + b, 0u, (uint8_t)(done ? 1 : 0));  // :639-653
-        if (done) st_out<WT, int>(p.o.makespan + b, 0u, e.t);            // last_time_step :650
-        if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, 1, done ? 1 : 0, done ? e.t : 0, rn);
+    r.rn = step_env<JPL, WT>(e, c, p, a_in);
+    r.called = a_in != JSS_ACTION_SKIP && !r.restart;
+    r.done = !any_legal(e);
+    if (r.called) hd.step += 1;
+    return r;
+}
+template <int JPL, bool WT>
+__device__ __forceinline__ void step_outputs(const Env<JPL> &e, const Ctx &c, const Params &p, const StepResult &r) {
+    const int b = c.b;
+    if (c.lane != 0) return;
+    if (r.restart) {
+        st_out<WT, float>(p.o.reward + b, 0u, 0.f);
+        st_out<WT, uint8_t>(p.o.done + b, 0u, (uint8_t)0);
     }
-    return restart;
+    if (r.called) {                                                      // a skipped env keeps its reward / done / makespan
+        st_out<WT, float>(p.o.reward + b, 0u, reward_of(r.rn, c));       // :483-493 (0 for ignored actions)
+        st_out<WT, uint8_t>(p.o.done + b, 0u, (uint8_t)(r.done ? 1 : 0));   // :639-653
+        if (r.done) st_out<WT, int>(p.o.makespan + b, 0u, e.t);          // last_time_step :650
+        if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, 1, r.done ? 1 : 0, r.done ? e.t : 0, r.rn);
+    }
+}
+template <int JPL, int TAB, bool WT>
+__device__ __forceinline__ bool step_call(Env<JPL> &e, Header &hd, Ctx &c, const Params &p, const int32_t *lds, int a_in,
+                                          int &rn, bool &called) {
+    const StepResult r = step_compute<JPL, TAB, WT>(e, hd, c, p, lds, a_in);
+    step_outputs<JPL, WT>(e, c, p, r);
+    rn = r.rn;
+    called = r.called;
+    return r.restart;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1216,14 +1233,14 @@ __global__ __launch_bounds__(kBlock, JPL == 1 ? 6 : 4) void jss_session_kernel(P
                 unpack_env<JPL, TAB>(e, c, raw, clock, status, reinterpret_cast<int32_t *>(scratch));
             }
             if (c.J != 0) {                           // (J == 0: the env was never reset -- the session leaves it alone)
-                int rn;
-                bool called;
-                const bool fresh = step_call<JPL, TAB, true>(e, hd, c, p, lds, a, rn, called);
-                if (pending) {                        // the previous step's stores have had this step's compute to drain
-                    wt_drain();
+                const StepResult res = step_compute<JPL, TAB, true>(e, hd, c, p, lds, a);
+                const bool fresh = res.restart;
+                if (pending) {                        // the previous step's stores have had this step's compute to drain: the
+                    wt_drain();                       // progress word goes out BEFORE any output store of this step is issued
                     if (lane == 0) wt_store(p.progress + gw, pending);
                     pending = 0;
                 }
+                step_outputs<JPL, true>(e, c, p, res);
                 store_mask<JPL, true>(e, c, p.o.action_mask + (size_t)c.b * (p.d.jmax + 1), p.d.jmax);
                 store_obs<JPL, true>(e, c, p.o.real_obs + (size_t)c.b * p.d.jmax * 7, scratch, fresh ? p.d.jmax : c.J);
             }

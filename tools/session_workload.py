@@ -69,7 +69,15 @@ def main():
     del env, snap
     env = env2
     extra = {}
-    if args.form == "steps":
+    if args.form == "steps":                                     # every step's outputs recorded, like the session writes them
+        rec = ("real_obs", "action_mask", "reward", "done")
+        Jm = env.jmax
+        bufs = {"real_obs": torch.zeros((K, batch, Jm, 7), dtype=torch.float32, device=dev),
+                "action_mask": torch.zeros((K, batch, Jm + 1), dtype=torch.uint8, device=dev),
+                "reward": torch.zeros((K, batch), dtype=torch.float32, device=dev),
+                "done": torch.zeros((K, batch), dtype=torch.uint8, device=dev)}
+        run(lambda w: env.steps(acts[w * K:(w + 1) * K], record=rec, buffers=bufs))
+    elif args.form == "steps_bare":                              # reward / done per step, observation of the last step only
         run(lambda w: env.steps(acts[w * K:(w + 1) * K]))
     elif args.form == "step_launches":
         def launches(w):
