@@ -107,7 +107,7 @@ def usable_threads():
 
 
 
-def cpu_baseline_restatement(inst_name, seed, target_seconds=10.0):
+def cpu_baseline_restatement(inst_name, seed, target_seconds=10.0, instance=None):
     """The reference's own way of doing a step -- Python loops over NumPy arrays, one env, one core
     (oracle/np_restatement.py: attribute-for-attribute restatement of jss_env.py:121-653, pinned bit-exactly to the
     reference's golden traces; in the build container it runs at the live reference's speed) -- driven by the
@@ -115,7 +115,7 @@ def cpu_baseline_restatement(inst_name, seed, target_seconds=10.0):
     import numpy as np
     from jssenv_amd import builtin_instance
     from oracle.np_restatement import NumpyJssEnv, random_masked_episode
-    env = NumpyJssEnv(builtin_instance(inst_name))
+    env = NumpyJssEnv(instance if instance is not None else builtin_instance(inst_name))
     rng = np.random.default_rng(seed)
     random_masked_episode(env, rng)                      # warm
     steps, t0 = 0, time.perf_counter()
@@ -429,8 +429,10 @@ def main():
         return med, rows
 
     def window_stats(rows, steps):
+        med = rows[len(rows) // 2]["rate"]
         return {"n": len(rows), "steps_each": steps, "statistic": "median", "min": rows[0]["rate"], "max": rows[-1]["rate"],
-                "timed_seconds_total": sum(r["seconds"] for r in rows)}
+                "below_90pct_of_median": sum(1 for r in rows if r["rate"] < 0.9 * med),
+                "p10": rows[len(rows) // 10]["rate"], "timed_seconds_total": sum(r["seconds"] for r in rows)}
 
     def launch_label(mode):
         if mode.startswith("sub"):
@@ -448,19 +450,22 @@ def main():
         return f"jss_kernel<{1 if jm <= 64 else 2},kRollout1,{tab}>"
 
     def static_traffic(key, batch):
+        """(HBM-side bytes per launch, where they come from, {wave cycles per env step, wait fraction, ...}) from the
+        committed rocprofv3 counter summaries -- static numbers, tied to the kernel sources by their hash."""
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if key is None:
-            return None, None
+            return None, None, {}
         try:
             with open(prof) as fh:
                 ent = json.load(fh).get(f"{key}_b{batch}")
             if not ent:
-                return None, None
+                return None, None, {}
             stale = ent.get("csrc_sha16") != csrc_hash()
+            sq = {k: ent[k] for k in ("wave_cycles_per_env_step", "wait_fraction", "valu_per_wave", "salu_per_wave") if k in ent}
             return ent["bytes_per_launch"], (f"profiles/{ent['source']} (static: rocprofv3 PMC passes of round {ent.get('round')}, not re-measured in "
-                                             f"this run; kernel sources {'CHANGED since' if stale else 'unchanged since'} -- csrc_sha16 {ent.get('csrc_sha16')})")
+                                             f"this run; kernel sources {'CHANGED since' if stale else 'unchanged since'} -- csrc_sha16 {ent.get('csrc_sha16')})"), sq
         except Exception:
-            return None, None
+            return None, None, {}
 
     def roofline(med, alg_per_step, steps, env, key, batch):
         """frac = whole-job env steps per second x algorithmic bytes per env step / (N x peak): the wall-clock figure,
@@ -469,9 +474,17 @@ def main():
         stepped = med["steps"] / world / steps
         achieved = med["rate"] / world * alg_per_step / 1e9
         gpu_time = stepped * alg_per_step / (med["kernel_ms"] * 1e-3) / 1e9
-        traffic, src = static_traffic(key, batch)
+        traffic, src, sq = static_traffic(key, batch)
+        step_s = med["seconds"] / steps
+        # of the bytes the kernel really moves (counters; a pass in which every env steps): traffic / wall time per step
+        own = (traffic / step_s / 1e9) if traffic else None
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_PEAK_GBS,
+                "frac_own_bytes": (own / HBM_PEAK_GBS) if own else None, "achieved_own_bytes": own,
+                "frac_note": "frac = ALGORITHMIC bytes (SURVEY 8(d): 89 J + 10 M + 40 per env step) over the wall clock; the kernels move "
+                             "fewer bytes than that (compact records, unchanged records not rewritten), so frac can exceed what a copy of "
+                             "the algorithmic bytes could reach -- frac_own_bytes = the counters' bytes (traffic) over the same wall clock",
+                **sq,
                 "frac_gpu_time": gpu_time / HBM_PEAK_GBS, "achieved_gpu_time": gpu_time,
                 "measured_peak": HBM_MEASURED_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                 "kernel": kernel_name(env), "kernel_ms": med["kernel_ms"],
@@ -502,6 +515,48 @@ def main():
                     "note": "jss_trajectory: policy + step x K per launch with the observation, mask, action, reward and done of "
                             "EVERY step written out ([K][B] buffers); roofline_frac uses the same algorithmic bytes per env step "
                             "as the step-per-launch figure next to it (SURVEY 8(d)), the last two fields its own byte count"}
+        except Exception as exc:
+            torch.cuda.synchronize()
+            return {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+
+    def step_only_measure(env, policy, alg, B):
+        """The boundary entry point itself: jss_step with the actions already resident in HBM, ONE launch per env step,
+        next-step auto-reset folded into the action codes.  The actions are a recorded behaviour trajectory (jss_trajectory
+        from a snapshot of the state, restored before every window), so every launch executes real, legal steps.  Eager
+        ctypes launches and a hipGraph replay of the same K launches; the better one is reported."""
+        try:
+            n2 = max(20, min(100, args.steps))
+            env.zero_counters()                          # (the counters live in the arena: the snapshot holds zeros)
+            snap = env._arena.clone(), env.solution.clone()
+            acts = env.trajectory(policy, steps=n2, record=("action",))["action"]
+
+            def restore():
+                env._arena.copy_(snap[0])
+                env.solution.copy_(snap[1])
+
+            def replay_steps(n):
+                for k in range(n):
+                    env.step(acts[k])
+            meds, rowss = measure(env, policy, n2, "eager", run=replay_steps, prep=restore)
+            restore()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            gs = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(gs, stream=side):
+                    replay_steps(n2)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            medg, rowsg = measure(env, policy, n2, "eager", run=lambda n: gs.replay(), prep=restore)
+            del gs
+            best, rws, how = (medg, rowsg, "hipGraph replay") if medg["rate"] > meds["rate"] else (meds, rowss, "eager ctypes launches")
+            rfs = roofline(best, alg, n2, env, None, B)
+            restore()
+            del snap
+            return {"value": best["rate"], "unit": "env steps/s", "ms_per_step": best["seconds"] / n2 * 1e3,
+                    "launch": f"jss_step(actions resident in HBM), one launch per env step, {how}",
+                    "roofline_frac": rfs["frac"], "roofline_frac_gpu_time": rfs["frac_gpu_time"],
+                    "windows": window_stats(rws, n2), "eager": meds["rate"], "graph": medg["rate"],
+                    "note": "the entry point an RL trainer with its own policy network calls; the policy's cost is not in it"}
         except Exception as exc:
             torch.cuda.synchronize()
             return {"value": None, "error": f"{type(exc).__name__}: {exc}"}
@@ -609,6 +664,7 @@ def main():
         if with_trajectory and not bucketed:
             out["trajectory"] = traj_measure(env, policy, alg)
         if with_external and not bucketed:
+            out["step_only"] = step_only_measure(env, policy, alg, batch)
             out["external_actions"] = external_action_forms(env, policy, alg, args.steps)
         if keep:
             return out, env
@@ -668,45 +724,7 @@ def main():
         out["fused_rollout"] = {"value": medf["rate"], "unit": "env steps/s", "iterations_per_launch": 64, "launches": n_l,
                                 "note": "policy+step x64 per launch, observation written once per launch"}
     if not args.no_extras and world == 1 and not hasattr(env, "buckets"):
-        try:
-            # ---- the boundary entry point itself: jss_step with the actions already resident in HBM, ONE launch per env
-            # step, next-step auto-reset folded into the action codes.  The actions are a recorded behaviour trajectory
-            # (jss_trajectory from a snapshot of the state, restored afterwards), so every launch executes real, legal steps.
-            n2 = max(20, min(100, args.steps))
-            env.zero_counters()                          # (the counters live in the arena: the snapshot holds zeros)
-            snap = env._arena.clone(), env.solution.clone()
-            acts = env.trajectory(args.policy, steps=n2, record=("action",))["action"]
-
-            def restore():
-                env._arena.copy_(snap[0])
-                env.solution.copy_(snap[1])
-
-            def replay_steps(n):
-                for k in range(n):
-                    env.step(acts[k])
-            meds, rowss = measure(env, args.policy, n2, "eager", run=replay_steps, prep=restore)
-            restore()
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            gs = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(gs, stream=side):
-                    replay_steps(n2)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            medg, rowsg = measure(env, args.policy, n2, "eager", run=lambda n: gs.replay(), prep=restore)
-            del gs
-            best, rws, how = (medg, rowsg, "hipGraph replay") if medg["rate"] > meds["rate"] else (meds, rowss, "eager ctypes launches")
-            rfs = roofline(best, alg_per_step, n2, env, None, B)
-            out["step_only"] = {"value": best["rate"], "unit": "env steps/s", "ms_per_step": best["seconds"] / n2 * 1e3,
-                                "launch": f"jss_step(actions resident in HBM), one launch per env step, {how}",
-                                "roofline_frac": rfs["frac"], "roofline_frac_gpu_time": rfs["frac_gpu_time"],
-                                "windows": window_stats(rws, n2), "eager": meds["rate"], "graph": medg["rate"],
-                                "note": "the entry point an RL trainer with its own policy network calls; the policy's cost is not in it"}
-            restore()
-            del snap
-        except Exception as exc:
-            out["step_only"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
-            torch.cuda.synchronize()
+        out["step_only"] = step_only_measure(env, args.policy, alg_per_step, B)
         out["trajectory"] = traj_measure(env, args.policy, alg_per_step)
         out["external_actions"] = external_action_forms(env, args.policy, alg_per_step, args.steps)
         # the un-fused path: jss_policy (stand-in for a policy network) then jss_step(actions) with next-step auto-reset --
@@ -820,6 +838,16 @@ def main():
                 out[name]["host"] = host_cores()
             except Exception as exc:
                 out[name] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+        try:     # the other BASELINE shapes at the reference's speed: ta41 (config 3), synthetic 50x20 (config 4), ta80 (config 5's largest)
+            from jssenv_amd.instances import taillard_instance
+            per = {}
+            for label, name, inst in (("config3_ta41", "ta41", None), ("config4_synthetic50x20", "synthetic 50x20 (time seed 1, machine seed 2)",
+                                                                        taillard_instance(50, 20, 1, 2)), ("config5_ta80", "ta80", None)):
+                r = cpu_baseline_restatement(name, args.seed, target_seconds=4.0, instance=inst)
+                per[label] = {"value": r["value"], "unit": r["unit"], "cores": 1, "kind": "restatement", "sample": r["sample"]}
+            out["cpu_baseline_per_config"] = per
+        except Exception as exc:
+            out["cpu_baseline_per_config"] = {"error": f"{type(exc).__name__}: {exc}"}
     elif rank == 0:
         out["cpu_baseline"] = None
 

@@ -185,6 +185,11 @@ extern "C" {
 #define JSS_POLICY_LOR 6
 #define JSS_POLICY_CR 7 /* critical ratio (1.5 * job length - now) / remaining work, dispatching.py:365-408 */
 #define JSS_N_POLICIES 8
+/* `kind` arguments: bits 0-7 = the policy.  For JSS_POLICY_CR bits 8-15 / 16-23 may carry a due-date factor p / q other than
+ * the reference's default 3 / 2 (CriticalRatio(due_date_factor=...), dispatching.py:337-360): 1 <= p <= 255, q a power of
+ * two <= 64 -- the factors for which factor * job_length is exact in the reference's doubles, so that the device's exact
+ * fraction comparison (p * job_length - q * now) / remaining sees the reference's order AND its ties.  0 = 3 / 2. */
+#define JSS_POLICY_CR_FACTOR(p, q) (JSS_POLICY_CR | ((p) << 8) | ((q) << 16))
 
 /* jss_rollout flags */
 #define JSS_ROLLOUT_AUTORESET 1 /* an env found done is reset instead of stepped (iteration not counted) */

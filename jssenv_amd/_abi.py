@@ -29,6 +29,23 @@ ERR_ILLEGAL_ACTION, ERR_NOPE_IDLE, ERR_BAD_ACTION = 1, 2, 4
 ACTION_SKIP, ACTION_RESET, ACTION_CLOSE = -1, -2, -3
 POLICY = {"random": 0, "FIFO": 1, "SPT": 2, "MWR": 3, "LWR": 4, "MOR": 5, "LOR": 6, "CR": 7}
 ROLLOUT_AUTORESET, ROLLOUT_FORK_JOIN = 1, 2
+
+
+def cr_kind(due_date_factor: float = 1.5):
+    """The `kind` code of CriticalRatio with a due-date factor other than the default (JSS_POLICY_CR_FACTOR): factor = p / q
+    with q a power of two <= 64 and p <= 255, or None when the factor has no such form (the host loop serves it then)."""
+    from fractions import Fraction
+    f = Fraction(due_date_factor).limit_denominator(64)
+    if float(f) != float(due_date_factor) or f <= 0 or f.numerator > 255 or f.denominator & (f.denominator - 1):
+        return None
+    if (f.numerator, f.denominator) == (3, 2):
+        return POLICY["CR"]
+    return POLICY["CR"] | (f.numerator << 8) | (f.denominator << 16)
+
+
+def policy_code(kind):
+    """str | int -> the int the C ABI takes."""
+    return POLICY[kind] if isinstance(kind, str) else int(kind)
 KERNEL = {"auto": 0, "wave": 1}
 E_NULL, E_SHAPE, E_KIND, E_LDS, E_RESIDENT, E_SESSION = -1, -2, -3, -4, -5, -6
 MAX_SUB_BATCHES = 16

@@ -271,13 +271,16 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t env_id, uint
     const uint32_t b = (uint32_t)(seed >> 32) ^ ((uint32_t)(env_id >> 32) * 0x27D4EB2Fu);
     return fmix32(fmix32(a) ^ b);
 }
-// CriticalRatio (dispatching.py:365-408): ratio = (1.5 * job_length - now) / remaining_work, smallest first, lowest
-// job index on ties.  Compared exactly as the fraction (3 * job_length - 2 * now) / remaining_work by cross
+// CriticalRatio (dispatching.py:365-408): ratio = (factor * job_length - now) / remaining_work, smallest first, lowest
+// job index on ties; factor = p / q, by default 3 / 2.  Compared exactly as the fraction (p * job_length - q * now) / remaining_work by cross
 // multiplication in int64: two different such fractions differ by > 1e-13 relative, far above a double's 1.1e-16, so
 // the order (and the ties) are the ones the reference's float comparison sees.
 struct CrKey {
     int num, den, idx;
 };
+// due-date factor p / q carried in the `kind` argument (include/jss_hip.h JSS_POLICY_CR_FACTOR); none = the default 3 / 2
+__device__ __forceinline__ int cr_p(const Params &p) { return ((p.kind >> 8) & 0xFF) ? ((p.kind >> 8) & 0xFF) : 3; }
+__device__ __forceinline__ int cr_q(const Params &p) { return ((p.kind >> 8) & 0xFF) ? ((p.kind >> 16) & 0xFF) : 2; }
 __device__ __forceinline__ bool cr_better(const CrKey &a, const CrKey &b) {
     const long long l = (long long)a.num * b.den, r = (long long)b.num * a.den;
     return l < r || (l == r && a.idx < b.idx);

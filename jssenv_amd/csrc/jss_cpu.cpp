@@ -385,7 +385,9 @@ int select_action(const Env &e, const Call &c, uint64_t env_id) {
     const int nl = n_legal(e);
     const int n = nl + e.noop();
     if (n == 0) return -1;
-    if (c.kind == JSS_POLICY_RANDOM) {                                    // README.md:58-60 uniform over the mask's set bits
+    const int kind = c.kind & 0xFF;                                       // bits 8-23: CriticalRatio's due-date factor p / q (0 = 3 / 2)
+    const long long cr_p = ((c.kind >> 8) & 0xFF) ? ((c.kind >> 8) & 0xFF) : 3, cr_q = ((c.kind >> 8) & 0xFF) ? ((c.kind >> 16) & 0xFF) : 2;
+    if (kind == JSS_POLICY_RANDOM) {                                      // README.md:58-60 uniform over the mask's set bits
         int pick = (int)(((uint64_t)rng_u32(c.seed, env_id, episode, step) * (uint32_t)n) >> 32);
         for (int j = 0; j < e.J; ++j)
             if (e.legal(j) && pick-- == 0) return j;
@@ -398,8 +400,8 @@ int select_action(const Env &e, const Call &c, uint64_t env_id) {
     for (int j = 0; j < e.J; ++j) {
         if (!e.legal(j)) continue;
         const int todo = e.todo(j);
-        if (c.kind == JSS_POLICY_CR) {                                    // dispatching.py:365-408, (3 L - 2 t) / remaining
-            const long long num = 3LL * e.rem[j * e.stride] - 2LL * e.t(), den = e.rem[j * e.stride + todo];
+        if (kind == JSS_POLICY_CR) {                                      // dispatching.py:365-408, (p L - q t) / remaining
+            const long long num = cr_p * e.rem[j * e.stride] - cr_q * e.t(), den = e.rem[j * e.stride + todo];
             if (best < 0 || num * best_den < best_num * den) {
                 best = j;
                 best_num = num;
@@ -409,7 +411,7 @@ int select_action(const Env &e, const Call &c, uint64_t env_id) {
         }
         int v;
         bool larger = false;
-        switch (c.kind) {
+        switch (kind) {
         case JSS_POLICY_FIFO: v = e.w(j, JSS_F_IDLE_LAST); larger = true; break;      // :146
         case JSS_POLICY_SPT: v = e.cur(j) & kDurMask; break;                 // :105-106
         case JSS_POLICY_MWR: v = e.rem[j * e.stride + todo]; larger = true; break;    // :187-189
@@ -648,8 +650,12 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
     return 0;
 }
 
-int check_kind(const JssDesc *d, int kind) {
-    if (kind < 0 || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+int check_kind(const JssDesc *d, int kind_arg) {
+    const int kind = kind_arg & 0xFF, fp = (kind_arg >> 8) & 0xFF, fq = (kind_arg >> 16) & 0xFF;
+    if (kind_arg < 0 || (kind_arg >> 24) || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+    if (fp || fq) {                                  // a due-date factor p / q: CriticalRatio only, q a power of two <= 64
+        if (kind != JSS_POLICY_CR || fp < 1 || fq < 1 || fq > 64 || (fq & (fq - 1))) return JSS_E_KIND;
+    }
     if ((kind == JSS_POLICY_MWR || kind == JSS_POLICY_LWR || kind == JSS_POLICY_CR) && !d->rem) return JSS_E_NULL;
     return 0;
 }

@@ -35,8 +35,12 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
     return 0;
 }
 
-int check_kind(const JssDesc *d, int kind) {
-    if (kind < 0 || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+int check_kind(const JssDesc *d, int kind_arg) {
+    const int kind = kind_arg & 0xFF, fp = (kind_arg >> 8) & 0xFF, fq = (kind_arg >> 16) & 0xFF;
+    if (kind_arg < 0 || (kind_arg >> 24) || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+    if (fp || fq) {                                  // a due-date factor p / q: CriticalRatio only, q a power of two <= 64
+        if (kind != JSS_POLICY_CR || fp < 1 || fq < 1 || fq > 64 || (fq & (fq - 1))) return JSS_E_KIND;
+    }
     if ((kind == JSS_POLICY_MWR || kind == JSS_POLICY_LWR || kind == JSS_POLICY_CR) && !d->rem) return JSS_E_NULL;
     return 0;
 }

@@ -465,7 +465,7 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G, TAB> &c, const P
 template <int G, int TAB>
 __device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, uint64_t env_id,
                                         uint32_t episode, uint32_t step) {
-    const int kind = p.kind;
+    const int kind = p.kind & 0xFF;
     const uint32_t lm = grp_ballot<G>(e.legal, c.gbase);
     const int nl = __popc(lm);
     const int n = nl + (e.noop ? 1 : 0);
@@ -483,7 +483,7 @@ __device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G, TAB> &c,
             const int total = e.legal ? rem[0] : 0;                      // dispatching.py:373 job length
             const int remaining = e.legal ? rem[e.todo] : 1;             // :391
             CrKey key;
-            key.num = e.legal ? 3 * total - 2 * e.t : 0x3fffffff;
+            key.num = e.legal ? cr_p(p) * total - cr_q(p) * e.t : 0x3fffffff;
             key.den = remaining;
             key.idx = e.legal ? c.gl : kCrNone;
             key = cr_argmin<G>(key);

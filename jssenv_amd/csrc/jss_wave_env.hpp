@@ -321,7 +321,7 @@ __device__ __forceinline__ void check_no_op(Env<JPL> &e, const Ctx &c) {
         for (int i = 0; i < 4; ++i) {
             cf[i] = -1;
             if (i < nl) {
-                if (b0) {
+                if (JPL == 1 || b0) {                                    // (one slot: i < nl says a bit is left)
                     const int l = __ffsll((unsigned long long)b0) - 1;
                     b0 &= b0 - 1;
                     cf[i] = __builtin_amdgcn_readlane(e.cur[0], l);
@@ -476,7 +476,7 @@ __device__ __forceinline__ int nth_set_bit(uint64_t mask, int n, int lane) {
 template <int JPL>
 __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, const Params &p, uint64_t env_id,
                                              uint32_t episode, uint32_t step) {
-    const int kind = p.kind;
+    const int kind = p.kind & 0xFF;
     const int nl = nb_legal(e);
     const int n = nl + (e.noop ? 1 : 0);
     if (n == 0) return -1;
@@ -512,7 +512,7 @@ __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, co
             const int j = s * kWave + c.lane;
             const bool lg = (e.legal[s] >> c.lane) & 1;
             CrKey key;
-            key.num = lg ? 3 * rem[j * c.stride] - 2 * e.t : 0x3fffffff; // :373 job length
+            key.num = lg ? cr_p(p) * rem[j * c.stride] - cr_q(p) * e.t : 0x3fffffff; // :373 job length
             key.den = lg ? rem[j * c.stride + e.todo[s]] : 1;            // :391 remaining work
             key.idx = lg ? j : kCrNone;
             if (cr_better(key, best)) best = key;
@@ -857,11 +857,13 @@ struct StepResult {
     int rn;
     bool called, restart, done;
 };
-template <int JPL, int TAB, bool WT>
+// RESTART = false: the caller has routed JSS_ACTION_RESET elsewhere (jss_step sends such envs through the reset body:
+// the step path then carries none of the restart's live values -- SGPRs are what the one-wavefront-per-env kernels run out of)
+template <int JPL, int TAB, bool WT, bool RESTART = true>
 __device__ __forceinline__ StepResult step_compute(Env<JPL> &e, Header &hd, Ctx &c, const Params &p, const int32_t *lds, int a_in) {
     StepResult r;
-    r.restart = a_in == JSS_ACTION_RESET;                                // reset() this env instead of stepping it
-    if (r.restart) {
+    r.restart = RESTART && a_in == JSS_ACTION_RESET;                     // reset() this env instead of stepping it
+    if (RESTART && r.restart) {
         // the env may have been given another instance since its last reset (table_of_env)
         const int tid = tab_in_lds(TAB) ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[c.b] : c.tid);
         ctx_from_instance(c, p, tid);
@@ -934,14 +936,17 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
         ctx_table<TAB>(c, p, lds);
         hd.episode = __builtin_amdgcn_readfirstlane(h.episode);
         hd.step = __builtin_amdgcn_readfirstlane(h.step);
+        if (MODE == kStep || MODE == kAdvance) {                         // no policy keys an RNG with them here: only the header
+            hd.episode = in_vgpr(hd.episode);                            // store at the very end reads them -- out of the scalar
+            hd.step = in_vgpr(hd.step);                                  // register file, which these kernels run out of
+        }
         unpack_env<JPL, TAB>(e, c, raw, __builtin_amdgcn_readfirstlane(h.clock), __builtin_amdgcn_readfirstlane(h.status),
                              reinterpret_cast<int32_t *>(scratch));
     }
 
-    if (MODE == kStep) {
-        int rn;
-        bool called;
-        fresh = step_call<JPL, TAB, false>(e, hd, c, p, lds, a_in, rn, called);
+    if (MODE == kStep) {                                                 // (JSS_ACTION_RESET never gets here: jss_kernel)
+        const StepResult r = step_compute<JPL, TAB, false, false>(e, hd, c, p, lds, a_in);
+        step_outputs<JPL, false>(e, c, p, r);
     } else if (MODE == kSteps) {
         // n_iter x jss_step with the actions given up front: the state stays in registers, every step optionally recorded
         for (int it = 0; it < p.n_iter; ++it) {
@@ -1084,10 +1089,16 @@ __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel
         const int tid = tab_in_lds(TAB) ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : b);
         ctx_from_instance(c, p, tid);
         wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);   // full width: a reset writes every row of the padded block
+    } else if (MODE == kStep && a_in == JSS_ACTION_RESET) {
+        // jss_step's "reset this env instead of stepping it" IS a reset: nothing of the old state is needed but the episode
+        // counter, and the env may have been handed another (wider) instance since (table_of_env) -- the reset body, full width
+        if (__builtin_amdgcn_readfirstlane(h.J) == 0) return;            // never reset: left alone, like by every step-type call
+        const int tid = tab_in_lds(TAB) ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : h.tid);
+        ctx_from_instance(c, p, tid);
+        wave_main<JPL, kReset, TAB>(p, c, h, ragged, a_in, lds, scratch);
     } else {
-        // (a restart may hand the env a wider instance: it takes the full-width body)
         // (J == 64 stays on the full-width body: the NOPE flag of its mask row lives at index 64, slot 1's first lane)
-        if (JPL == 2 && ragged && MODE != kSteps && !(MODE == kStep && a_in == JSS_ACTION_RESET) && __builtin_amdgcn_readfirstlane(h.J) < kWave)
+        if (JPL == 2 && ragged && MODE != kSteps && __builtin_amdgcn_readfirstlane(h.J) < kWave)
             wave_main<1, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
         else
             wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);

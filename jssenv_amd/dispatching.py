@@ -82,7 +82,7 @@ class DispatchingRule:
         if device_rng:
             if self.kind is None or not hasattr(env, "_b") or not _device_rule_ok(self):
                 raise ValueError("device_rng=True needs a jssenv_amd.JssEnv and a rule with an on-device selector")
-            return env._run_rule(self.kind, explore=EXPLORATION_PROBABILITY, seed=seed)
+            return env._run_rule(device_kind(self), explore=EXPLORATION_PROBABILITY, seed=seed)
         env.reset()
         done = False
         total_reward = 0.0
@@ -94,8 +94,19 @@ class DispatchingRule:
 
 
 def _device_rule_ok(rule) -> bool:
-    """CriticalRatio's device selector is the default due-date factor only."""
-    return getattr(rule, "due_date_factor", 1.5) == 1.5
+    """CriticalRatio's device selector takes due-date factors p / q with q a power of two (exact in the reference's
+    doubles); any other factor stays on the host."""
+    return device_kind(rule) is not None
+
+
+def device_kind(rule):
+    """What the device entry points take as `kind` for this rule (None: no on-device selector)."""
+    if rule.kind is None:
+        return None
+    if hasattr(rule, "due_date_factor"):
+        from ._abi import cr_kind
+        return cr_kind(rule.due_date_factor)
+    return rule.kind
 
 
 def _remaining_work(env, job: int) -> int:                                # dispatching.py:187-189
@@ -181,15 +192,20 @@ class CriticalRatio(DispatchingRule):                                     # disp
         return self._due_dates[job]
 
     def _best_job(self, env, legal_actions) -> int:
-        # the device selector compares (3 * job_length - 2 * now) / remaining, i.e. a due-date factor of exactly 1.5;
-        # any other factor takes the host loop
-        if self.due_date_factor != 1.5:
-            saved, self.kind = self.kind, None
-            try:
-                return super()._best_job(env, legal_actions)
-            finally:
-                self.kind = saved
-        return super()._best_job(env, legal_actions)
+        # on a jssenv_amd env the arg-min comes from the host snapshot of the step (the reference's float expression,
+        # vectorised) or from the device selector, which compares (p * job_length - q * now) / remaining exactly for
+        # factors p / q with q a power of two; any other factor takes the loop below
+        if hasattr(env, "_rule_best"):
+            return env._rule_best("CR", legal_actions, due_date_factor=self.due_date_factor)
+        code = device_kind(self)
+        if code is not None and hasattr(env, "_policy"):
+            a = env._policy(code)
+            return a if a < env.jobs else -1
+        saved, self.kind = self.kind, None
+        try:
+            return super()._best_job(env, legal_actions)
+        finally:
+            self.kind = saved
 
     def _value(self, env, job):
         remaining = _remaining_work(env, job)
@@ -250,7 +266,7 @@ def compare_rules(env, rules: Optional[List[str]] = None, num_episodes: int = 10
             batch.reset()
             batch.zero_counters()
             for _ in range(64):
-                batch.rollout(get_rule(name).kind, n_iter=chunk, autoreset=False, explore=EXPLORATION_PROBABILITY)
+                batch.rollout(device_kind(get_rule(name)), n_iter=chunk, autoreset=False, explore=EXPLORATION_PROBABILITY)
                 if bool(batch.backend.numpy(batch.done).all()):
                     break
             else:

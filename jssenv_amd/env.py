@@ -63,11 +63,21 @@ class HipBackend:
     def from_numpy(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
+    def zeros_pinned(self, shape, dtype):
+        """Zero-filled page-locked HOST memory the device reads and writes in place (hipHostMalloc: coherent, uncached on
+        the GPU): a tensor on the CPU whose data_ptr() the kernels take like any other -- the B = 1 facade's arena."""
+        return self.torch.zeros(shape, dtype=getattr(self.torch, dtype), pin_memory=True)
+
     def ptr(self, x):
         return 0 if x is None else x.data_ptr()
 
     def numpy(self, x):
-        return x if isinstance(x, np.ndarray) else x.detach().cpu().numpy()   # (host-derived attributes are NumPy already)
+        if isinstance(x, np.ndarray):              # (host-derived attributes are NumPy already)
+            return x
+        if x.device.type == "cpu":                 # a view of a host arena: the kernels write it in place -- wait, then copy
+            self.sync()
+            return x.detach().numpy().copy()
+        return x.detach().cpu().numpy()
 
     def as_device(self, x, dtype):
         t = self.torch.as_tensor(x, device=self.device)
@@ -314,7 +324,7 @@ class BatchedJssEnv:
 
     def __init__(self, instances, batch: Optional[int] = None, device=None, env_id_base: int = 0,
                  table_of_env: Optional[Sequence[int]] = None, seed: int = 0, kernel: Optional[str] = None,
-                 compact: Optional[bool] = None, _backend=None):
+                 compact: Optional[bool] = None, host_arena: bool = False, _backend=None):
         self._owns_backend = _backend is None
         self.backend = be = _backend if _backend is not None else make_backend(device)
         if isinstance(instances, PackedBatch):
@@ -381,13 +391,18 @@ class BatchedJssEnv:
             for name, shape, dtype in specs:
                 self._layout[name] = (off, shape, dtype)
                 off += (int(np.prod(shape)) * np.dtype(dtype).itemsize + 255) & ~255
-            self._arena = be.zeros((off,), "uint8")
+            # host_arena (tiny batches: the B = 1 facade): state and outputs live in page-locked HOST memory that the kernels
+            # read and write in place over PCIe -- a step is one launch and one stream synchronisation, no copy either way
+            self.host_arena = bool(host_arena) and hasattr(be, "zeros_pinned")
+            self._arena = be.zeros_pinned((off,), "uint8") if self.host_arena else be.zeros((off,), "uint8")
             carve = getattr(be, "carve", None) or (lambda a, o, sh, dt: _carve_numpy(a, o, sh, dt))
             for name, (o, shape, dtype) in self._layout.items():
                 setattr(self, name, carve(self._arena, o, shape, dtype))
             self._host_arena = None
             self._host_views = None
             self._stream_events = {}                             # fork / join events of rollout_steps, owned by this env
+            if self.host_arena:                                  # (atomics across PCIe are not something to lean on: the
+                self.counters = be.zeros((B, 4), "int64")        #  counters stay in device memory)
             self.solution = be.zeros((B, J, M), "int32")         # the one large, rarely read tensor stays on its own
             if hasattr(be, "scalar"):
                 be.scalar(_abi.ACTION_RESET, "int32")
@@ -521,7 +536,7 @@ class BatchedJssEnv:
         if not self._is_reset:
             raise RuntimeError("call reset() before policy()")
         be = self.backend
-        k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
+        k = _abi.policy_code(kind)
         d, s, _ = self._refs()
         with be.on_device():
             _abi.check(be.lib, be.lib.jss_policy(d, s, k, self.seed if seed is None else int(seed),
@@ -535,7 +550,7 @@ class BatchedJssEnv:
         if not self._is_reset:
             raise RuntimeError("call reset() before rollout()")
         be = self.backend
-        k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
+        k = _abi.policy_code(kind)
         flags = _abi.ROLLOUT_AUTORESET if autoreset else 0
         d, s, o = self._refs()
         with be.on_device():
@@ -555,7 +570,7 @@ class BatchedJssEnv:
         if not 1 <= int(n_sub) <= _abi.MAX_SUB_BATCHES:
             raise ValueError(f"n_sub must be in [1, {_abi.MAX_SUB_BATCHES}]")
         be = self.backend
-        k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
+        k = _abi.policy_code(kind)
         flags = _abi.ROLLOUT_AUTORESET if autoreset else 0
         d, s, o = self._refs()
         sd = self.seed if seed is None else int(seed)
@@ -582,7 +597,7 @@ class BatchedJssEnv:
         be = self.backend
         if not hasattr(be, "stream_array"):
             return lambda: self.rollout_steps(kind, steps, n_sub, seed, autoreset, explore)
-        k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
+        k = _abi.policy_code(kind)
         flags = (_abi.ROLLOUT_AUTORESET if autoreset else 0) | (0 if caller_orders_streams else _abi.ROLLOUT_FORK_JOIN)
         d, s, o = self._refs()
         with be.on_device():
@@ -620,7 +635,7 @@ class BatchedJssEnv:
                 shape, dtype = shapes[name]
                 t = None if buffers is None else buffers.get(name)
                 out[name] = t if t is not None and tuple(t.shape) == shape else be.zeros(shape, dtype)
-        k = _abi.POLICY[kind] if isinstance(kind, str) else int(kind)
+        k = _abi.policy_code(kind)
         flags = _abi.ROLLOUT_AUTORESET if autoreset else 0
         traj = _abi.JssTraj(*[be.ptr(out.get(n)) for n in ("real_obs", "action_mask", "action", "reward", "done")])
         d, s, o = self._refs()
@@ -702,6 +717,8 @@ class BatchedJssEnv:
 
     def clear_errors(self):
         """Clear the sticky per-env error bits (the NOPE flag in the same word is kept)."""
+        if getattr(self, "host_arena", False):
+            self.backend.sync()                    # host memory the kernels work on in place: nothing may be in flight
         self.env_header[:, _abi.H_STATUS] &= ~0xFF
 
     @property
@@ -842,6 +859,7 @@ class BatchedJssEnv:
             raise ValueError(f"checkpoint was written by envs with other global ids (env_id_base {int(m['env_id_base'])} "
                              f"vs {self.env_id_base}, or different set_env_ids): the RNG streams would not continue")
         with self.backend.on_device():
+            self.backend.sync()
             for k in self._saved_tensors():
                 self.backend.copy_into(getattr(self, k), np.asarray(d[k]))
         self.seed, self._is_reset = int(m["seed"]), True
@@ -893,6 +911,13 @@ class BatchedJssEnv:
         """NumPy copies of the state and output tensors (not ``solution``).  A small batch comes over in ONE
         device -> host copy of the arena they were carved from."""
         be = self.backend
+        if getattr(self, "host_arena", False):        # the arena IS host memory: wait for the kernels, look at it
+            be.sync()
+            if self._host_views is None:
+                flat = self._arena.numpy()
+                self._host_views = {k: _carve_numpy(flat, o, sh, dt) for k, (o, sh, dt) in self._layout.items() if not k.startswith("_")}
+                self._host_views["counters"] = _LazyRows(lambda: be.numpy(self.counters))   # device memory: fetched when read
+            return self._host_views
         if self.batch <= 64 and hasattr(be, "snapshot"):
             with be.on_device():
                 host, flat = be.snapshot(self._arena, self._host_arena)
@@ -940,6 +965,16 @@ class BatchedJssEnv:
         if with_solution:
             out["solution"] = n(self.solution[i])[:J, :M].astype(np.int64)
         return out
+
+
+class _LazyRows:
+    """rows[i] of an array that is only fetched (from the device) when somebody indexes it."""
+
+    def __init__(self, fetch):
+        self._fetch = fetch
+
+    def __getitem__(self, i):
+        return self._fetch()[i]
 
 
 class _Snap:
@@ -1030,12 +1065,16 @@ class JssEnv(gymnasium_base("Env")):
         self.sum_op = inst.sum_op                                          # :88
         self.last_time_step = float("inf")                                 # :53
         self.last_solution = None                                          # :52
-        self._b = BatchedJssEnv([inst], batch=1, device=device, _backend=_backend)
+        # on the GPU the env's arena (state + outputs, ~1 KB) lives in page-locked host memory the kernel works on in
+        # place: step() = one launch + one stream synchronisation, nothing is copied (JSSENV_AMD_HOST_ARENA=0: device
+        # memory and one device -> host copy per step, the round-3 form)
+        self._b = BatchedJssEnv([inst], batch=1, device=device, _backend=_backend,
+                                host_arena=os.environ.get("JSSENV_AMD_HOST_ARENA", "1") != "0")
         self._cache = None
         self._act = np.zeros(1, dtype=np.int32)
         # remaining work of job j from op k on (MWR / LWR / CR on the host): suffix sums of the durations
         self._remaining = np.cumsum(inst.duration[:, ::-1], axis=1)[:, ::-1].astype(np.int64)
-        self._act_pinned, self._zero_copy = None, False
+        self._act_pinned, self._zero_copy, self._act_np = None, False, None
         be = self._b.backend
         if getattr(be, "name", "") == "hip":
             self._act_pinned = be.torch.zeros(1, dtype=be.torch.int32).pin_memory()
@@ -1138,7 +1177,13 @@ class JssEnv(gymnasium_base("Env")):
     def step(self, action):
         """jss_env.py:403-481."""
         action = int(action)
-        if self._act_pinned is not None:           # GPU: the action goes out through a pinned word, nothing is allocated
+        if getattr(self._b, "host_arena", False):  # GPU, arena in host memory: the action word is part of it
+            b = self._b
+            if self._act_np is None:
+                self._act_np = b._act_in.numpy()
+            self._act_np[0] = action
+            b.step_raw(b._act_in.data_ptr())
+        elif self._act_pinned is not None:         # GPU: the action goes out through a pinned word, nothing is allocated
             self._act_pinned[0] = action
             b = self._b
             if self._zero_copy:                    # the kernel reads the pinned word itself
@@ -1195,7 +1240,7 @@ class JssEnv(gymnasium_base("Env")):
         self.last_solution = self._solution()
         return float(h["counters"][3]) / self.max_time_op, h["clock"]
 
-    def _rule_best(self, kind, legal_actions):
+    def _rule_best(self, kind, legal_actions, due_date_factor: float = 1.5):
         """arg-best of a dispatching rule over the legal jobs from the host snapshot of this step (dispatching.py's
         strict comparisons: the lowest job index wins ties); -1 when no job is legal.  Same selectors as the device's
         jss_policy (tests hold the two to each other)."""
@@ -1218,7 +1263,7 @@ class JssEnv(gymnasium_base("Env")):
                 key = -rem
             elif kind == "CR":     # smallest (1.5 * job length - now) / remaining work, as the reference's floats (:391-398)
                 with np.errstate(divide="ignore"):
-                    key = -np.where(rem > 0, (1.5 * self._remaining[:, 0] - self._h()["clock"]) / np.maximum(rem, 1), np.inf)
+                    key = -np.where(rem > 0, (self._remaining[:, 0] * due_date_factor - self._h()["clock"]) / np.maximum(rem, 1), np.inf)
             else:
                 raise KeyError(kind)
         key = np.where(legal, key, -np.inf)

@@ -667,9 +667,9 @@ def case_dispatching_on_device(backend, inst="ta01", rules=("SPT", "FIFO", "MWR"
     a = D.compare_rules(env, ["SPT"], num_episodes=3)
     np.random.seed(3)
     assert a == D.compare_rules(env, ["SPT"], num_episodes=3)           # np.random.seed still makes it reproducible
-    try:
-        D.CriticalRatio(due_date_factor=2.0).run_episode(env, device_rng=True)
-        raise AssertionError("a custom due-date factor has no device selector")
+    try:      # 1.2 is no p / q with q a power of two: no exact device comparison, the host loop serves it
+        D.CriticalRatio(due_date_factor=1.2).run_episode(env, device_rng=True)
+        raise AssertionError("a due-date factor that is not dyadic has no device selector")
     except ValueError:
         pass
 
@@ -1369,3 +1369,56 @@ def case_session_emulator(backend, kw=None, K=14, kind="random", seed=5, warm=20
     for name in want:
         assert np.array_equal(got[name], want[name]), f"session (emulator, slots {status[3]}): {name} differs from {K} x jss_step"
     return status
+
+
+def case_cr_due_date_factor(backend, factors=(2.0, 0.5, 1.25), inst="ta01", batch=6, steps=260, seed=4):
+    """CriticalRatio(due_date_factor = p / q) on the device (the factor travels in the `kind` argument, exact fraction
+    comparison) picks, state by state, the job the reference's float expression picks (dispatching.py:365-408, here the
+    package's rule class running its host loop on the oracle env)."""
+    from jssenv_amd import dispatching as D
+    assert _abi.cr_kind(1.5) == _abi.POLICY["CR"] and _abi.cr_kind(1.2) is None and _abi.cr_kind(1000.0) is None
+    assert _abi.cr_kind(0.5) == _abi.POLICY["CR"] | (1 << 8) | (2 << 16)
+    real = np.random.random
+    np.random.random = lambda *a, **k: 1.0               # no NOPE exploration on the host side
+    try:
+        for factor in factors:
+            code = _abi.cr_kind(factor)
+            assert code is not None
+            env = BatchedJssEnv(inst, batch=batch, seed=seed, _backend=backend)
+            orcs = [OracleEnv(I.builtin_instance(inst), strict=True) for _ in range(batch)]
+            rules = [D.CriticalRatio(due_date_factor=factor) for _ in range(batch)]
+            env.reset()
+            for o in orcs:
+                o.reset()
+            rng = np.random.default_rng(seed)
+            for st in range(steps):
+                dev = np.asarray(env.backend.numpy(env.policy(code)))
+                acts = []
+                for i, o in enumerate(orcs):
+                    if o.nb_legal_actions == 0:
+                        acts.append(_abi.ACTION_SKIP)
+                        continue
+                    want = rules[i](o)
+                    assert dev[i] == want, f"factor {factor} step {st} env {i}: device {dev[i]} vs host {want}"
+                    # every few steps another legal action instead, so that the envs drift apart
+                    if st % 5 == i % 5:
+                        want = int(rng.choice(np.flatnonzero(o.legal_actions)))
+                    o.step(want)
+                    acts.append(want)
+                env.step(np.asarray(acts, dtype=np.int32))
+        # the facade: run_episode through the fused device path == the host path of the same rule
+        for factor in factors[:1]:
+            rule = D.CriticalRatio(due_date_factor=factor)
+            env1 = JssEnv({"instance_path": inst}, _backend=backend)
+            _, mk_host = rule.run_episode(env1)
+            _, mk_dev = D.CriticalRatio(due_date_factor=factor).run_episode(env1, device_rng=False)
+            assert mk_host == mk_dev
+            if hasattr(env1, "_run_rule"):
+                real_explore, D.EXPLORATION_PROBABILITY = D.EXPLORATION_PROBABILITY, 0.0
+                try:
+                    _, mk_fused = D.CriticalRatio(due_date_factor=factor).run_episode(env1, device_rng=True, seed=1)
+                finally:
+                    D.EXPLORATION_PROBABILITY = real_explore
+                assert mk_fused == mk_host, (factor, mk_fused, mk_host)
+    finally:
+        np.random.random = real

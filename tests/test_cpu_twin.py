@@ -242,3 +242,7 @@ def test_steps_and_step_session(cpu):
     P.case_steps(cpu, dict(instances=["ta01", "ta31", "ta71"], batch=11), K=40, kind="SPT", warm=5)
     P.case_session(cpu, dict(instances="ta01", batch=50), K=36)
     P.case_session(cpu, dict(instances=["ta02", "ta51"], batch=7), K=20, kind="FIFO")
+
+
+def test_critical_ratio_due_date_factor_on_device(cpu):
+    P.case_cr_due_date_factor(cpu)

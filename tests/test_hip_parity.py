@@ -348,3 +348,7 @@ def test_step_session_gives_up_instead_of_hanging(hip_auto):
     after = P._state_snapshot(env)
     for name in before:
         assert np.array_equal(before[name], after[name]), name
+
+
+def test_critical_ratio_due_date_factor_on_device(hip):
+    P.case_cr_due_date_factor(hip)

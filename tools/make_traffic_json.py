@@ -57,6 +57,15 @@ def main(rnd):
         out[key] = {"kernel": label, "fetch_size_kib": fetch, "write_size_kib": write, "bytes_per_launch": int(b),
                     "algorithmic_bytes_per_launch_if_every_env_steps": int(a), "ratio": round(b / a, 3),
                     "source": f"{rnd}_{suffix}/pmc_fetch_summary.csv + pmc_write_summary.csv", "round": rnd, "csrc_sha16": sha}
+        try:      # wave-cycles per env step and the share of them spent waiting (SQ_WAVE_CYCLES, SQ_WAIT_ANY)
+            pm = os.path.join(d, "pmc_pmc1_summary.csv")
+            cyc, wait, waves = counter(pm, kern, "SQ_WAVE_CYCLES"), counter(pm, kern, "SQ_WAIT_ANY"), counter(pm, kern, "SQ_WAVES")
+            out[key].update(sq_wave_cycles_per_launch=cyc, sq_wait_any_per_launch=wait, sq_waves_per_launch=waves,
+                            wave_cycles_per_env_step=round(cyc / batch, 1), wait_fraction=round(wait / cyc, 3),
+                            valu_per_wave=round(counter(pm, kern, "SQ_INSTS_VALU") / waves, 1),
+                            salu_per_wave=round(counter(pm, kern, "SQ_INSTS_SALU") / waves, 1))
+        except (OSError, KeyError, ZeroDivisionError) as exc:
+            print("no pmc1 for", key, exc)
     with open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps({k: v.get("ratio") for k, v in out.items() if k != "_note"}))
