@@ -571,8 +571,8 @@ def main():
         out = {}
         try:
             B = env.batch
-            K = int(max(5, min(K, 50)))
-            n_win = int(max(6, min(60, 256e6 // (K * B * 4))))
+            K = 32                                        # steps per launch / per wait: the trajectory figure's K
+            n_win = int(max(6, min(40, 256e6 // (K * B * 4))))
             env.zero_counters()
             snap = env._arena.clone(), env.solution.clone()
 

@@ -1221,7 +1221,8 @@ __global__ __launch_bounds__(kBlock, JPL == 1 ? 6 : 4) void jss_session_kernel(P
                     pending = 0;
                 }
                 if (spins < 32u) __builtin_amdgcn_s_sleep(2);       // a few quick looks, then back off: thousands of wavefronts
-                else __builtin_amdgcn_s_sleep(16);                  // polling flat out would flood the fabric
+                else if (spins < 1024u) __builtin_amdgcn_s_sleep(16);   // polling flat out would flood the fabric; after ~0.5 ms
+                else __builtin_amdgcn_s_sleep(127);                 // of silence (the caller is busy elsewhere) one look per ~3 us
                 if ((++spins & 63u) == 0) {
                     const long long now = wall_clock64();
                     if (t0 == 0) t0 = now;

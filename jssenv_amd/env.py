@@ -675,9 +675,11 @@ class BatchedJssEnv:
         self._steps_keep = a                  # alive until the launch has read it
         return out
 
-    def session(self, depth: int = 16, timeout_ms: int = 2000, slots: int = 0):
+    def session(self, depth: int = 16, timeout_ms: int = 10000, slots: int = 0):
         """Open a step session (``jssenv_amd.session.StepSession``): the env state stays on the chip between steps, the
-        caller posts actions and waits for outputs.  Use as a context manager."""
+        caller posts actions and waits for outputs.  Use as a context manager.  ``timeout_ms`` bounds how long the resident
+        kernel waits for the next actions before it gives the session up (close it around anything longer, e.g. a
+        training phase)."""
         from .session import StepSession
         return StepSession(self, depth=depth, timeout_ms=timeout_ms, slots=slots)
 
@@ -1074,7 +1076,7 @@ class JssEnv(gymnasium_base("Env")):
         self._act = np.zeros(1, dtype=np.int32)
         # remaining work of job j from op k on (MWR / LWR / CR on the host): suffix sums of the durations
         self._remaining = np.cumsum(inst.duration[:, ::-1], axis=1)[:, ::-1].astype(np.int64)
-        self._act_pinned, self._zero_copy, self._act_np = None, False, None
+        self._act_pinned, self._zero_copy, self._fast = None, False, None
         be = self._b.backend
         if getattr(be, "name", "") == "hip":
             self._act_pinned = be.torch.zeros(1, dtype=be.torch.int32).pin_memory()
@@ -1178,11 +1180,7 @@ class JssEnv(gymnasium_base("Env")):
         """jss_env.py:403-481."""
         action = int(action)
         if getattr(self._b, "host_arena", False):  # GPU, arena in host memory: the action word is part of it
-            b = self._b
-            if self._act_np is None:
-                self._act_np = b._act_in.numpy()
-            self._act_np[0] = action
-            b.step_raw(b._act_in.data_ptr())
+            return self._step_host_arena(action)
         elif self._act_pinned is not None:         # GPU: the action goes out through a pinned word, nothing is allocated
             self._act_pinned[0] = action
             b = self._b
@@ -1201,6 +1199,37 @@ class JssEnv(gymnasium_base("Env")):
             self.last_time_step = h["clock"]
             self.last_solution = self._solution()
         return self._obs(), h["reward"], h["done"], False, {}
+
+    def _step_host_arena(self, action):
+        """step() when the env's arena is page-locked host memory: the action is written into it, ONE launch works on it
+        in place, one stream synchronisation (through the library: it also surfaces a kernel fault), and the results are
+        read where they lie.  Everything that does not change between calls is bound once."""
+        fp = self._fast
+        if fp is None:
+            b, be = self._b, self._b.backend
+            if not b._is_reset:
+                raise RuntimeError("call reset() before step()")
+            lib, (d, s, o) = be.lib, b._refs()
+            views = b.host_tensors()
+            fp = self._fast = (b._act_in.numpy(), lib.jss_step, lib.jss_sync_check, d, s, o, b._act_in.data_ptr(),
+                               be.torch.cuda.current_stream, be.device, views, lib, b)
+        act, jss_step, sync_check, d, s, o, a_ptr, current_stream, dev, views, lib, b = fp
+        act[0] = action
+        stream = current_stream(dev).cuda_stream
+        rc = jss_step(d, s, a_ptr, o, stream)
+        if rc == 0:
+            rc = sync_check(stream)
+        if rc:
+            _abi.check(lib, rc, "jss_step")
+        h = self._cache = _Snap(views, self.jobs, self.machines, b.decode_jobs)
+        err = h["err"]
+        if err:
+            self._raise_for(err, action)
+        done = h["done"]
+        if done:                                                            # :649-652
+            self.last_time_step = h["clock"]
+            self.last_solution = self._solution()
+        return {"real_obs": h["obs"], "action_mask": h["mask"]}, h["reward"], done, False, {}
 
     def increase_time_step(self):
         """jss_env.py:495-637 -- public in the reference and called directly by its tests."""

@@ -32,7 +32,7 @@ from . import _abi
 
 
 class StepSession:
-    def __init__(self, env, depth: int = 16, timeout_ms: int = 2000, slots: int = 0):
+    def __init__(self, env, depth: int = 16, timeout_ms: int = 10000, slots: int = 0):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         if not env._is_reset:
