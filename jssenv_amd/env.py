@@ -1276,7 +1276,18 @@ class JssEnv(gymnasium_base("Env")):
         legal = np.asarray(legal_actions[:self.jobs], dtype=bool)
         if not legal.any():
             return -1
-        js = self._h()["job_state"]
+        h = self._h()
+        if "job_state" not in h and kind in ("FIFO", "MOR", "LOR"):
+            # these rank on ONE word of the job records: read it where it lies instead of decoding every record
+            raw = h.t["job_state"][0][:self.jobs]
+            if kind == "FIFO":
+                key = raw[:, _abi.FC_IDLE_LAST if self._b.compact else _abi.F_IDLE_LAST].astype(np.float64)
+            else:
+                todo = raw[:, 0] & (_abi.FC_TODO_MASK if self._b.compact else _abi.TODO_MASK)
+                key = ((self.machines - todo) * (1 if kind == "MOR" else -1)).astype(np.float64)
+            key[~legal] = -np.inf
+            return int(np.argmax(key))
+        js = h["job_state"]
         todo = js[_abi.F_TODO]
         if kind == "FIFO":
             key = js[_abi.F_IDLE_LAST]
