@@ -326,8 +326,12 @@ int jss_steps(const JssDesc *desc, const JssState *state, const JssOut *out, con
  * While a session is open the caller synchronises its own streams, never the device (hipDeviceSynchronize would wait for
  * the resident kernel).  Every device-side wait is bounded: a wavefront that sees no mail for timeout_ms stores its state, bumps status[0] and
  * exits (the session is then dead: close it); a wait that times out bumps status[1].
- * Residency: the grid must fit the chip in ONE round with a workgroup slot per CU to spare for the caller's kernels;
- * jss_session_open picks the smallest number of env sets per wavefront (1, 2, 4, 8) that does, JSS_E_RESIDENT if none. */
+ * Residency: the grid must fit the chip in ONE round with room to spare for the caller's kernels (two workgroup slots per
+ * CU and 64 KB of its LDS stay free); jss_session_open picks the smallest number of env sets per wavefront (1, 2, 4, 8)
+ * that does, JSS_E_RESIDENT if none.  One session per device at a time: a second resident grid would not find the room
+ * the first one was promised.
+ * The env -> instance map (JssDesc.table_of_env) is fixed while a session is open: a JSS_ACTION_RESET restarts the env
+ * on the instance it has. */
 typedef struct JssSession {
     uint64_t *mail;      /* [depth][B] action granules; zero-filled by the caller before open                          */
     int32_t *progress;   /* [B] (one word per wavefront is used): steps published; zero-filled by the caller          */

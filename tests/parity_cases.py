@@ -1317,8 +1317,15 @@ def case_session(backend, kw=None, K=36, kind="random", seed=5, warm=20, depth=8
                 s.post(dev_acts[k:k + m])
                 s.wait()
             k += m
-            env.backend.sync()
             last = ref_out[k - 1]
+            if hasattr(env.backend, "torch"):
+                # what a learner does: KERNELS on the caller's stream read the outputs behind the wait (through the caches,
+                # which still hold the previous steps' lines of these very tensors), not a copy engine
+                t = env.backend.torch
+                for name in ("real_obs", "action_mask", "reward", "done"):
+                    same = t.equal(getattr(env, name), t.as_tensor(last[name], device=env.backend.device))
+                    assert same, f"session: a kernel behind wait() sees a stale {name} after step {k - 1}"
+            env.backend.sync()
             for name in ("real_obs", "action_mask", "reward", "done", "makespan", "solution"):
                 assert np.array_equal(n(getattr(env, name)), last[name]), f"session: {name} after step {k - 1} differs from jss_step"
         try:
@@ -1422,3 +1429,55 @@ def case_cr_due_date_factor(backend, factors=(2.0, 0.5, 1.25), inst="ta01", batc
                 assert mk_fused == mk_host, (factor, mk_fused, mk_host)
     finally:
         np.random.random = real
+
+
+def case_steps_and_session_edges(backend, emulator=False):
+    """Edges of the external-action forms: K = 0 and K = 1, a batch that does not fill its last wavefront, envs that
+    were never reset (partial reset: every step-type call leaves them alone, the session too)."""
+    import ctypes as C
+    env = BatchedJssEnv("ta01", batch=11, seed=2, _backend=backend)
+    which = np.ones(11, dtype=np.uint8)
+    which[[3, 10]] = 0                                       # envs 3 and 10 are never reset
+    env.reset(which=which)
+    before = _state_snapshot(env)
+    env.steps(np.zeros((0, 11), dtype=np.int32))             # K = 0: nothing happens
+    env.synchronize()
+    after = _state_snapshot(env)
+    for name in before:
+        assert np.array_equal(before[name], after[name]), f"jss_steps with K = 0 changed {name}"
+    ref = BatchedJssEnv("ta01", batch=11, seed=2, _backend=backend)
+    ref.reset(which=which)
+    rng = np.random.default_rng(0)
+    acts = rng.integers(0, 16, size=(7, 11)).astype(np.int32)        # whatever: legal or not, NOPEs included
+    for k in range(7):
+        ref.step(acts[k])
+    want = _state_snapshot(ref)
+    env.steps(acts[:1])
+    env.steps(acts[1:])
+    env.synchronize()
+    got = _state_snapshot(env)
+    for name in want:
+        assert np.array_equal(got[name], want[name]), f"jss_steps (1 + 6 steps, never-reset envs) differs in {name}"
+    assert not got["env_header"][[3, 10]].any() and not got["counters"][[3, 10]].any()
+    # the same through a session
+    env2 = BatchedJssEnv("ta01", batch=11, seed=2, _backend=backend)
+    env2.reset(which=which)
+    if emulator:
+        lib = backend.lib
+        mail, progress, status = np.zeros((8, 11), dtype=np.int64), np.zeros(11, dtype=np.int32), np.zeros(4, dtype=np.int32)
+        sess = _abi.JssSession(mail.ctypes.data, progress.ctypes.data, status.ctypes.data, 8, 2000, 2, 0)
+        d, s, o = env2._refs()
+        a = np.ascontiguousarray(acts)
+        _abi.check(lib, lib.jss_session_post(d, C.byref(sess), a.ctypes.data, 0, 7, 0, 0), "post")
+        _abi.check(lib, lib.jss_session_close(d, C.byref(sess), 7, 0), "close")
+        _abi.check(lib, lib.jss_session_open(d, s, o, C.byref(sess), 0), "open")
+        assert status[0] == 0 and status[2] > 0
+    else:
+        with env2.session(depth=4, slots=2) as s:
+            s.post(acts[:3])
+            s.wait()
+            for k in range(3, 7):
+                s.step(acts[k])
+    got = _state_snapshot(env2)
+    for name in want:
+        assert np.array_equal(got[name], want[name]), f"session (never-reset envs, ragged last wavefront) differs in {name}"

@@ -246,3 +246,7 @@ def test_steps_and_step_session(cpu):
 
 def test_critical_ratio_due_date_factor_on_device(cpu):
     P.case_cr_due_date_factor(cpu)
+
+
+def test_steps_and_session_edges(cpu):
+    P.case_steps_and_session_edges(cpu)

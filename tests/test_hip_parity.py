@@ -352,3 +352,7 @@ def test_step_session_gives_up_instead_of_hanging(hip_auto):
 
 def test_critical_ratio_due_date_factor_on_device(hip):
     P.case_cr_due_date_factor(hip)
+
+
+def test_steps_and_session_edges(hip):
+    P.case_steps_and_session_edges(hip)

@@ -155,3 +155,7 @@ def test_step_session_times_out_instead_of_hanging(emu):
 
 def test_critical_ratio_due_date_factor_on_device(emu):
     P.case_cr_due_date_factor(emu, steps=60, batch=3, factors=(2.0, 0.5))
+
+
+def test_steps_and_session_edges(emu):
+    P.case_steps_and_session_edges(emu, emulator=True)
