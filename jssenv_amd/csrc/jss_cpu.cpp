@@ -752,8 +752,9 @@ int jss_steps(const JssDesc *desc, const JssState *state, const JssOut *out, con
               int32_t n_steps, void *) {
     int rc = check_args(desc, state, out, true);
     if (rc) return rc;
-    if (!actions) return JSS_E_NULL;
     if (n_steps < 0) return JSS_E_SHAPE;
+    if (n_steps == 0) return 0;                       // nothing to do (an empty action buffer has no address)
+    if (!actions) return JSS_E_NULL;
     Call c;
     c.d = *desc; c.s = *state; c.o = *out; c.actions = actions; c.n_iter = n_steps;
     if (traj) c.t = *traj;

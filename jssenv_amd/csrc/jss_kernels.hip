@@ -427,8 +427,9 @@ int jss_steps(const JssDesc *desc, const JssState *state, const JssOut *out, con
               int32_t n_steps, void *stream) {
     int rc = check_args(desc, state, out, true);
     if (rc) return rc;
-    if (!actions) return JSS_E_NULL;
     if (n_steps < 0) return JSS_E_SHAPE;
+    if (n_steps == 0) return 0;                       // nothing to do (an empty action buffer has no address)
+    if (!actions) return JSS_E_NULL;
     Params p = {};
     p.d = *desc; p.s = *state; p.o = *out; p.actions = actions; p.n_iter = n_steps;
     if (traj) p.t = *traj;
