@@ -727,8 +727,8 @@ def main():
         out["step_only"] = step_only_measure(env, args.policy, alg_per_step, B)
         out["trajectory"] = traj_measure(env, args.policy, alg_per_step)
         out["external_actions"] = external_action_forms(env, args.policy, alg_per_step, args.steps)
-        # the un-fused path: jss_policy (stand-in for a policy network) then jss_step(actions) with next-step auto-reset --
-        # two launches + the action select per env step, hipGraph replay
+        # the un-fused path: jss_policy (stand-in for a policy network) then jss_step_autoreset(actions) -- two launches per
+        # env step, hipGraph replay
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -744,8 +744,8 @@ def main():
             out["policy_then_step_two_launches"] = {"value": med2["rate"], "unit": "env steps/s", "iterations": n2,
                                                     "windows": window_stats(rows2, n2),
                                                     "roofline_frac": roofline(med2, alg_per_step, n2, env, None, B)["frac"],
-                                                    "note": "jss_policy + action select + jss_step(autoreset) per env step (three "
-                                                            "launches, actions through HBM), hipGraph replay"}
+                                                    "note": "jss_policy + jss_step_autoreset per env step (two launches, actions "
+                                                            "through HBM; the auto-reset is folded into the step kernel), hipGraph replay"}
         except Exception as exc:
             out["policy_then_step_two_launches"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.synchronize()

@@ -275,6 +275,11 @@ int jss_reset(const JssDesc *desc, const JssState *state, const JssOut *out, con
 /* one step() per env; actions[i] in [0, J], JSS_ACTION_SKIP or JSS_ACTION_RESET */
 int jss_step(const JssDesc *desc, const JssState *state, const int32_t *actions, const JssOut *out, void *stream);
 
+/* jss_step with gymnasium.vector "next-step" auto-reset folded in: an env whose out->done is set (it reported done on the
+ * previous call) is reset instead of stepped -- its action is ignored, reward 0, done 0, episode + 1 -- exactly as if the
+ * caller had put JSS_ACTION_RESET into actions[i].  One launch for the whole `obs, r, done = envs.step(a)` of a vector env. */
+int jss_step_autoreset(const JssDesc *desc, const JssState *state, const int32_t *actions, const JssOut *out, void *stream);
+
 /* one increase_time_step() per env with which[i] != 0 (NULL = all); hole[i] = returned idle time (may be NULL) */
 int jss_advance(const JssDesc *desc, const JssState *state, const uint8_t *which, int32_t *hole, const JssOut *out,
                 void *stream);

@@ -52,7 +52,7 @@ MAX_SUB_BATCHES = 16
 
 SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_backend", "jss_reset", "jss_step", "jss_advance", "jss_policy",
            "jss_rollout", "jss_rollout_steps", "jss_rollout_steps_multi", "jss_trajectory", "jss_sync_check",
-           "jss_steps", "jss_session_open", "jss_session_post", "jss_session_wait", "jss_session_step", "jss_session_close")
+           "jss_step_autoreset", "jss_steps", "jss_session_open", "jss_session_post", "jss_session_wait", "jss_session_step", "jss_session_close")
 
 _p = C.c_void_p
 
@@ -99,6 +99,7 @@ def bind(lib):
     lib.jss_backend.restype, lib.jss_backend.argtypes = C.c_char_p, []
     lib.jss_reset.restype, lib.jss_reset.argtypes = C.c_int, [D, S, O, _p, _p]
     lib.jss_step.restype, lib.jss_step.argtypes = C.c_int, [D, S, _p, O, _p]
+    lib.jss_step_autoreset.restype, lib.jss_step_autoreset.argtypes = C.c_int, [D, S, _p, O, _p]
     lib.jss_advance.restype, lib.jss_advance.argtypes = C.c_int, [D, S, _p, _p, O, _p]
     lib.jss_policy.restype, lib.jss_policy.argtypes = C.c_int, [D, S, C.c_int, C.c_uint64, C.c_uint32, _p, _p]
     lib.jss_rollout.restype = C.c_int

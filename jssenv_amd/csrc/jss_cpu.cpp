@@ -534,7 +534,9 @@ void run_env(const Call &c, int mode, int b) {
     case kStep: {
         bool called;
         int rn;
-        step_call(e, c, b, c.actions[b], called, rn);
+        // jss_step_autoreset: an env that reported done on the previous call is reset instead of stepped
+        const int a = ((c.flags & JSS_ROLLOUT_AUTORESET) && c.o.done[b]) ? JSS_ACTION_RESET : c.actions[b];
+        step_call(e, c, b, a, called, rn);
         break;
     }
     case kSteps: {                                                        // n_iter x kStep, actions [n_iter][B], every step optionally recorded
@@ -701,6 +703,15 @@ int jss_step(const JssDesc *desc, const JssState *state, const int32_t *actions,
     if (!actions) return JSS_E_NULL;
     Call c;
     c.d = *desc; c.s = *state; c.o = *out; c.actions = actions;
+    return run(c, kStep);
+}
+
+int jss_step_autoreset(const JssDesc *desc, const JssState *state, const int32_t *actions, const JssOut *out, void *) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if (!actions) return JSS_E_NULL;
+    Call c;
+    c.d = *desc; c.s = *state; c.o = *out; c.actions = actions; c.flags = JSS_ROLLOUT_AUTORESET;
     return run(c, kStep);
 }
 

@@ -378,6 +378,15 @@ int jss_step(const JssDesc *desc, const JssState *state, const int32_t *actions,
     return launch<kStep>(p, stream);
 }
 
+int jss_step_autoreset(const JssDesc *desc, const JssState *state, const int32_t *actions, const JssOut *out, void *stream) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if (!actions) return JSS_E_NULL;
+    Params p = {};
+    p.d = *desc; p.s = *state; p.o = *out; p.actions = actions; p.flags = JSS_ROLLOUT_AUTORESET;
+    return launch<kStep>(p, stream);
+}
+
 int jss_advance(const JssDesc *desc, const JssState *state, const uint8_t *which, int32_t *hole, const JssOut *out,
                 void *stream) {
     int rc = check_args(desc, state, out, true);

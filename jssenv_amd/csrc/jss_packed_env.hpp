@@ -951,7 +951,11 @@ void jss_packed_kernel(Params p) {
     c.tid = 0;
     if (!wave_dead) {
         raw = p_issue_loads<G, TAB>(c, p);
-        if (MODE == kStep) a_in = ld_off<int>(p.actions + fe, c.rel * 4u);
+        if (MODE == kStep) {
+            a_in = ld_off<int>(p.actions + fe, c.rel * 4u);
+            // jss_step_autoreset: an env that reported done on the previous call is reset instead of stepped
+            if ((p.flags & JSS_ROLLOUT_AUTORESET) && ld_off<uint8_t>(p.o.done + fe, c.rel) != 0) a_in = JSS_ACTION_RESET;
+        }
         if ((MODE == kReset || MODE == kAdvance) && p.which) selected = ld_off<uint8_t>(p.which + fe, c.rel) != 0;
         if (TAB == kTabGlobal) {
             if (MODE == kReset) {

@@ -1076,7 +1076,11 @@ __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel
     c.lane = lane;
     const HeaderWords h = load_header(p, b);
     int a_in = JSS_ACTION_SKIP;
-    if (MODE == kStep) a_in = __builtin_amdgcn_readfirstlane(p.actions[b]);
+    if (MODE == kStep) {
+        a_in = __builtin_amdgcn_readfirstlane(p.actions[b]);
+        // jss_step_autoreset: an env that reported done on the previous call is reset instead of stepped
+        if ((p.flags & JSS_ROLLOUT_AUTORESET) && __builtin_amdgcn_readfirstlane((int)p.o.done[b]) != 0) a_in = JSS_ACTION_RESET;
+    }
     bool selected = true;
     if ((MODE == kReset || MODE == kAdvance) && p.which) selected = __builtin_amdgcn_readfirstlane((int)p.which[b]) != 0;
     if (tab_in_lds(TAB)) {                                                // one instance for the whole batch: its op table -> LDS

@@ -495,17 +495,17 @@ class BatchedJssEnv:
         Returns (obs, reward (B,) float32, done (B,) uint8, truncated=False, info={}).
         autoreset=True gives gymnasium.vector "next-step" semantics: an env that reported done on the
         previous call is reset by this call instead of being stepped (its action is ignored, reward 0,
-        done 0) -- same launch (action code JSS_ACTION_RESET), no host synchronisation."""
+        done 0) -- same launch (jss_step_autoreset), no host synchronisation, no extra kernel."""
         if not self._is_reset:
             raise RuntimeError("call reset() before step()")
         be = self.backend
         d, s, o = self._refs()
         with be.on_device():
             a = self._stage(self._act_in, actions, "int32")   # the caller's int32 tensor itself, or a copy into our buffer
-            if autoreset:      # envs that reported done last time get JSS_ACTION_RESET: reset in the same launch
-                be.select_into(self._act_buf, self.done, _abi.ACTION_RESET, a)
-                a = self._act_buf
-            _abi.check(be.lib, be.lib.jss_step(d, s, be.ptr(a), o, be.stream()), "jss_step")
+            # autoreset: envs that reported done last time are reset instead of stepped, in the same launch (the kernel
+            # looks at the done flags itself: jss_step_autoreset)
+            fn = be.lib.jss_step_autoreset if autoreset else be.lib.jss_step
+            _abi.check(be.lib, fn(d, s, be.ptr(a), o, be.stream()), "jss_step")
         return self._obs(), self.reward, self.done, False, {}
 
     def step_raw(self, actions_ptr: int):

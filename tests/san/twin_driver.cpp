@@ -164,6 +164,34 @@ static void run_shape(int B, int J, int M, int max_dur, bool per_env) {
             (void)any;
         }
     }
+    // the external-action forms (ABI v8): K steps per call with hostile actions, recorded; the vector-env step with the
+    // auto-reset folded in; a step session (on the host cores: post executes its steps on the spot)
+    {
+        const int K = 13;
+        std::vector<int32_t> acts((size_t)K * B);
+        for (size_t x = 0; x < acts.size(); ++x) acts[x] = (int)(rnd() % (J + 5)) - 3;       // [-3, J + 1]: CLOSE is "bad action" here
+        std::vector<float> tobs((size_t)K * B * J * 7), trew((size_t)K * B);
+        std::vector<uint8_t> tmask((size_t)K * B * (J + 1)), tdone((size_t)K * B);
+        JssTraj tr{tobs.data(), tmask.data(), nullptr, trew.data(), tdone.data()};
+        CHECK(jss_steps(&b.d, &b.s, &b.o, &tr, acts.data(), K, nullptr) == 0);
+        CHECK(jss_steps(&b.d, &b.s, &b.o, nullptr, acts.data(), K, nullptr) == 0);
+        CHECK(jss_steps(&b.d, &b.s, &b.o, nullptr, nullptr, 0, nullptr) == 0);
+        for (int it = 0; it < 40; ++it) {
+            CHECK(jss_policy(&b.d, &b.s, JSS_POLICY_SPT, 5, 0, b.actions.data(), nullptr) == 0);
+            CHECK(jss_step_autoreset(&b.d, &b.s, b.actions.data(), &b.o, nullptr) == 0);
+        }
+        std::vector<uint64_t> mail((size_t)4 * B, 0);
+        std::vector<int32_t> progress(B, 0), status(4, 0);
+        JssSession ss{mail.data(), progress.data(), status.data(), 4, 0, 0, 0};
+        CHECK(jss_session_open(&b.d, &b.s, &b.o, &ss, nullptr) == 0);
+        CHECK(jss_session_post(&b.d, &ss, acts.data(), 0, 4, 0, nullptr) == 0);
+        CHECK(jss_session_post(&b.d, &ss, acts.data(), 4, 1, 0, nullptr) == JSS_E_SESSION);     // ring overrun
+        CHECK(jss_session_wait(&b.d, &ss, 4, nullptr) == 0);
+        CHECK(jss_session_step(&b.d, &ss, acts.data() + (size_t)4 * B, 4, nullptr) == 0);
+        CHECK(jss_session_close(&b.d, &ss, 5, nullptr) == 0);
+        CHECK(progress[0] == 5 && status[1] == 0);
+        CHECK(jss_policy(&b.d, &b.s, JSS_POLICY_CR_FACTOR(5, 4), 0, 0, b.actions.data(), nullptr) == 0 || b.d.rem == nullptr);
+    }
     CHECK(jss_sync_check(nullptr) == 0);
     std::printf("shape %dx%d x %d envs (%s tables): ok\n", J, M, B, per_env ? "per-env" : "shared");
 }
@@ -185,6 +213,8 @@ int main() {
     CHECK(jss_reset(&b.d, &bad, &b.o, nullptr, nullptr) == JSS_E_NULL);
     CHECK(jss_policy(&b.d, &b.s, 99, 0, 0, b.actions.data(), nullptr) == JSS_E_KIND);
     CHECK(jss_rollout(&b.d, &b.s, &b.o, 0, 0, 0, -1, 0, nullptr) == JSS_E_SHAPE);
+    CHECK(jss_policy(&b.d, &b.s, JSS_POLICY_CR_FACTOR(3, 5), 0, 0, b.actions.data(), nullptr) == JSS_E_KIND);      // q not a power of two
+    CHECK(jss_policy(&b.d, &b.s, JSS_POLICY_SPT | (2 << 8) | (1 << 16), 0, 0, b.actions.data(), nullptr) == JSS_E_KIND);   // a factor on another rule
     std::printf("SANITIZED-TWIN-OK\n");
     return 0;
 }
