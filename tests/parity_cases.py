@@ -1044,7 +1044,7 @@ def drive_steps(env, kind, iters, form="fused", explore=0.0, autoreset=True, win
                 done += n
         else:
             depth = 1 if form == "session_lockstep" else window
-            with env.session(depth=depth) as s:
+            with env.session(depth=depth, timeout_ms=3000) as s:
                 done = 0
                 while done < iters:
                     n = min(depth, iters - done)
@@ -1301,7 +1301,7 @@ def case_session(backend, kw=None, K=36, kind="random", seed=5, warm=20, depth=8
     want = _state_snapshot(env)
     _restore(env, start, sol0)
     dev_acts = env.backend.as_device(acts, "int32") if hasattr(env.backend, "torch") else acts
-    with env.session(depth=depth, slots=slots) as s:
+    with env.session(depth=depth, slots=slots, timeout_ms=3000) as s:
         try:
             env.step(acts[0])
             raise AssertionError("other calls must be refused while a session is open")
@@ -1473,7 +1473,7 @@ def case_steps_and_session_edges(backend, emulator=False):
         _abi.check(lib, lib.jss_session_open(d, s, o, C.byref(sess), 0), "open")
         assert status[0] == 0 and status[2] > 0
     else:
-        with env2.session(depth=4, slots=2) as s:
+        with env2.session(depth=4, slots=2, timeout_ms=3000) as s:
             s.post(acts[:3])
             s.wait()
             for k in range(3, 7):

@@ -323,7 +323,7 @@ def test_step_session_fits_the_baseline_batches(hip_auto):
                      (dict(instances=I.synthetic_packed(8192, 50, 20)), 2), (dict(instances="ta01", batch=65536), 8)):
         env = BatchedJssEnv(_backend=hip_auto, **kw)
         env.reset()
-        with env.session(depth=2) as s:
+        with env.session(depth=2, timeout_ms=3000) as s:
             s.step(env.backend.torch.zeros(env.batch, dtype=env.backend.torch.int32, device=env.backend.device))
         st = s.host_status()
         assert st["env_sets_per_wavefront"] == want and st["session_timeouts"] == 0 and st["wait_timeouts"] == 0, (kw.get("batch"), st)
