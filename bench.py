@@ -443,7 +443,7 @@ def main():
     def kernel_name(env):
         if hasattr(env, "buckets"):
             return "four launches per step: jss_packed_kernel<16|32,kRollout1,*>, jss_kernel<1|2,kRollout1,*>"
-        tab = ("kTabLdsC" if env.compact else "kTabLds") if env.n_tables == 1 else "kTabGlobal"
+        tab = ("kTabLdsC" if env.compact else "kTabLds") if env.n_tables == 1 else ("kTabGlobalM" if getattr(env, "medium", False) else "kTabGlobal")
         jm, mm = env.jmax, env.mmax
         if max(jm, mm) <= 32:
             return f"jss_packed_kernel<{16 if max(jm, mm) <= 16 else 32},kRollout1,{tab}>"

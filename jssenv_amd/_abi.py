@@ -17,6 +17,9 @@ TODO_MASK, FLAG_LEGAL, FLAG_BLOCKED, NEXT2_SHIFT = 255, 256, 512, 10
 # compact 16-byte record of shared-instance batches (JSS_FC_*): no cached ops, packed words
 FC_W0, FC_LEFT_F4, FC_IDLE, FC_IDLE_LAST, NFC = 0, 1, 2, 3, 4
 FC_TODO_MASK, FC_FLAG_LEGAL, FC_FLAG_BLOCKED, FC_FLAG_F4_ONE, FC_PERF_SHIFT = 127, 128, 256, 512, 10
+# medium 24-byte record of per-env-instance batches with jobs, machines <= 32 (JSS_FM_*): three 21-bit cached ops, no machine clocks
+FM_W0, FM_LEFT_F4, FM_PERF_NEXT, FM_NEXT_NEXT2, FM_IDLE, FM_IDLE_LAST, NFM = 0, 1, 2, 3, 4, 5, 6
+FM_TODO_MASK, FM_FLAG_LEGAL, FM_FLAG_BLOCKED, FM_FLAG_F4_ONE, FM_CUR_SHIFT, FM_OP_MASK = 63, 64, 128, 256, 9, 0x1FFFFF
 H_CLOCK, H_EPISODE, H_STEP, H_STATUS = 0, 1, 2, 3
 NH = 4
 C_JOBS, C_MACHINES, C_MAX_TIME_OP, C_TABLE, C_MAX_TIME_JOBS, C_SUM_OP = 0, 1, 2, 3, 4, 5

@@ -57,9 +57,15 @@ constexpr int kDurMask = 0xffff;
 enum Mode { kReset = 0, kStep = 1, kAdvance = 2, kPolicy = 3, kRollout = 4, kRollout1 = 5, kTraj = 6, kSteps = 7, kSession = 8 };
 // where the op table lives: LDS (one instance shared by the batch) or global memory; kTabLdsC = LDS + compact 16-byte
 // job records (the three cached ops are re-read from the LDS table, the machine clocks rebuilt from the records)
-enum Tab { kTabLds = 0, kTabGlobal = 1, kTabLdsC = 2 };
-constexpr bool tab_in_lds(int tab) { return tab != kTabGlobal; }
+// kTabGlobalM = global memory + 24-byte medium records (packed kernels only: jobs, machines <= 32; the three cached ops in 21
+// bits each, machine clocks rebuilt from the records)
+enum Tab { kTabLds = 0, kTabGlobal = 1, kTabLdsC = 2, kTabGlobalM = 3 };
+constexpr bool tab_in_lds(int tab) { return tab == kTabLds || tab == kTabLdsC; }
+constexpr bool tab_global(int tab) { return !tab_in_lds(tab); }
 constexpr bool tab_compact(int tab) { return tab == kTabLdsC; }
+constexpr bool tab_medium(int tab) { return tab == kTabGlobalM; }
+constexpr bool tab_no_clocks(int tab) { return tab_compact(tab) || tab_medium(tab); }   // machine clocks rebuilt from the job records
+constexpr int tab_record_ints(int tab) { return tab_compact(tab) ? JSS_NFC : tab_medium(tab) ? JSS_NFM : JSS_NF; }
 
 struct Params {
     JssDesc d;

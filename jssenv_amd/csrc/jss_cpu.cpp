@@ -54,7 +54,8 @@ struct Env {
 
     // word f (JSS_F_*) of job j's record.  `job` is the batch tensor itself for full records; for compact 16-byte
     // records (JSS_FC_*) it is a thread-local full-layout copy that load_compact() fills and store_compact() writes back
-    int32_t *packed;            // compact records of my env in the batch tensor (nullptr with full records)
+    int32_t *packed;            // compact / medium records of my env in the batch tensor (nullptr with full records)
+    int packed_ints;            // JSS_NFC or JSS_NFM (0 with full records)
     int32_t &w(int j, int f) const { return job[j * JSS_NF + f]; }
     int op_at(int j, int k) const { return k < M ? ops[j * stride + k] : -1; }
     int cur(int j) const { return w(j, JSS_F_CUR); }                                     // current op, -1 = job finished
@@ -105,8 +106,48 @@ void load_compact(const Env &e) {
     for (int j = 0; j < e.J; ++j)
         if (e.w(j, JSS_F_LEFT) > 0 && e.cur(j) >= 0) e.tm[e.cur(j) >> 16] = e.w(j, JSS_F_LEFT);
 }
+// 24-byte medium records (JSS_FM_*: per-env instances, jobs / machines <= 32) <-> the full-layout working copy
+void load_medium(const Env &e) {
+    for (int j = 0; j < e.jmax; ++j) {
+        const int32_t *r = e.packed + j * JSS_NFM;
+        const unsigned w0 = (unsigned)r[JSS_FM_W0], w1 = (unsigned)r[JSS_FM_LEFT_F4], w2 = (unsigned)r[JSS_FM_PERF_NEXT], w3 = (unsigned)r[JSS_FM_NEXT_NEXT2];
+        const unsigned cur = (w0 >> JSS_FM_CUR_SHIFT) & JSS_FM_OP_MASK, nxt = (w2 >> 21) | ((w3 & 0x3FFu) << 11), nxt2 = (w3 >> 10) & JSS_FM_OP_MASK;
+        e.w(j, JSS_F_TODO) = (int)(w0 & JSS_FM_TODO_MASK) | ((w0 & JSS_FM_FLAG_LEGAL) ? JSS_FLAG_LEGAL : 0) | ((w0 & JSS_FM_FLAG_BLOCKED) ? JSS_FLAG_BLOCKED : 0);
+        e.w(j, JSS_F_CUR) = cur ? (int)cur : -1;
+        e.w(j, JSS_F_LEFT) = (int)(w1 & 0xffffu);
+        e.w(j, JSS_F_PERF) = (int)(w2 & JSS_FM_OP_MASK);
+        e.w(j, JSS_F_IDLE) = r[JSS_FM_IDLE];
+        e.w(j, JSS_F_IDLE_LAST) = r[JSS_FM_IDLE_LAST];
+        e.w(j, JSS_F_F4) = (w0 & JSS_FM_FLAG_F4_ONE) ? JSS_F4_ONE : (int)(w1 >> 16);
+        e.w(j, JSS_F_NEXT) = nxt ? (int)nxt : -1;
+        e.set_next2(j, nxt2 ? (int)nxt2 : -1);
+    }
+    for (int m = 0; m < e.mmax; ++m) e.tm[m] = 0;                         // no machine clocks in memory (load_compact)
+    for (int j = 0; j < e.J; ++j)
+        if (e.w(j, JSS_F_LEFT) > 0 && e.cur(j) >= 0) e.tm[e.cur(j) >> 16] = e.w(j, JSS_F_LEFT);
+}
+void store_medium(const Env &e) {
+    for (int j = 0; j < e.jmax; ++j) {
+        int32_t *r = e.packed + j * JSS_NFM;
+        const int w0 = e.w(j, JSS_F_TODO), f4 = e.w(j, JSS_F_F4);
+        const unsigned cur = e.cur(j) >= 0 ? (unsigned)e.cur(j) : 0u, nxt = e.nxt(j) >= 0 ? (unsigned)e.nxt(j) : 0u;
+        const unsigned nxt2 = e.next2(j) >= 0 ? (unsigned)e.next2(j) : 0u;
+        r[JSS_FM_W0] = (int32_t)((unsigned)(w0 & JSS_TODO_MASK) | ((w0 & JSS_FLAG_LEGAL) ? JSS_FM_FLAG_LEGAL : 0u) |
+                                 ((w0 & JSS_FLAG_BLOCKED) ? JSS_FM_FLAG_BLOCKED : 0u) | (f4 == JSS_F4_ONE ? JSS_FM_FLAG_F4_ONE : 0u) |
+                                 (cur << JSS_FM_CUR_SHIFT));
+        r[JSS_FM_LEFT_F4] = (int32_t)((unsigned)e.w(j, JSS_F_LEFT) | ((unsigned)(f4 == JSS_F4_ONE ? 0 : f4) << 16));
+        r[JSS_FM_PERF_NEXT] = (int32_t)((unsigned)e.w(j, JSS_F_PERF) | (nxt << 21));
+        r[JSS_FM_NEXT_NEXT2] = (int32_t)((nxt >> 11) | (nxt2 << 10));
+        r[JSS_FM_IDLE] = e.w(j, JSS_F_IDLE);
+        r[JSS_FM_IDLE_LAST] = e.w(j, JSS_F_IDLE_LAST);
+    }
+}
 void store_compact(const Env &e) {
     if (!e.packed) return;
+    if (e.packed_ints == JSS_NFM) {
+        store_medium(e);
+        return;
+    }
     for (int j = 0; j < e.jmax; ++j) {
         int32_t *r = e.packed + j * JSS_NFC;
         const int w0 = e.w(j, JSS_F_TODO), f4 = e.w(j, JSS_F_F4);
@@ -146,14 +187,17 @@ Env env_of(const Call &c, int b, bool from_instance) {
     e.stride = d.mmax;
     e.jmax = d.jmax;
     e.mmax = d.mmax;
-    if (d.record_ints == JSS_NFC) {
+    if (d.record_ints == JSS_NFC || d.record_ints == JSS_NFM) {
         static thread_local int32_t unpacked[JSS_MAX_JOBS * JSS_NF], clocks[JSS_MAX_MACHINES];
-        e.packed = c.s.job + (size_t)b * d.jmax * JSS_NFC;
+        e.packed = c.s.job + (size_t)b * d.jmax * d.record_ints;
+        e.packed_ints = d.record_ints;
         e.job = unpacked;
         e.tm = clocks;
-        load_compact(e);
+        if (d.record_ints == JSS_NFC) load_compact(e);
+        else load_medium(e);
     } else {
         e.packed = nullptr;
+        e.packed_ints = 0;
         e.job = c.s.job + (size_t)b * d.jmax * JSS_NF;
         e.tm = c.s.machine + (size_t)b * d.mmax;
     }
@@ -640,15 +684,16 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
     if (!d || !s) return JSS_E_NULL;
     if (!d->ops || !d->inst) return JSS_E_NULL;
     if (!s->env || !s->env_const || !s->job || !s->solution) return JSS_E_NULL;
-    if (!s->machine && d->record_ints != JSS_NFC) return JSS_E_NULL;   // compact batches keep no machine clocks
+    if (!s->machine && d->record_ints != JSS_NFC && d->record_ints != JSS_NFM) return JSS_E_NULL;   // compact / medium batches keep no machine clocks
     if (need_out && (!o || !o->real_obs || !o->action_mask || !o->reward || !o->done || !o->makespan)) return JSS_E_NULL;
     if (d->batch < 0 || d->jmax < 1 || d->jmax > JSS_MAX_JOBS || d->mmax < 2 || d->mmax > JSS_MAX_MACHINES ||
         d->n_tables < 1)
         return JSS_E_SHAPE;
     if (!d->table_of_env && d->n_tables != 1 && d->n_tables != d->batch) return JSS_E_SHAPE;
     if (d->kernel != JSS_KERNEL_AUTO && d->kernel != JSS_KERNEL_WAVE) return JSS_E_KIND;
-    if (d->record_ints != 0 && d->record_ints != JSS_NF && d->record_ints != JSS_NFC) return JSS_E_SHAPE;
+    if (d->record_ints != 0 && d->record_ints != JSS_NF && d->record_ints != JSS_NFC && d->record_ints != JSS_NFM) return JSS_E_SHAPE;
     if (d->record_ints == JSS_NFC && d->n_tables != 1) return JSS_E_SHAPE;
+    if (d->record_ints == JSS_NFM && (d->jmax > 32 || d->mmax > 32 || d->kernel != JSS_KERNEL_AUTO || d->n_tables == 1)) return JSS_E_SHAPE;
     return 0;
 }
 

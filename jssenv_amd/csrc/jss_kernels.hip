@@ -23,17 +23,21 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
     if (!d || !s) return JSS_E_NULL;
     if (!d->ops || !d->inst) return JSS_E_NULL;
     if (!s->env || !s->env_const || !s->job || !s->solution) return JSS_E_NULL;
-    if (!s->machine && d->record_ints != JSS_NFC) return JSS_E_NULL;   // compact batches keep no machine clocks
+    if (!s->machine && d->record_ints != JSS_NFC && d->record_ints != JSS_NFM) return JSS_E_NULL;   // compact / medium batches keep no machine clocks
     if (need_out && (!o || !o->real_obs || !o->action_mask || !o->reward || !o->done || !o->makespan)) return JSS_E_NULL;
     if (d->batch < 0 || d->jmax < 1 || d->jmax > JSS_MAX_JOBS || d->mmax < 2 || d->mmax > JSS_MAX_MACHINES ||
         d->n_tables < 1)
         return JSS_E_SHAPE;
     if (!d->table_of_env && d->n_tables != 1 && d->n_tables != d->batch) return JSS_E_SHAPE;
     if (d->kernel != JSS_KERNEL_AUTO && d->kernel != JSS_KERNEL_WAVE) return JSS_E_KIND;
-    if (d->record_ints != 0 && d->record_ints != JSS_NF && d->record_ints != JSS_NFC) return JSS_E_SHAPE;
+    if (d->record_ints != 0 && d->record_ints != JSS_NF && d->record_ints != JSS_NFC && d->record_ints != JSS_NFM) return JSS_E_SHAPE;
     if (d->record_ints == JSS_NFC && d->n_tables != 1) return JSS_E_SHAPE;   // compact records need the ONE table in LDS
+    // medium records: 21-bit ops and a 32-lane group at most -- the packed kernels' shapes, per-env tables
+    if (d->record_ints == JSS_NFM && (d->jmax > 32 || d->mmax > 32 || d->kernel != JSS_KERNEL_AUTO || d->n_tables == 1)) return JSS_E_SHAPE;
     return 0;
 }
+
+int record_ints_of(const JssDesc &d) { return d.record_ints == JSS_NFC ? JSS_NFC : d.record_ints == JSS_NFM ? JSS_NFM : JSS_NF; }
 
 int check_kind(const JssDesc *d, int kind_arg) {
     const int kind = kind_arg & 0xFF, fp = (kind_arg >> 8) & 0xFF, fq = (kind_arg >> 16) & 0xFF;
@@ -112,9 +116,14 @@ KernelFn pick_tab(int G, int jpl) {
     return jss_kernel<2, MODE, TAB>;
 }
 template <int MODE>
-KernelFn pick(int G, int jpl, bool shared, bool compact) {
-    if (!shared) return pick_tab<MODE, kTabGlobal>(G, jpl);
-    return compact ? pick_tab<MODE, kTabLdsC>(G, jpl) : pick_tab<MODE, kTabLds>(G, jpl);
+KernelFn pick_medium(int G) {                          // (check_args: medium records come with a packed shape only)
+    if (G == 16) return jss_packed_kernel<16, MODE, kTabGlobalM>;
+    return jss_packed_kernel<32, MODE, kTabGlobalM>;
+}
+template <int MODE>
+KernelFn pick(int G, int jpl, bool shared, int record_ints) {
+    if (!shared) return record_ints == JSS_NFM ? pick_medium<MODE>(G) : pick_tab<MODE, kTabGlobal>(G, jpl);
+    return record_ints == JSS_NFC ? pick_tab<MODE, kTabLdsC>(G, jpl) : pick_tab<MODE, kTabLds>(G, jpl);
 }
 
 struct LaunchPlan {
@@ -151,7 +160,7 @@ int plan(Params &p, LaunchPlan &lp) {
     lp.shmem += g_lds_pad;
 #endif
     if (lp.shmem > kMaxDynamicLds) return JSS_E_LDS;
-    lp.fn = pick<MODE>(G, p.d.jmax <= kWave ? 1 : 2, shared, p.d.record_ints == JSS_NFC);
+    lp.fn = pick<MODE>(G, p.d.jmax <= kWave ? 1 : 2, shared, p.d.record_ints);
     return 0;
 }
 
@@ -163,9 +172,10 @@ KernelFn pick_session_tab(int G, int jpl) {
     if (jpl == 1) return jss_session_kernel<1, TAB>;
     return jss_session_kernel<2, TAB>;
 }
-KernelFn pick_session(int G, int jpl, bool shared, bool compact) {
+KernelFn pick_session(int G, int jpl, bool shared, int record_ints) {
+    if (!shared && record_ints == JSS_NFM) return G == 16 ? jss_packed_session_kernel<16, kTabGlobalM> : jss_packed_session_kernel<32, kTabGlobalM>;
     if (!shared) return pick_session_tab<kTabGlobal>(G, jpl);
-    return compact ? pick_session_tab<kTabLdsC>(G, jpl) : pick_session_tab<kTabLds>(G, jpl);
+    return record_ints == JSS_NFC ? pick_session_tab<kTabLdsC>(G, jpl) : pick_session_tab<kTabLds>(G, jpl);
 }
 
 struct SessionInfo {          // what jss_session_wait needs to know about an open session (keyed by its progress pointer)
@@ -198,7 +208,7 @@ int plan_session(Params &p, LaunchPlan &lp, int slots, int *blocks_out, int *act
         p.norm_off_ints = p.mv_off_ints + kBlock;
         p.norm_slot_ints = shared ? 0 : kBlock;
         p.park_off_ints = p.norm_off_ints + (shared ? 0 : slots * kBlock);
-        park4 = (compact ? 1 : 3) * kWave + 8;
+        park4 = (compact ? 1 : p.d.record_ints == JSS_NFM ? 2 : 3) * kWave + 8;
     } else {
         envs_per_wave = 1;
         p.obs_wave_floats = (p.d.jmax * 7 + 3 + 3) & ~3;
@@ -209,7 +219,7 @@ int plan_session(Params &p, LaunchPlan &lp, int slots, int *blocks_out, int *act
     }
     lp.shmem = sizeof(int32_t) * ((size_t)p.park_off_ints + (slots > 1 ? (size_t)kWavesPerBlock * slots * park4 * 4 : 0));
     if (lp.shmem > kMaxSessionLds) return JSS_E_RESIDENT;
-    lp.fn = pick_session(G, jpl, shared, compact);
+    lp.fn = pick_session(G, jpl, shared, p.d.record_ints);
     lp.envs_per_block = envs_per_wave * kWavesPerBlock * slots;
     const int sets = (p.d.batch + envs_per_wave - 1) / envs_per_wave;
     const int waves = (sets + slots - 1) / slots;
@@ -314,7 +324,7 @@ Params sub_batch(const Params &p, int start, int count) {
     q.d.env_id_base = p.d.env_id_base + start;
     q.s.env = p.s.env + s0 * JSS_NH;
     q.s.env_const = p.s.env_const + s0 * JSS_NC;
-    q.s.job = p.s.job + s0 * jm * (p.d.record_ints == JSS_NFC ? JSS_NFC : JSS_NF);
+    q.s.job = p.s.job + s0 * jm * record_ints_of(p.d);
     q.s.machine = p.s.machine ? p.s.machine + s0 * mm : nullptr;
     q.s.solution = p.s.solution + s0 * jm * mm;
     if (p.s.counters) q.s.counters = p.s.counters + s0 * 4;

@@ -534,6 +534,12 @@ __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G, TAB> &c, const Pa
     if (tab_compact(TAB)) {          // 16-byte records (JSS_FC_*): one access per job
         r.lo = ld_off<int4>(p.s.job + fe * jm * JSS_NFC, (c.rel * jm + jc) * (JSS_NFC * 4u));
         r.hi = make_int4(0, 0, 0, 0);
+    } else if (tab_medium(TAB)) {    // 24-byte records (JSS_FM_*): three 8-byte accesses (a record is 8-byte aligned)
+        const int32_t *jb = p.s.job + fe * jm * JSS_NFM;
+        const unsigned jo = (c.rel * jm + jc) * (JSS_NFM * 4u);
+        const int2 a = ld_off<int2>(jb, jo), b = ld_off<int2>(jb, jo + 8u), d = ld_off<int2>(jb, jo + 16u);
+        r.lo = make_int4(a.x, a.y, b.x, b.y);
+        r.hi = make_int4(d.x, d.y, 0, 0);
     } else {
         const int32_t *jb = p.s.job + fe * jm * JSS_NF;
         const unsigned jo = (c.rel * jm + jc) * 32u;
@@ -541,7 +547,7 @@ __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G, TAB> &c, const Pa
         r.hi = ld_off<int4>(jb, jo + 16u);
     }
     // compact batches keep no machine clocks in memory: a machine is busy for as long as the job on it (p_unpack)
-    r.tm = tab_compact(TAB) ? 0 : ld_off<int>(p.s.machine + fe * mm, (c.rel * mm + mc) * 4u);
+    r.tm = tab_no_clocks(TAB) ? 0 : ld_off<int>(p.s.machine + fe * mm, (c.rel * mm + mc) * 4u);
     return r;
 }
 
@@ -565,14 +571,21 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, c
         e.nxt2 = (v && e.todo + 2 < c.M) ? c.lds_row[e.todo + 2] : -1;
         e.legal = v && (w0 & JSS_FC_FLAG_LEGAL);
         e.blocked = v && (w0 & JSS_FC_FLAG_BLOCKED);
-        // time_until_available_machine[m] == time_until_finish_current_op_jobs[the job running on m] (both are set to
-        // the op's duration at :446-449 and count down together at :521-530), 0 for an idle machine
-        mvtab[c.lane] = 0;
-        wave_lds_sync();
-        if (e.left > 0 && e.cur >= 0) mvtab[c.gbase + (e.cur >> 16)] = e.left;   // (cur < 0: a reset call reading stale memory)
-        wave_lds_sync();
-        e.tm = c.mvalid ? mvtab[c.lane] : 0;
-        wave_lds_sync();
+    } else if (tab_medium(TAB)) {    // the three cached ops travel in the record, 21 bits each (0 = none)
+        const unsigned w0 = (unsigned)r.lo.x, w1 = (unsigned)r.lo.y, w2 = (unsigned)r.lo.z, w3 = (unsigned)r.lo.w;
+        const unsigned cur = (w0 >> JSS_FM_CUR_SHIFT) & JSS_FM_OP_MASK;
+        const unsigned nxt = (w2 >> 21) | ((w3 & 0x3FFu) << 11), nxt2 = (w3 >> 10) & JSS_FM_OP_MASK;
+        e.todo = v ? (int)(w0 & JSS_FM_TODO_MASK) : 0;
+        e.left = v ? (int)(w1 & 0xffffu) : 0;
+        e.perf = v ? (int)(w2 & JSS_FM_OP_MASK) : 0;
+        e.idle = v ? r.hi.x : 0;
+        e.idle_last = v ? r.hi.y : 0;
+        e.f4 = v ? ((w0 & JSS_FM_FLAG_F4_ONE) ? JSS_F4_ONE : (int)(w1 >> 16)) : 0;
+        e.cur = (v && cur) ? (int)cur : -1;
+        e.nxt = (v && nxt) ? (int)nxt : -1;
+        e.nxt2 = (v && nxt2) ? (int)nxt2 : -1;
+        e.legal = v && (w0 & JSS_FM_FLAG_LEGAL);
+        e.blocked = v && (w0 & JSS_FM_FLAG_BLOCKED);
     } else {
         e.todo = v ? (r.lo.x & JSS_TODO_MASK) : 0;
         e.cur = v ? r.lo.y : -1;
@@ -585,6 +598,16 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, c
         e.nxt2 = (v && ((unsigned)r.lo.x >> JSS_NEXT2_SHIFT)) ? (int)((unsigned)r.lo.x >> JSS_NEXT2_SHIFT) : -1;
         e.legal = v && (r.lo.x & JSS_FLAG_LEGAL);
         e.blocked = v && (r.lo.x & JSS_FLAG_BLOCKED);
+    }
+    if (tab_no_clocks(TAB)) {
+        // time_until_available_machine[m] == time_until_finish_current_op_jobs[the job running on m] (both are set to
+        // the op's duration at :446-449 and count down together at :521-530), 0 for an idle machine
+        mvtab[c.lane] = 0;
+        wave_lds_sync();
+        if (e.left > 0 && e.cur >= 0) mvtab[c.gbase + ((e.cur >> 16) & (G - 1))] = e.left;   // (cur < 0: a reset call reading stale memory)
+        wave_lds_sync();
+        e.tm = c.mvalid ? mvtab[c.lane] : 0;
+        wave_lds_sync();
     }
     PHeader hd;
     hd.episode = r.h.y;
@@ -633,6 +656,14 @@ __device__ __forceinline__ PRaw<G> p_pack(const PEnv<G> &e, const PCtx<G, TAB> &
                                (one ? JSS_FC_FLAG_F4_ONE : 0u) | ((unsigned)e.perf << JSS_FC_PERF_SHIFT)),
                          (int)((unsigned)e.left | ((unsigned)(one ? 0 : e.f4) << 16)), e.idle, e.idle_last);
         r.hi = make_int4(0, 0, 0, 0);
+    } else if (tab_medium(TAB)) {
+        const bool one = e.f4 == JSS_F4_ONE;
+        const unsigned cur = e.cur >= 0 ? (unsigned)e.cur : 0u, nxt = e.nxt >= 0 ? (unsigned)e.nxt : 0u, nxt2 = e.nxt2 >= 0 ? (unsigned)e.nxt2 : 0u;
+        r.lo = make_int4((int)((unsigned)e.todo | (e.legal ? JSS_FM_FLAG_LEGAL : 0u) | (e.blocked ? JSS_FM_FLAG_BLOCKED : 0u) |
+                               (one ? JSS_FM_FLAG_F4_ONE : 0u) | (cur << JSS_FM_CUR_SHIFT)),
+                         (int)((unsigned)e.left | ((unsigned)(one ? 0 : e.f4) << 16)),
+                         (int)((unsigned)e.perf | (nxt << 21)), (int)((nxt >> 11) | (nxt2 << 10)));
+        r.hi = make_int4(e.idle, e.idle_last, 0, 0);
     } else {
         r.lo = make_int4(e.todo | (e.legal ? JSS_FLAG_LEGAL : 0) | (e.blocked ? JSS_FLAG_BLOCKED : 0) |
                              (e.nxt2 >= 0 ? (int)((unsigned)e.nxt2 << JSS_NEXT2_SHIFT) : 0), e.cur, e.left, e.perf);
@@ -662,11 +693,20 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
             st_off(cp, co + 32u, make_int4(as_int(n.r_sum), as_int(n.r_m), 0, 0));
         }
     }
-    if (tab_compact(TAB)) {
+    if (tab_no_clocks(TAB)) {
         // no machine clocks in memory (p_unpack)
     } else if (fresh ? (unsigned)c.gl < mm : (c.mvalid && e.tm != raw.tm))      // idle machines stay 0
         st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
-    if (tab_compact(TAB)) {
+    if (tab_medium(TAB)) {
+        if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {   // the thirds of the record that changed
+            int32_t *jb = p.s.job + fe * jm * JSS_NFM;
+            const unsigned jo = (c.rel * jm + c.gl) * (JSS_NFM * 4u);
+            const int4 lo = now.lo, hi = now.hi;
+            if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y) st_off(jb, jo, make_int2(lo.x, lo.y));
+            if (fresh || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo + 8u, make_int2(lo.z, lo.w));
+            if (fresh || hi.x != raw.hi.x || hi.y != raw.hi.y) st_off(jb, jo + 16u, make_int2(hi.x, hi.y));
+        }
+    } else if (tab_compact(TAB)) {
         if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
             const int4 lo = now.lo;
             // an unchanged record is not rewritten (steps without a time advance touch few jobs)
@@ -904,7 +944,7 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
 // launch bounds: the largest occupancy each mode reaches without spilling (8 waves per SIMD = 64 VGPRs)
 // With kTabGlobal the instance (tid, J, M, max_time_op) is group-uniform data in VGPRs instead of SGPRs: the step
 // kernels need 66-70 VGPRs.  7 waves/SIMD (72 VGPRs) beats 8 with two VGPRs in scratch: 19.4 vs 21.5 us per step
-// on synthetic 15x15, B = 65 536 (profiles/README.md).
+// on synthetic 15x15, B = 65 536 (profiles/README.md).  The medium-record one-step rollout needs 62: 8 waves per SIMD.
 #ifndef JSS_PTRAJ_LDS_MIN_BLOCKS
 #define JSS_PTRAJ_LDS_MIN_BLOCKS 4
 #endif
@@ -914,10 +954,14 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
 #ifndef JSS_PACKED_GLOBAL_MIN_BLOCKS
 #define JSS_PACKED_GLOBAL_MIN_BLOCKS 7
 #endif
+#ifndef JSS_PACKED_MEDIUM_MIN_BLOCKS
+#define JSS_PACKED_MEDIUM_MIN_BLOCKS 8
+#endif
 template <int G, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, (MODE == kTraj || MODE == kSteps) ? (TAB == kTabGlobal ? JSS_PTRAJ_GLOBAL_MIN_BLOCKS : JSS_PTRAJ_LDS_MIN_BLOCKS)
-                                     : MODE == kRollout ? (TAB == kTabGlobal ? 4 : 5)
-                                     : ((TAB == kTabGlobal && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
+__global__ __launch_bounds__(kBlock, (MODE == kTraj || MODE == kSteps) ? (tab_global(TAB) ? JSS_PTRAJ_GLOBAL_MIN_BLOCKS : JSS_PTRAJ_LDS_MIN_BLOCKS)
+                                     : MODE == kRollout ? (tab_global(TAB) ? 4 : 5)
+                                     : (tab_medium(TAB) && MODE == kRollout1) ? JSS_PACKED_MEDIUM_MIN_BLOCKS
+                                     : ((tab_global(TAB) && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
 void jss_packed_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     constexpr int E = kWave / G;                      // envs per wave
@@ -957,7 +1001,7 @@ void jss_packed_kernel(Params p) {
             if ((p.flags & JSS_ROLLOUT_AUTORESET) && ld_off<uint8_t>(p.o.done + fe, c.rel) != 0) a_in = JSS_ACTION_RESET;
         }
         if ((MODE == kReset || MODE == kAdvance) && p.which) selected = ld_off<uint8_t>(p.which + fe, c.rel) != 0;
-        if (TAB == kTabGlobal) {
+        if (tab_global(TAB)) {
             if (MODE == kReset) {
                 c.tid = p.d.table_of_env ? ld_off<int>(p.d.table_of_env + fe, c.rel * 4u) : (int)(fe + c.rel);
             } else {
@@ -1029,7 +1073,7 @@ void jss_packed_kernel(Params p) {
 // LDS footprint of one parked env set, in int4: per lane the job record (compact: 1 int4; full: lo, hi and the machine
 // clock), then per env (<= 4 of them) the header and -- per-env tables -- the instance constants
 template <int TAB>
-constexpr int park_lane_int4() { return tab_compact(TAB) ? 1 : 3; }
+constexpr int park_lane_int4() { return tab_compact(TAB) ? 1 : tab_medium(TAB) ? 2 : 3; }
 template <int TAB>
 constexpr int park_int4() { return park_lane_int4<TAB>() * kWave + 8; }
 
@@ -1059,14 +1103,12 @@ template <int G, int TAB>
 __device__ __forceinline__ void p_park(int4 *park, int slot, int lane, const PRaw<G> &r, const PCtx<G, TAB> &c) {
     int4 *q = park + (size_t)slot * park_int4<TAB>();
     q[lane] = r.lo;
-    if (!tab_compact(TAB)) {
-        q[kWave + lane] = r.hi;
-        q[2 * kWave + lane] = make_int4(r.tm, 0, 0, 0);
-    }
+    if (!tab_compact(TAB)) q[kWave + lane] = r.hi;
+    if (!tab_no_clocks(TAB)) q[2 * kWave + lane] = make_int4(r.tm, 0, 0, 0);
     if (c.gl == 0) {                                   // per env: its header, its instance constants
         int4 *g = q + park_lane_int4<TAB>() * kWave + 2 * (lane / G);
         g[0] = r.h;
-        if (TAB == kTabGlobal) g[1] = make_int4(c.J, c.M, c.max_time_op, c.tid);
+        if (tab_global(TAB)) g[1] = make_int4(c.J, c.M, c.max_time_op, c.tid);
     }
     wave_lds_sync();                                   // the group's lanes read what its lane 0 wrote
 }
@@ -1079,11 +1121,9 @@ __device__ __forceinline__ PRaw<G> p_unpark(const int4 *park, int slot, int lane
     r.lo = q[lane];
     r.hi = make_int4(0, 0, 0, 0);
     r.tm = 0;
-    if (!tab_compact(TAB)) {
-        r.hi = q[kWave + lane];
-        r.tm = q[2 * kWave + lane].x;
-    }
-    if (TAB == kTabGlobal) {                           // the set's instance constants (an env's restart may change them)
+    if (!tab_compact(TAB)) r.hi = q[kWave + lane];
+    if (!tab_no_clocks(TAB)) r.tm = q[2 * kWave + lane].x;
+    if (tab_global(TAB)) {                             // the set's instance constants (an env's restart may change them)
         const int4 k = g[1];
         c.J = k.x;
         c.M = k.y;
@@ -1143,7 +1183,7 @@ __global__ __launch_bounds__(kBlock, 6) void jss_packed_session_kernel(Params p)
         if (!sl.live) break;
         const size_t fe = (size_t)c.first_env;
         PRaw<G> raw = p_issue_loads<G, TAB>(c, p);
-        if (TAB == kTabGlobal) {
+        if (tab_global(TAB)) {
             const int4 hx = ld_off<int4>(p.s.env_const + fe * JSS_NC, c.rel * (JSS_NC * 4u));
             if (c.gl < 6) c.norm[c.gl] = ld_off<int>(p.s.env_const + fe * JSS_NC, c.rel * (JSS_NC * 4u) + 16u + (unsigned)c.gl * 4u);
             c.J = hx.x;

@@ -324,7 +324,7 @@ class BatchedJssEnv:
 
     def __init__(self, instances, batch: Optional[int] = None, device=None, env_id_base: int = 0,
                  table_of_env: Optional[Sequence[int]] = None, seed: int = 0, kernel: Optional[str] = None,
-                 compact: Optional[bool] = None, host_arena: bool = False, _backend=None):
+                 compact: Optional[bool] = None, host_arena: bool = False, records: Optional[str] = None, _backend=None):
         self._owns_backend = _backend is None
         self.backend = be = _backend if _backend is not None else make_backend(device)
         if isinstance(instances, PackedBatch):
@@ -356,13 +356,27 @@ class BatchedJssEnv:
         self.machines_per_env = pk.machines[self.table_of_env_host]
         # job records: 16-byte compact records (no cached ops: they are read from the ONE op table, which every workgroup
         # has in LDS) whenever the batch shares one instance; 32-byte records otherwise
+        if records is not None:                       # explicit layout: "compact" (16 B), "medium" (24 B) or "full" (32 B)
+            if records not in ("compact", "medium", "full"):
+                raise ValueError("records must be 'compact', 'medium' or 'full'")
+            compact = records == "compact"
         self.compact = (n == 1) if compact is None else bool(compact)
         if self.compact and n != 1:
             raise ValueError("compact job records need a batch that shares one instance")
-        self.record_ints = _abi.NFC if self.compact else _abi.NF
         self.kernel = kernel if kernel is not None else getattr(be, "default_kernel", "auto")
         if self.kernel not in _abi.KERNEL:
             raise ValueError(f"kernel must be one of {list(_abi.KERNEL)}")
+        # 24-byte medium records (the three cached ops in 21 bits each, no machine clocks) for batches of different instances.
+        # The library takes them for every shape the packed kernels serve (jobs, machines <= 32); by default they are used
+        # where they measure faster than full records: the 16-lane groups (jobs, machines <= 16: +8-10 % on 15 x 15; with 32-lane
+        # groups the three 8-byte accesses and the unpacking cost more than the bytes save, -2 % on 20 x 20 --
+        # profiles/README.md).  `compact=False` / records="full" asks for full records everywhere.
+        fits = n != 1 and self.kernel == "auto" and pk.jmax <= 32 and pk.mmax <= 32
+        if records == "medium" and not fits:
+            raise ValueError("medium job records need per-env instances with jobs, machines <= 32 and the packed kernels")
+        self.medium = records == "medium" or (records is None and compact is None and fits and pk.jmax <= 16 and pk.mmax <= 16)
+        self.record_ints = _abi.NFC if self.compact else _abi.NFM if self.medium else _abi.NF
+        self.no_clocks = self.compact or self.medium           # time_until_available_machine is derived, not stored
 
         with be.on_device():
             # instance tables
@@ -385,7 +399,7 @@ class BatchedJssEnv:
                      ("reward", (B,), "float32"), ("done", (B,), "uint8"), ("makespan", (B,), "int32"),
                      ("_actions_out", (B,), "int32"), ("_hole", (B,), "int32"), ("_act_buf", (B,), "int32"),
                      ("_act_in", (B,), "int32"), ("_which_in", (B,), "uint8")]
-            if self.compact:
+            if self.no_clocks:
                 specs = [sp for sp in specs if sp[0] != "machine_state"]
             self._layout, off = {}, 0
             for name, shape, dtype in specs:
@@ -412,7 +426,7 @@ class BatchedJssEnv:
                                   self.env_id_base, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)),
                                   int(pk.jobs.min()), self.record_ints)
         self._state = _abi.JssState(p(self.env_header), p(self.env_const), p(self.job_state),
-                                    None if self.compact else p(self.machine_state), p(self.solution),
+                                    None if self.no_clocks else p(self.machine_state), p(self.solution),
                                     p(self.counters))
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
         self._is_reset = False
@@ -725,12 +739,18 @@ class BatchedJssEnv:
 
     @property
     def todo_time_step_job(self):
-        return self.job_state[:, :, 0] & (_abi.FC_TODO_MASK if self.compact else _abi.TODO_MASK)
+        return self.job_state[:, :, 0] & (_abi.FC_TODO_MASK if self.compact else _abi.FM_TODO_MASK if self.medium else _abi.TODO_MASK)
 
     def _word(self, f):
         """Word JSS_F_* `f` (LEFT, PERF, IDLE, IDLE_LAST) of every job record as a (B, J) tensor, whichever record layout
         the batch uses (a view of the state for full records, decoded from the packed words for compact ones)."""
         js = self.job_state
+        if self.medium:
+            if f == _abi.F_LEFT:
+                return js[:, :, _abi.FM_LEFT_F4] & 0xFFFF
+            if f == _abi.F_PERF:
+                return js[:, :, _abi.FM_PERF_NEXT] & _abi.FM_OP_MASK
+            return js[:, :, {_abi.F_IDLE: _abi.FM_IDLE, _abi.F_IDLE_LAST: _abi.FM_IDLE_LAST}[f]]
         if not self.compact:
             return js[:, :, f]
         if f == _abi.F_LEFT:
@@ -743,6 +763,8 @@ class BatchedJssEnv:
     def needed_machine_jobs(self):
         """(B, J) machine of every job's current op, -1 once the job is finished (same kind of array as the state
         tensors).  With compact records the op is not stored: it is looked up in the batch's one op table."""
+        if self.medium:
+            return self._current_ops() >> 16
         if not self.compact:
             return self.job_state[:, :, _abi.F_CUR] >> 16
         return self._current_ops() >> 16                      # a finished job's "op" is -1, and -1 >> 16 == -1
@@ -750,7 +772,14 @@ class BatchedJssEnv:
     def _current_ops(self):
         """(B, J) op table entry [j][todo_time_step_job[j]] of a compact batch (machine << 16 | duration), -1 where the
         job is finished -- what a full record carries as its JSS_F_CUR word."""
-        js, M, J = self.job_state, int(self.packed.machines[0]), self.jmax
+        js = self.job_state
+        if self.medium:                                       # the record carries the op itself (21 bits, 0 = job finished)
+            cur = (js[:, :, _abi.FM_W0] >> _abi.FM_CUR_SHIFT) & _abi.FM_OP_MASK
+            if isinstance(js, np.ndarray):
+                return np.where(cur != 0, cur, -1).astype(np.int32)
+            import torch
+            return torch.where(cur != 0, cur, torch.full_like(cur, -1))
+        M, J = int(self.packed.machines[0]), self.jmax
         todo = js[:, :, _abi.FC_W0] & _abi.FC_TODO_MASK
         if isinstance(js, np.ndarray):
             cur = self.packed.ops[0][np.arange(J)[None, :], np.minimum(todo, M - 1)]
@@ -785,19 +814,19 @@ class BatchedJssEnv:
 
     @property
     def action_illegal_no_op(self):
-        return (self.job_state[:, :, 0] >> (8 if self.compact else 9)) & 1
+        return (self.job_state[:, :, 0] >> (8 if self.compact else 7 if self.medium else 9)) & 1
 
     def __getattr__(self, name):
         # compact batches keep no machine clocks in memory: time_until_available_machine[m] is the time left of the job
         # running on m (both are set to the op's duration at jss_env.py:446-449 and count down together, :521-530)
-        if name == "machine_state" and self.__dict__.get("compact"):
+        if name == "machine_state" and self.__dict__.get("no_clocks"):
             return self._clocks_from_records()
         raise AttributeError(name)
 
     def _clocks_from_records(self):
         """(B, M) int32 time_until_available_machine of a compact batch, computed from its job records where they live."""
         js, cur = self.job_state, self._current_ops()
-        left = js[:, :, _abi.FC_LEFT_F4] & 0xFFFF
+        left = js[:, :, _abi.FC_LEFT_F4] & 0xFFFF             # (the same word and bits in the medium record)
         if isinstance(js, np.ndarray):
             tm = np.zeros((self.batch, self.mmax), dtype=np.int32)
             b, j = np.nonzero((cur >= 0) & (left > 0))
@@ -833,8 +862,8 @@ class BatchedJssEnv:
     _STATE_TENSORS = ("env_header", "env_const", "job_state", "machine_state", "solution", "counters", "real_obs", "action_mask",
                       "reward", "done", "makespan")
 
-    def _saved_tensors(self):                      # a compact batch has no machine clocks to save: they are derived
-        return tuple(k for k in self._STATE_TENSORS if k != "machine_state" or not self.compact)
+    def _saved_tensors(self):                      # a compact / medium batch has no machine clocks to save: they are derived
+        return tuple(k for k in self._STATE_TENSORS if k != "machine_state" or not self.no_clocks)
 
     def state_dict(self):
         """Host copy of everything needed to resume: state + last outputs + the batch description."""
@@ -852,7 +881,7 @@ class BatchedJssEnv:
         if int(m.get("abi", 0)) != _abi.STATE_LAYOUT:
             raise ValueError(f"checkpoint was written with state layout v{m.get('abi')}, this build is v{_abi.STATE_LAYOUT}")
         if int(m.get("record_ints", _abi.NF)) != self.record_ints:
-            raise ValueError("checkpoint uses the other job-record layout (compact vs full)")
+            raise ValueError("checkpoint uses another job-record layout (compact / medium / full)")
         if (int(m["batch"]), int(m["jmax"]), int(m["mmax"])) != (self.batch, self.jmax, self.mmax) or \
                 not np.array_equal(m["ops"], self.packed.ops) or not np.array_equal(m["table_of_env"], self.table_of_env_host):
             raise ValueError("checkpoint belongs to a different batch (shape or instances differ)")
@@ -890,7 +919,16 @@ class BatchedJssEnv:
         raw = np.asarray(raw)[:J].astype(np.int64)                 # the record's words, signed
         u0 = raw[:, 0] & 0xFFFFFFFF                                 # word 0 as the bit field it is
         js = np.zeros((8, J), dtype=np.int64)
-        if self.compact:
+        if self.medium:
+            u1, u2, u3 = (raw[:, k] & 0xFFFFFFFF for k in (_abi.FM_LEFT_F4, _abi.FM_PERF_NEXT, _abi.FM_NEXT_NEXT2))
+            op = lambda x: np.where(x != 0, x, -1)                  # noqa: E731  21-bit op, 0 = none
+            js[_abi.F_TODO], js[7] = u0 & _abi.FM_TODO_MASK, (u0 >> 6) & 3
+            js[_abi.F_CUR] = op((u0 >> _abi.FM_CUR_SHIFT) & _abi.FM_OP_MASK)
+            nxt, nxt2 = op((u2 >> 21) | ((u3 & 0x3FF) << 11)), op((u3 >> 10) & _abi.FM_OP_MASK)
+            js[_abi.F_LEFT], js[_abi.F_PERF] = u1 & 0xFFFF, u2 & _abi.FM_OP_MASK
+            js[_abi.F_F4] = np.where(u0 & _abi.FM_FLAG_F4_ONE, _abi.F4_ONE, u1 >> 16)
+            js[_abi.F_IDLE], js[_abi.F_IDLE_LAST] = raw[:, _abi.FM_IDLE], raw[:, _abi.FM_IDLE_LAST]
+        elif self.compact:
             u1 = raw[:, _abi.FC_LEFT_F4] & 0xFFFFFFFF
             todo = u0 & _abi.FC_TODO_MASK
             js[_abi.F_TODO], js[7] = todo, (u0 >> 7) & 3
@@ -949,7 +987,7 @@ class BatchedJssEnv:
             "job_state": js,
             "next_op": nxt,
             "next2_op": nxt2,
-            "tm": self.clocks_from_jobs(js, M) if self.compact else t["machine_state"][:M].astype(np.int64),
+            "tm": self.clocks_from_jobs(js, M) if self.no_clocks else t["machine_state"][:M].astype(np.int64),
             "mask": t["action_mask"][:J + 1].astype(bool),
             "mask_padding": t["action_mask"][J + 1:].copy(),
             "blocked": (js[7] & 2) != 0,

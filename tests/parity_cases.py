@@ -134,9 +134,9 @@ def case_random_golden(backend, inst, max_rows=None):
 # batched API: ragged batch, on-device policies, every env compared with its own oracle
 # -----------------------------------------------------------------------------------------
 def case_batch_lockstep(backend, inst_names, batch, n_steps, kind="random", seed=11, nope_every=0, check_every=1,
-                        explore=0.0):
+                        explore=0.0, records=None):
     insts = [I.builtin_instance(n) if isinstance(n, str) else n for n in inst_names]
-    env = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=1000, _backend=backend)
+    env = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=1000, records=records, _backend=backend)
     orcs = [OracleEnv(insts[t], strict=True) for t in env.table_of_env_host]
     env.reset()
     for o in orcs:
@@ -589,8 +589,11 @@ def case_instance_resampling(backend):
     assert row[:15].all() and not row[15:].any(), row
     # ... and so must the rows behind the new J of every state tensor: nothing of the larger instance survives a reset
     js = env.backend.numpy(env.job_state)[4]
-    assert (js[15:, _abi.F_CUR] == -1).all() and (js[15:, _abi.F_NEXT] == -1).all(), js[15:]
-    assert not js[15:, [_abi.F_TODO, _abi.F_LEFT, _abi.F_PERF, _abi.F_IDLE, _abi.F_IDLE_LAST, _abi.F_F4]].any(), js[15:]
+    if env.medium:            # 24-byte records: "no job" is an all-zero record (op 0 = none)
+        assert not js[15:].any(), js[15:]
+    else:
+        assert (js[15:, _abi.F_CUR] == -1).all() and (js[15:, _abi.F_NEXT] == -1).all(), js[15:]
+        assert not js[15:, [_abi.F_TODO, _abi.F_LEFT, _abi.F_PERF, _abi.F_IDLE, _abi.F_IDLE_LAST, _abi.F_F4]].any(), js[15:]
     assert (env.backend.numpy(env.solution)[4] == -1).all()
     assert not env.backend.numpy(env.machine_state)[4].any()
     cst = env.backend.numpy(env.env_const)[4]
@@ -1097,7 +1100,7 @@ def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=
 
 def _state_snapshot(env):
     n = env.backend.numpy
-    return {k: n(getattr(env, k)) for k in BatchedJssEnv._STATE_TENSORS if k != "machine_state" or not env.compact}
+    return {k: n(getattr(env, k)) for k in BatchedJssEnv._STATE_TENSORS if k != "machine_state" or not env.no_clocks}
 
 
 def case_step_graph_replay(backend, inst="ta01", batch=4096, K=40, warm=60, seed=8):
@@ -1481,3 +1484,68 @@ def case_steps_and_session_edges(backend, emulator=False):
     got = _state_snapshot(env2)
     for name in want:
         assert np.array_equal(got[name], want[name]), f"session (never-reset envs, ragged last wavefront) differs in {name}"
+
+
+def case_medium_equals_full(backend, batch=40, n_iter=500, seed=29):
+    """Batches of different instances whose shapes the packed kernels serve keep 24-byte medium records (three 21-bit
+    cached ops, no machine clocks); `compact=False` keeps the full 32-byte records.  Same batch, same policy: the decoded
+    state is equal after every chunk, and equal to the oracle at the end."""
+    rng = np.random.default_rng(seed)
+    sets = [[I.builtin_instance(nm) for nm in ("ta01", "ta02", "ta03")],                      # 15 x 15, env -> instance map (G16)
+            [I.builtin_instance("ta21"), I.builtin_instance("ta11"), random_instance(rng, 32, 32, max_dur=200)],   # ragged, G32
+            [random_instance(rng, 7, 5, max_dur=9) for _ in range(batch)]]                     # one table per env
+    for insts in sets:
+        a = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=7, records="medium", _backend=backend)
+        b = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=7, records="full", _backend=backend)
+        assert a.medium and not b.medium and a.job_state.shape[-1] == _abi.NFM and b.job_state.shape[-1] == _abi.NF
+        assert "machine_state" not in a._layout and "machine_state" in b._layout
+        a.reset()
+        b.reset()
+        for chunk in (1, 3, n_iter // 2, n_iter - n_iter // 2 - 4):
+            a.rollout("random", n_iter=chunk)
+            b.rollout("random", n_iter=chunk)
+            for i in range(0, batch, max(1, batch // 6)):
+                ha, hb = a.host_state(i), b.host_state(i)
+                for key in ("clock", "reward", "done", "err", "noop_flag", "makespan", "episode", "step_in_episode"):
+                    assert ha[key] == hb[key], (key, i)
+                for key in ("job_state", "next_op", "next2_op", "tm", "mask", "blocked", "obs", "solution", "counters"):
+                    assert np.array_equal(ha[key], hb[key]), f"medium vs full records: {key} of env {i}"
+            for name in ("todo_time_step_job", "needed_machine_jobs", "time_until_finish_current_op_jobs", "total_perform_op_time_jobs",
+                         "total_idle_time_jobs", "idle_time_jobs_last_op", "action_illegal_no_op", "machine_state"):
+                x, y = np.asarray(a.backend.numpy(getattr(a, name))), np.asarray(b.backend.numpy(getattr(b, name)))
+                live = np.arange(a.jmax)[None, :] < a.jobs_per_env[:, None]
+                if x.shape == live.shape:
+                    x, y = np.where(live, x, 0), np.where(live, y, 0)
+                assert np.array_equal(x, y), f"medium vs full records: attribute {name}"
+        toe = a.table_of_env_host if a._table_of_env is not None else None
+        want = rollout_batch(a.packed, a.batch, "random", seed, n_iter, table_of_env=toe, env_id_base=7)
+        assert np.array_equal(a.backend.numpy(a.env_header)[:, _abi.H_CLOCK], want["clock"])
+        assert np.array_equal(a.backend.numpy(a.solution), want["solution"]) and np.array_equal(a.backend.numpy(a.counters), want["counters"])
+        d = a.state_dict()                                   # checkpoint round trip of the medium layout
+        c = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=7, records="medium", _backend=backend)
+        c.load_state_dict(d)
+        c.rollout("random", n_iter=5)
+        a.rollout("random", n_iter=5)
+        assert np.array_equal(a.backend.numpy(a.job_state), c.backend.numpy(c.job_state))
+        try:
+            b.load_state_dict(d)
+            raise AssertionError("a medium checkpoint must not load into a full-record batch")
+        except ValueError:
+            pass
+
+
+def case_medium_limits(backend, seed=5, jobs=32):
+    """The packed words of the medium record at the library's limits: 32 jobs x 32 machines, durations 65535 (op =
+    31 << 16 | 65535 = all 21 bits set, total_perform_op_time_jobs up to 32 x 65535 < 2^21, todo up to 32), in lock step
+    with the oracle to the end of the episode."""
+    rng = np.random.default_rng(seed)
+    insts = []
+    for k, (J, M) in enumerate(((jobs, 32), (jobs, 32), (3, 32))):
+        machine = np.stack([rng.permutation(M) for _ in range(J)]).astype(np.int32)
+        duration = np.full((J, M), 65535, dtype=np.int32) if k < 2 else (65535 - rng.integers(0, 3, size=(J, M))).astype(np.int32)
+        insts.append(I.Instance(f"limit_medium_{k}", machine, duration))
+    env, orcs = case_batch_lockstep(backend, insts, batch=6, n_steps=2 * jobs * 32 + 200, kind="random", seed=seed, check_every=64,
+                                    records="medium")
+    assert env.medium
+    h = env.host_state(0)
+    assert h["done"] and (h["job_state"][_abi.F_PERF] == 32 * 65535).all() and (h["job_state"][_abi.F_TODO] == 32).all()

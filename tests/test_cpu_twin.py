@@ -250,3 +250,15 @@ def test_critical_ratio_due_date_factor_on_device(cpu):
 
 def test_steps_and_session_edges(cpu):
     P.case_steps_and_session_edges(cpu)
+
+
+def test_medium_records_equal_full_records(cpu):
+    if getattr(cpu, "default_kernel", "auto") != "auto":
+        pytest.skip("medium records are a packed-kernel layout")
+    P.case_medium_equals_full(cpu)
+
+
+def test_medium_records_at_the_limits(cpu):
+    if getattr(cpu, "default_kernel", "auto") != "auto":
+        pytest.skip("medium records are a packed-kernel layout")
+    P.case_medium_limits(cpu)

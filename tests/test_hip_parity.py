@@ -356,3 +356,15 @@ def test_critical_ratio_due_date_factor_on_device(hip):
 
 def test_steps_and_session_edges(hip):
     P.case_steps_and_session_edges(hip)
+
+
+def test_medium_records_equal_full_records(hip):
+    if getattr(hip, "default_kernel", "auto") != "auto":
+        pytest.skip("medium records are a packed-kernel layout")
+    P.case_medium_equals_full(hip, batch=700, n_iter=900)
+
+
+def test_medium_records_at_the_limits(hip):
+    if getattr(hip, "default_kernel", "auto") != "auto":
+        pytest.skip("medium records are a packed-kernel layout")
+    P.case_medium_limits(hip)
