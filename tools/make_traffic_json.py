@@ -19,7 +19,7 @@ WORKLOADS = {
     "ta01_b65536": ("ta01_single", "jss_packed_kernel<16, 5, 2>", "jss_packed_kernel<16,kRollout1,kTabLdsC>", b_alg(15, 15), 65536),
     "ta01_b262144": ("ta01_b262144", "jss_packed_kernel<16, 5, 2>", "jss_packed_kernel<16,kRollout1,kTabLdsC>", b_alg(15, 15), 262144),
     "ta01_b4096": ("ta01_b4096", "jss_packed_kernel<16, 5, 2>", "jss_packed_kernel<16,kRollout1,kTabLdsC>", b_alg(15, 15), 4096),
-    "syn15x15_b65536": ("syn15x15", "jss_packed_kernel<16, 5, 1>", "jss_packed_kernel<16,kRollout1,kTabGlobal>", b_alg(15, 15), 65536),
+    "syn15x15_b65536": ("syn15x15", "jss_packed_kernel<16, 5, 3>", "jss_packed_kernel<16,kRollout1,kTabGlobalM> (24-byte medium records)", b_alg(15, 15), 65536),
     "ta41_b16384": ("ta41", "jss_packed_kernel<32, 5, 2>", "jss_packed_kernel<32,kRollout1,kTabLdsC>", b_alg(30, 20), 16384),
     "syn50x20_b8192": ("syn50x20", "jss_kernel<1, 5, 1>", "jss_kernel<1,kRollout1,kTabGlobal>", b_alg(50, 20), 8192),
     "mixed_b32768": ("mixed", "jss_kernel<2, 5, 1>", "jss_kernel<2,kRollout1,kTabGlobal> (one-job-per-lane body for J <= 64)", None, 32768),
