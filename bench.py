@@ -561,6 +561,29 @@ def main():
             torch.cuda.synchronize()
             return {"value": None, "error": f"{type(exc).__name__}: {exc}"}
 
+    def unfused_pipelined(env, policy, alg, B):
+        """The un-fused loop with the policy a launch of its own (jss_policy stands in for a policy network), the actions
+        through HBM and the auto-reset folded into the step kernel -- issued by the library over 2 or 3 sub-batches on as
+        many streams, so that one sub-batch's policy overlaps another's step (jss_policy_step_steps): what a learner that
+        double-buffers its env batch gets per env step."""
+        try:
+            n2 = max(20, min(100, args.steps))
+            best = None
+            for n_sub in (1, 2, 3):
+                def run(n, n_sub=n_sub):
+                    env.policy_step_steps(policy, steps=n, n_sub=n_sub, autoreset=True)
+                med, rows = measure(env, policy, n2, "eager", run=run)
+                if best is None or med["rate"] > best[0]["rate"]:
+                    best = (med, rows, n_sub)
+            med, rows, n_sub = best
+            return {"value": med["rate"], "unit": "env steps/s", "ms_per_step": med["seconds"] / n2 * 1e3, "n_sub": n_sub,
+                    "roofline_frac": roofline(med, alg, n2, env, None, B)["frac"], "windows": window_stats(rows, n2),
+                    "note": "jss_policy -> actions in HBM -> jss_step_autoreset per sub-batch and step (jss_policy_step_steps), "
+                            "sub-batches on their own streams"}
+        except Exception as exc:
+            torch.cuda.synchronize()
+            return {"value": None, "error": f"{type(exc).__name__}: {exc}"}
+
     def external_action_forms(env, policy, alg, K):
         """The step entry points that take the caller's actions, with the actions already resident in HBM (a recorded
         behaviour trajectory of `policy` from the current state, consumed window after window -- every launch executes
@@ -664,6 +687,7 @@ def main():
         if with_trajectory and not bucketed:
             out["trajectory"] = traj_measure(env, policy, alg)
         if with_external and not bucketed:
+            out["policy_then_step_pipelined"] = unfused_pipelined(env, policy, alg, batch)
             out["step_only"] = step_only_measure(env, policy, alg, batch)
             out["external_actions"] = external_action_forms(env, policy, alg, args.steps)
         if keep:
@@ -749,6 +773,7 @@ def main():
         except Exception as exc:
             out["policy_then_step_two_launches"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.synchronize()
+        out["policy_then_step_pipelined"] = unfused_pipelined(env, args.policy, alg_per_step, B)
         try:
             # ---- the B = 1 drop-in facade (make('jss-v1')): what a user who only swaps the package gets per step()
             from jssenv_amd import make

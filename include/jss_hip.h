@@ -393,6 +393,16 @@ int jss_sync_check(void *stream);
 int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
                       uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub, void *const *streams);
 
+/* The UN-fused loop `a = policy(obs); obs, r, done = envs.step(a)` (README.md:53-64 with a vector env), n_steps times, with
+ * the policy a launch of its own (jss_policy as the stand-in for the caller's policy network) and the actions going through
+ * memory: per step and sub-batch jss_policy -> `actions` -> jss_step (jss_step_autoreset with JSS_ROLLOUT_AUTORESET), the
+ * sub-batches on n_sub streams so that one sub-batch's policy overlaps another's step.  Same results as n_steps x
+ * (jss_policy, jss_step) over the whole batch.  `actions` = int32 [B] scratch of the caller.  Streams and
+ * JSS_ROLLOUT_FORK_JOIN as jss_rollout_steps. */
+int jss_policy_step_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
+                          uint32_t explore_q16, int32_t *actions, int32_t n_steps, int32_t flags, int32_t n_sub,
+                          void *const *streams);
+
 /* The same for SEVERAL independent env sets at once (the shape classes of a ragged population, each a compact batch of
  * its own: jssenv_amd.BucketedJssEnv): n_steps x jss_rollout(n_iter = 1) per set, set i on streams[i], the launches
  * issued step-major (step s of every set before step s + 1 of any), so that sets whose streams share a hardware queue

@@ -55,7 +55,7 @@ MAX_SUB_BATCHES = 16
 
 SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_backend", "jss_reset", "jss_step", "jss_advance", "jss_policy",
            "jss_rollout", "jss_rollout_steps", "jss_rollout_steps_multi", "jss_trajectory", "jss_sync_check",
-           "jss_step_autoreset", "jss_steps", "jss_session_open", "jss_session_post", "jss_session_wait", "jss_session_step", "jss_session_close")
+           "jss_step_autoreset", "jss_policy_step_steps", "jss_steps", "jss_session_open", "jss_session_post", "jss_session_wait", "jss_session_step", "jss_session_close")
 
 _p = C.c_void_p
 
@@ -110,6 +110,9 @@ def bind(lib):
     lib.jss_rollout_steps.restype = C.c_int
     lib.jss_rollout_steps.argtypes = [D, S, O, C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(_p)]
+    lib.jss_policy_step_steps.restype = C.c_int
+    lib.jss_policy_step_steps.argtypes = [D, S, O, C.c_int, C.c_uint64, C.c_uint32, _p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.POINTER(_p)]
     lib.jss_rollout_steps_multi.restype = C.c_int
     lib.jss_rollout_steps_multi.argtypes = [C.c_int32, C.POINTER(D), C.POINTER(S), C.POINTER(O), C.c_int, C.c_uint64, C.c_uint32,
                                             C.c_int32, C.c_int32, C.POINTER(_p)]

@@ -904,6 +904,21 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
     return jss_rollout(desc, state, out, kind, seed, explore_q16, n_steps, flags, nullptr);
 }
 
+// the un-fused loop: envs are independent and every call is synchronous, so sub-batches and streams have nothing to overlap
+int jss_policy_step_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
+                          uint32_t explore_q16, int32_t *actions, int32_t n_steps, int32_t flags, int32_t n_sub,
+                          void *const *streams) {
+    if (n_steps < 0 || n_sub < 1 || n_sub > 16) return desc && state ? JSS_E_SHAPE : JSS_E_NULL;
+    if (!streams || !actions) return JSS_E_NULL;
+    for (int s = 0; s < n_steps; ++s) {
+        int rc = jss_policy(desc, state, kind, seed, explore_q16, actions, nullptr);
+        if (!rc) rc = (flags & JSS_ROLLOUT_AUTORESET) ? jss_step_autoreset(desc, state, actions, out, nullptr)
+                                                     : jss_step(desc, state, actions, out, nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // several independent env sets: each is its own synchronous rollout here
 int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states,
                             const JssOut *const *outs, int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps,

@@ -574,6 +574,44 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
     return rc ? rc : jrc;
 }
 
+int jss_policy_step_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
+                          uint32_t explore_q16, int32_t *actions, int32_t n_steps, int32_t flags, int32_t n_sub,
+                          void *const *streams) {
+    int rc = check_args(desc, state, out, true);
+    if (rc) return rc;
+    if ((rc = check_kind(desc, kind))) return rc;
+    if (n_steps < 0 || n_sub < 1 || n_sub > 16) return JSS_E_SHAPE;
+    if (!streams || !actions) return JSS_E_NULL;
+    Params pp = {}, ps = {};
+    pp.d = *desc; pp.s = *state; pp.actions_out = actions; pp.kind = kind; pp.seed = seed; pp.explore_q16 = explore_q16;
+    ps.d = *desc; ps.s = *state; ps.o = *out; ps.actions = actions; ps.flags = flags & JSS_ROLLOUT_AUTORESET;
+    LaunchPlan lpp, lps;
+    if ((rc = plan<kPolicy>(pp, lpp)) || (rc = plan<kStep>(ps, lps))) return rc;
+    const int chunk = (((desc->batch + n_sub - 1) / n_sub) + 63) & ~63;       // whole workgroups, 16-byte aligned rows
+    Params subp[16], subs[16];
+    int n = 0;
+    for (int i = 0; i < n_sub; ++i) {
+        const int start = i * chunk;
+        if (start >= desc->batch) break;
+        const int count = desc->batch - start < chunk ? desc->batch - start : chunk;
+        subp[n] = sub_batch(pp, start, count);
+        subp[n].actions_out = actions + start;
+        subs[n] = sub_batch(ps, start, count);
+        subs[n].actions = actions + start;
+        ++n;
+    }
+    const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n > 1;
+    ForkJoinEvents *ev = nullptr;
+    if (fork_join && ((rc = events_for(streams[0], &ev)) || (rc = fork_streams(*ev, streams, n)))) return rc;
+    for (int s = 0; s < n_steps && !rc; ++s)
+        for (int i = 0; i < n && !rc; ++i) {
+            rc = fire(subp[i], lpp, streams[i]);
+            if (!rc) rc = fire(subs[i], lps, streams[i]);
+        }
+    const int jrc = fork_join ? join_streams(*ev, streams, n) : 0;
+    return rc ? rc : jrc;
+}
+
 int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states,
                             const JssOut *const *outs, int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps,
                             int32_t flags, void *const *streams) {

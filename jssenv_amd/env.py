@@ -598,6 +598,32 @@ class BatchedJssEnv:
         _abi.check(be.lib, rc, "jss_rollout_steps")
         return self._obs(), self.reward, self.done, False, {}
 
+    def policy_step_steps(self, kind: Union[str, int] = "random", steps: int = 1, n_sub: int = 2, seed: Optional[int] = None,
+                          autoreset: bool = True, explore: float = 0.0, caller_orders_streams: bool = False):
+        """``steps`` x (``policy`` -> actions in memory -> ``step``): the UN-fused loop of a learner whose policy is a
+        launch of its own (``jss_policy`` stands in for it), issued by the library over ``n_sub`` sub-batches on ``n_sub``
+        streams so that one sub-batch's policy overlaps another's step (``jss_policy_step_steps``).  Same results as the
+        Python loop ``for _ in range(steps): env.step(env.policy(kind), autoreset=autoreset)``."""
+        if not self._is_reset:
+            raise RuntimeError("call reset() before policy_step_steps()")
+        if not 1 <= int(n_sub) <= _abi.MAX_SUB_BATCHES:
+            raise ValueError(f"n_sub must be in [1, {_abi.MAX_SUB_BATCHES}]")
+        be = self.backend
+        k = _abi.policy_code(kind)
+        flags = (_abi.ROLLOUT_AUTORESET if autoreset else 0)
+        d, s, o = self._refs()
+        sd, q16 = self.seed if seed is None else int(seed), int(round(explore * 65536))
+        with be.on_device():
+            if hasattr(be, "stream_array"):
+                flags |= 0 if caller_orders_streams else _abi.ROLLOUT_FORK_JOIN
+                rc = be.lib.jss_policy_step_steps(d, s, o, k, sd, q16, be.ptr(self._actions_out), int(steps), flags, int(n_sub),
+                                                  be.stream_array(int(n_sub)))
+            else:
+                rc = be.with_streams(int(n_sub), lambda streams: be.lib.jss_policy_step_steps(
+                    d, s, o, k, sd, q16, be.ptr(self._actions_out), int(steps), flags, int(n_sub), streams), self._stream_events)
+        _abi.check(be.lib, rc, "jss_policy_step_steps")
+        return self._obs(), self.reward, self.done, False, {}
+
     def bind_rollout_steps(self, kind: Union[str, int] = "random", steps: int = 1, n_sub: int = 2, seed: Optional[int] = None,
                            autoreset: bool = True, explore: float = 0.0, caller_orders_streams: bool = False):
         """``rollout_steps`` with every argument resolved now: returns a zero-argument callable that issues the same

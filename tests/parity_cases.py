@@ -1549,3 +1549,22 @@ def case_medium_limits(backend, seed=5, jobs=32):
     assert env.medium
     h = env.host_state(0)
     assert h["done"] and (h["job_state"][_abi.F_PERF] == 32 * 65535).all() and (h["job_state"][_abi.F_TODO] == 32).all()
+
+
+def case_policy_step_steps(backend, batch=300, steps=9, seed=13):
+    """jss_policy_step_steps (the un-fused loop over sub-batches on several streams) == the Python loop
+    `env.step(env.policy(kind), autoreset=True)` == the fused rollout: every tensor bit-identical."""
+    for kw, kind in ((dict(instances="ta01"), "random"), (dict(instances=[I.builtin_instance(n) for n in ("ta01", "ta31")]), "SPT")):
+        a = BatchedJssEnv(batch=batch, seed=seed, env_id_base=3, _backend=backend, **kw)
+        b = BatchedJssEnv(batch=batch, seed=seed, env_id_base=3, _backend=backend, **kw)
+        for e in (a, b):
+            e.reset()
+            e.rollout(kind, n_iter=230 if kind == "random" else 5)         # some envs are about to finish
+        a.policy_step_steps(kind, steps=steps, n_sub=3)
+        for _ in range(steps):
+            b.step(b.policy(kind), autoreset=True)
+        a.synchronize()
+        sa, sb = _state_snapshot(a), _state_snapshot(b)
+        for name in sa:
+            assert np.array_equal(sa[name], sb[name]), f"policy_step_steps differs from the policy / step loop in {name}"
+        assert a.stats()["steps"] > 0

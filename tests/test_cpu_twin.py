@@ -262,3 +262,7 @@ def test_medium_records_at_the_limits(cpu):
     if getattr(cpu, "default_kernel", "auto") != "auto":
         pytest.skip("medium records are a packed-kernel layout")
     P.case_medium_limits(cpu)
+
+
+def test_policy_step_steps_equals_the_loop(cpu):
+    P.case_policy_step_steps(cpu)

@@ -368,3 +368,7 @@ def test_medium_records_at_the_limits(hip):
     if getattr(hip, "default_kernel", "auto") != "auto":
         pytest.skip("medium records are a packed-kernel layout")
     P.case_medium_limits(hip)
+
+
+def test_policy_step_steps_equals_the_loop(hip):
+    P.case_policy_step_steps(hip, batch=5000, steps=30)

@@ -171,3 +171,7 @@ def test_medium_records_at_the_limits(emu):
     if getattr(emu, "default_kernel", "auto") != "auto":
         pytest.skip("medium records are a packed-kernel layout")
     P.case_medium_limits(emu, jobs=4)
+
+
+def test_policy_step_steps_equals_the_loop(emu):
+    P.case_policy_step_steps(emu, batch=70, steps=3)

@@ -18,7 +18,7 @@ rf = d["roofline"]
 print(f"headline {d['value']:.4g} steps/s  {d['ms_per_step'] * 1e3:.2f} us/step  frac {rf['frac']:.3f}  own-bytes {rf.get('frac_own_bytes')}  "
       f"gpu-time {rf['frac_gpu_time']:.3f}  windows {d['windows']}")
 print("  wave_cycles/env-step", rf.get("wave_cycles_per_env_step"), "wait_fraction", rf.get("wait_fraction"))
-for k in ("single_launch_per_step", "step_only", "trajectory", "policy_then_step_two_launches", "fused_rollout", "facade_b1"):
+for k in ("single_launch_per_step", "step_only", "trajectory", "policy_then_step_two_launches", "policy_then_step_pipelined", "fused_rollout", "facade_b1"):
     v = d.get(k)
     if isinstance(v, dict):
         print(f"  {k:32s}", {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()
@@ -31,8 +31,9 @@ for k, v in d.items():
             continue
         so = v.get("step_only") or {}
         tr = v.get("trajectory") or {}
+        pp = v.get("policy_then_step_pipelined") or {}
         print(f"{k:44s} {v['value']:.4g}  {v['ms_per_step'] * 1e3:6.2f} us/step  frac {v['roofline_frac']:.3f}   step_only {so.get('roofline_frac')}   "
-              f"trajectory {tr.get('roofline_frac')}")
+              f"trajectory {tr.get('roofline_frac')}   policy->step pipelined {pp.get('roofline_frac')} (n_sub {pp.get('n_sub')})")
         ext(v)
 for k in ("cpu_baseline", "cpu_baseline_port", "cpu_baseline_twin"):
     v = d.get(k) or {}
