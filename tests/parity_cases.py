@@ -1551,7 +1551,7 @@ def case_medium_limits(backend, seed=5, jobs=32):
     assert h["done"] and (h["job_state"][_abi.F_PERF] == 32 * 65535).all() and (h["job_state"][_abi.F_TODO] == 32).all()
 
 
-def case_policy_step_steps(backend, batch=300, steps=9, seed=13):
+def case_policy_step_steps(backend, batch=300, steps=9, seed=13, warm=230):
     """jss_policy_step_steps (the un-fused loop over sub-batches on several streams) == the Python loop
     `env.step(env.policy(kind), autoreset=True)` == the fused rollout: every tensor bit-identical."""
     for kw, kind in ((dict(instances="ta01"), "random"), (dict(instances=[I.builtin_instance(n) for n in ("ta01", "ta31")]), "SPT")):
@@ -1559,7 +1559,7 @@ def case_policy_step_steps(backend, batch=300, steps=9, seed=13):
         b = BatchedJssEnv(batch=batch, seed=seed, env_id_base=3, _backend=backend, **kw)
         for e in (a, b):
             e.reset()
-            e.rollout(kind, n_iter=230 if kind == "random" else 5)         # some envs are about to finish
+            e.rollout(kind, n_iter=warm if kind == "random" else 5)        # (warm = 230: some envs are about to finish)
         a.policy_step_steps(kind, steps=steps, n_sub=3)
         for _ in range(steps):
             b.step(b.policy(kind), autoreset=True)

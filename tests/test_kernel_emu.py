@@ -107,7 +107,7 @@ def test_instance_resampling(emu):
 
 
 def test_rollout_steps_equals_rollout(emu):
-    P.case_rollout_steps(emu, batch=150, steps=4, n_sub=3)
+    P.case_rollout_steps(emu, batch=130, steps=3, n_sub=3)
 
 
 def test_nope_fuzz_tiny_instances(emu):
@@ -174,4 +174,4 @@ def test_medium_records_at_the_limits(emu):
 
 
 def test_policy_step_steps_equals_the_loop(emu):
-    P.case_policy_step_steps(emu, batch=70, steps=3)
+    P.case_policy_step_steps(emu, batch=66, steps=3, warm=12)
