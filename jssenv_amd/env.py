@@ -188,7 +188,7 @@ class HipBackend:
 
     def stream_array(self, n):
         """(void* * n): the current stream + n - 1 of the process-wide side streams, for JSS_ROLLOUT_FORK_JOIN calls."""
-        main = self.torch.cuda.current_stream(self.device).cuda_stream
+        main = self.stream()
         key = (n, main)
         arr = self._stream_arrays.get(key)
         if arr is None:
