@@ -34,9 +34,13 @@
  *   jss_session_* <- the interactive loop `obs, r, done, _, _ = env.step(policy(obs))` (README.md:53-64) with the env
  *                   state RESIDENT on the chip between steps: a kernel that lives across steps takes each step's
  *                   actions from a device mailbox the caller's stream posts to, and writes that step's outputs
- *   jss_rollout_steps <- the same loop issued as n_sub independent sub-batches on
- *                   n_sub streams, so that consecutive steps of different sub-batches
+ *   jss_rollout_steps <- DispatchingRule.run_episode's loop (dispatching.py:55-75) issued as n_sub independent
+ *                   sub-batches on n_sub streams, so that consecutive steps of different sub-batches
  *                   overlap on the device (env instances are independent)
+ *   jss_step_autoreset <- JssEnv.step(action) / JssEnv.reset() (jss_env.py:403-481, :145-181) as a vector env calls them:
+ *                   an env that reported done on the previous call is reset instead of stepped, in the same launch
+ *   jss_policy_step_steps <- the un-fused loop `a = policy(obs); obs, r, done, _, _ = env.step(a)` (README.md:53-64), K
+ *                   times, policy and step as launches of their own, pipelined over sub-batches
  *
  * Conventions
  *   - plain pointers and sizes only; every pointer in JssDesc/JssState/JssOut is a
@@ -296,7 +300,8 @@ int jss_reset(const JssDesc *desc, const JssState *state, const JssOut *out, con
 /* one step() per env; actions[i] in [0, J], JSS_ACTION_SKIP or JSS_ACTION_RESET */
 int jss_step(const JssDesc *desc, const JssState *state, const int32_t *actions, const JssOut *out, void *stream);
 
-/* jss_step with gymnasium.vector "next-step" auto-reset folded in: an env whose out->done is set (it reported done on the
+/* JssEnv.step() (jss_env.py:403-481) with gymnasium.vector "next-step" auto-reset -- JssEnv.reset() (:145-181) of the envs
+ * that finished -- folded in: an env whose out->done is set (it reported done on the
  * previous call) is reset instead of stepped -- its action is ignored, reward 0, done 0, episode + 1 -- exactly as if the
  * caller had put JSS_ACTION_RESET into actions[i].  One launch for the whole `obs, r, done = envs.step(a)` of a vector env. */
 int jss_step_autoreset(const JssDesc *desc, const JssState *state, const int32_t *actions, const JssOut *out, void *stream);
