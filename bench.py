@@ -799,8 +799,9 @@ def main():
             out["facade_b1"] = {"us_per_step": dt_f / len(acts_f) * 1e6, "steps": len(acts_f), "instance": args.instance,
                                 "reference_us_per_step_build_container": 79.0,
                                 "fused_rule_episode_ms": dt_fused * 1e3, "fused_rule_makespan": mk_f,
-                                "note": "JssEnv.step(a) on the GPU: action in, one launch, ONE device->host copy of the env's "
-                                        "arena, sync; fused = DispatchingRule.run_episode(env, device_rng=True), whole episode on the device"}
+                                "note": "JssEnv.step(a) on the GPU: the env's arena lives in page-locked host memory the kernel works "
+                                        "on in place -- action written, one launch, one stream synchronise, no copy; fused = "
+                                        "DispatchingRule.run_episode(env, device_rng=True), whole episode on the device"}
         except Exception as exc:
             out["facade_b1"] = {"us_per_step": None, "error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.synchronize()
