@@ -63,7 +63,7 @@
  *                                                a lane moves its job with two dwordx4 accesses
  *                 or    [B][jmax][JSS_NFC]       16-byte compact records (JSS_FC_*) when the batch shares one instance
  *                                                and JssDesc.record_ints says so
- *                 or    [B][jmax][JSS_NFM]       24-byte medium records (JSS_FM_*): per-env instances with jobs, machines <= 32
+ *                 or    [B][jmax][JSS_NFM]       24-byte medium records (JSS_FM_*): per-env instances with machines <= 32
  *   env header    int32 [B][JSS_NH]              JSS_H_*: clock, episode, step, status
  *   env constants int32 [B][JSS_NC]              JSS_C_*: the env's instance constants (copied in by reset)
  *   machine state int32 [B][mmax]                time_until_available_machine (full records only)
@@ -125,10 +125,11 @@ extern "C" {
 #define JSS_FC_FLAG_F4_ONE 512
 #define JSS_FC_PERF_SHIFT 10
 /* The medium record (JssDesc.record_ints == JSS_NFM): 24 bytes, for batches whose envs differ in instance (so the op
- * table is not in LDS and the record has to carry the job's next three ops) but all fit a 32-lane group -- jmax, mmax <=
- * 32, the shapes the packed kernels serve (JSS_KERNEL_AUTO only; JSS_E_SHAPE otherwise).  With machines <= 32 an op is 21
+ * table is not in LDS and the record has to carry the job's next three ops) and whose instances have at most 32 machines
+ * (mmax <= 32, any number of jobs, either kernel flavour; JSS_E_SHAPE otherwise).  With machines <= 32 an op is 21
  * bits (machine << 16 | duration, 0 = none), todo <= 32 is 6 bits, total_perform_op_time_jobs <= 32 x 65535 < 2^21: 189
- * of the 192 bits.  No machine clocks in memory either (JssState.machine may be NULL), as with compact records.  Words: */
+ * of the 192 bits.  No machine clocks in memory either (JssState.machine may be NULL), as with compact records.  Measured
+ * faster than full records on the 16-lane packed shapes only (profiles/README.md): that is where the host uses it.  Words: */
 #define JSS_FM_W0 0        /* bits 0-5 todo_time_step_job, bit 6 legal_actions[j], bit 7 action_illegal_no_op[j], bit 8 observation
                               feature 4 is "1.0", bits 9-29 the current op (0 = job finished)                              */
 #define JSS_FM_LEFT_F4 1   /* bits 0-15 time_until_finish_current_op_jobs, bits 16-31 the feature-4 numerator          */
@@ -255,8 +256,8 @@ typedef struct JssDesc {
                                     jmin < jmax (a ragged, padded batch) the one-wavefront-per-env kernels read the
                                     instance record BEFORE the job records and never load the rows behind J(env)  */
     int32_t record_ints;         /* ints per job record: 0 or JSS_NF = full records; JSS_NFC = compact records
-                                    (n_tables == 1 only, else JSS_E_SHAPE); JSS_NFM = medium records (jmax, mmax <= 32,
-                                    JSS_KERNEL_AUTO, else JSS_E_SHAPE)                      */
+                                    (n_tables == 1 only, else JSS_E_SHAPE); JSS_NFM = medium records (n_tables > 1 and
+                                    mmax <= 32, else JSS_E_SHAPE)                           */
 } JssDesc;
 
 typedef struct JssState {

@@ -693,7 +693,7 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
     if (d->kernel != JSS_KERNEL_AUTO && d->kernel != JSS_KERNEL_WAVE) return JSS_E_KIND;
     if (d->record_ints != 0 && d->record_ints != JSS_NF && d->record_ints != JSS_NFC && d->record_ints != JSS_NFM) return JSS_E_SHAPE;
     if (d->record_ints == JSS_NFC && d->n_tables != 1) return JSS_E_SHAPE;
-    if (d->record_ints == JSS_NFM && (d->jmax > 32 || d->mmax > 32 || d->kernel != JSS_KERNEL_AUTO || d->n_tables == 1)) return JSS_E_SHAPE;
+    if (d->record_ints == JSS_NFM && (d->mmax > 32 || d->n_tables == 1)) return JSS_E_SHAPE;
     return 0;
 }
 

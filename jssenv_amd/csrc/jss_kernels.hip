@@ -32,8 +32,8 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
     if (d->kernel != JSS_KERNEL_AUTO && d->kernel != JSS_KERNEL_WAVE) return JSS_E_KIND;
     if (d->record_ints != 0 && d->record_ints != JSS_NF && d->record_ints != JSS_NFC && d->record_ints != JSS_NFM) return JSS_E_SHAPE;
     if (d->record_ints == JSS_NFC && d->n_tables != 1) return JSS_E_SHAPE;   // compact records need the ONE table in LDS
-    // medium records: 21-bit ops and a 32-lane group at most -- the packed kernels' shapes, per-env tables
-    if (d->record_ints == JSS_NFM && (d->jmax > 32 || d->mmax > 32 || d->kernel != JSS_KERNEL_AUTO || d->n_tables == 1)) return JSS_E_SHAPE;
+    // medium records: 21-bit ops (machines <= 32, whatever the number of jobs), per-env tables
+    if (d->record_ints == JSS_NFM && (d->mmax > 32 || d->n_tables == 1)) return JSS_E_SHAPE;
     return 0;
 }
 
@@ -116,13 +116,8 @@ KernelFn pick_tab(int G, int jpl) {
     return jss_kernel<2, MODE, TAB>;
 }
 template <int MODE>
-KernelFn pick_medium(int G) {                          // (check_args: medium records come with a packed shape only)
-    if (G == 16) return jss_packed_kernel<16, MODE, kTabGlobalM>;
-    return jss_packed_kernel<32, MODE, kTabGlobalM>;
-}
-template <int MODE>
 KernelFn pick(int G, int jpl, bool shared, int record_ints) {
-    if (!shared) return record_ints == JSS_NFM ? pick_medium<MODE>(G) : pick_tab<MODE, kTabGlobal>(G, jpl);
+    if (!shared) return record_ints == JSS_NFM ? pick_tab<MODE, kTabGlobalM>(G, jpl) : pick_tab<MODE, kTabGlobal>(G, jpl);
     return record_ints == JSS_NFC ? pick_tab<MODE, kTabLdsC>(G, jpl) : pick_tab<MODE, kTabLds>(G, jpl);
 }
 
@@ -173,8 +168,7 @@ KernelFn pick_session_tab(int G, int jpl) {
     return jss_session_kernel<2, TAB>;
 }
 KernelFn pick_session(int G, int jpl, bool shared, int record_ints) {
-    if (!shared && record_ints == JSS_NFM) return G == 16 ? jss_packed_session_kernel<16, kTabGlobalM> : jss_packed_session_kernel<32, kTabGlobalM>;
-    if (!shared) return pick_session_tab<kTabGlobal>(G, jpl);
+    if (!shared) return record_ints == JSS_NFM ? pick_session_tab<kTabGlobalM>(G, jpl) : pick_session_tab<kTabGlobal>(G, jpl);
     return record_ints == JSS_NFC ? pick_session_tab<kTabLdsC>(G, jpl) : pick_session_tab<kTabLds>(G, jpl);
 }
 
@@ -215,7 +209,7 @@ int plan_session(Params &p, LaunchPlan &lp, int slots, int *blocks_out, int *act
         if (p.obs_wave_floats < kWave) p.obs_wave_floats = kWave;
         p.mv_off_ints = p.norm_off_ints = p.norm_slot_ints = 0;
         p.park_off_ints = p.table_lds_ints + kWavesPerBlock * p.obs_wave_floats;
-        park4 = (compact ? jpl : 2 * jpl) * kWave + kWave / 4 + 1;
+        park4 = (compact ? jpl : 2 * jpl) * kWave + kWave / 4 + 1;   // (medium records: lo + hi rows like full ones)
     }
     lp.shmem = sizeof(int32_t) * ((size_t)p.park_off_ints + (slots > 1 ? (size_t)kWavesPerBlock * slots * park4 * 4 : 0));
     if (lp.shmem > kMaxSessionLds) return JSS_E_RESIDENT;

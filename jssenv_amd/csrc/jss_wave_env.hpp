@@ -570,9 +570,9 @@ struct RawEnv {  // what the state loads returned: unchanged halves of a record 
 template <int JPL, int TAB>
 __device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params &p, int jlimit) {
     RawEnv<JPL> r;
-    const int32_t *jb = p.s.job + (size_t)b * p.d.jmax * (tab_compact(TAB) ? JSS_NFC : JSS_NF);
-    // compact batches keep no machine clocks in memory: a machine is busy for as long as the job on it (unpack_env)
-    r.tm = tab_compact(TAB) ? 0 : ld_off<int>(p.s.machine + (size_t)b * p.d.mmax, (unsigned)(lane < p.d.mmax ? lane : 0) * 4u);
+    const int32_t *jb = p.s.job + (size_t)b * p.d.jmax * tab_record_ints(TAB);
+    // compact / medium batches keep no machine clocks in memory: a machine is busy for as long as the job on it (unpack_env)
+    r.tm = tab_no_clocks(TAB) ? 0 : ld_off<int>(p.s.machine + (size_t)b * p.d.mmax, (unsigned)(lane < p.d.mmax ? lane : 0) * 4u);
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + lane;
@@ -580,6 +580,15 @@ __device__ __forceinline__ RawEnv<JPL> issue_loads(int b, int lane, const Params
             r.lo[s] = make_int4(0, 0, 0, 0);
             r.hi[s] = make_int4(0, 0, 0, 0);
             if (j < jlimit) r.lo[s] = ld_off<int4>(jb, (unsigned)j * (JSS_NFC * 4u));
+        } else if (tab_medium(TAB)) {    // 24-byte records (JSS_FM_*): three 8-byte accesses; "no job" is all zeros
+            r.lo[s] = make_int4(0, 0, 0, 0);
+            r.hi[s] = make_int4(0, 0, 0, 0);
+            if (j < jlimit) {
+                const unsigned jo = (unsigned)j * (JSS_NFM * 4u);
+                const int2 a = ld_off<int2>(jb, jo), bb = ld_off<int2>(jb, jo + 8u), d = ld_off<int2>(jb, jo + 16u);
+                r.lo[s] = make_int4(a.x, a.y, bb.x, bb.y);
+                r.hi[s] = make_int4(d.x, d.y, 0, 0);
+            }
         } else {
             r.lo[s] = make_int4(0, -1, 0, 0);
             r.hi[s] = make_int4(0, 0, 0, -1);
@@ -598,8 +607,8 @@ __device__ __forceinline__ RawEnv<JPL> blank_raw() {                      // res
     r.tm = 0;
 #pragma unroll
     for (int s = 0; s < JPL; ++s) {
-        r.lo[s] = tab_compact(TAB) ? make_int4(0, 0, 0, 0) : make_int4(0, -1, 0, 0);
-        r.hi[s] = tab_compact(TAB) ? make_int4(0, 0, 0, 0) : make_int4(0, 0, 0, -1);
+        r.lo[s] = tab_no_clocks(TAB) ? make_int4(0, 0, 0, 0) : make_int4(0, -1, 0, 0);   // (compact / medium: "no job" is all zeros)
+        r.hi[s] = tab_no_clocks(TAB) ? make_int4(0, 0, 0, 0) : make_int4(0, 0, 0, -1);
     }
     return r;
 }
@@ -628,6 +637,21 @@ __device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawE
             e.cur[s] = (v && k < c.M) ? c.tab[j * c.stride + k] : -1;
             e.nxt[s] = (v && k + 1 < c.M) ? c.tab[j * c.stride + k + 1] : -1;
             e.nxt2[s] = (v && k + 2 < c.M) ? c.tab[j * c.stride + k + 2] : -1;
+        } else if (tab_medium(TAB)) {    // the three cached ops travel in the record, 21 bits each (0 = none)
+            const unsigned w0 = (unsigned)lo.x, w1 = (unsigned)lo.y, w2 = (unsigned)lo.z, w3 = (unsigned)lo.w;
+            const unsigned cur = (w0 >> JSS_FM_CUR_SHIFT) & JSS_FM_OP_MASK;
+            const unsigned nxt = (w2 >> 21) | ((w3 & 0x3FFu) << 11), nxt2 = (w3 >> 10) & JSS_FM_OP_MASK;
+            e.todo[s] = (int)(w0 & JSS_FM_TODO_MASK);
+            e.left[s] = (int)(w1 & 0xffffu);
+            e.perf[s] = (int)(w2 & JSS_FM_OP_MASK);
+            e.idle[s] = hi.x;
+            e.idle_last[s] = hi.y;
+            e.f4[s] = (w0 & JSS_FM_FLAG_F4_ONE) ? JSS_F4_ONE : (int)(w1 >> 16);
+            e.legal[s] = __ballot((w0 & JSS_FM_FLAG_LEGAL) != 0);
+            e.blocked[s] = (w0 & JSS_FM_FLAG_BLOCKED) != 0;
+            e.cur[s] = cur ? (int)cur : -1;
+            e.nxt[s] = nxt ? (int)nxt : -1;
+            e.nxt2[s] = nxt2 ? (int)nxt2 : -1;
         } else {
             e.todo[s] = lo.x & JSS_TODO_MASK;
             e.legal[s] = __ballot((lo.x & JSS_FLAG_LEGAL) != 0);
@@ -644,14 +668,14 @@ __device__ __forceinline__ void unpack_env(Env<JPL> &e, const Ctx &c, const RawE
         }
         e.fill[s] = -1;
     }
-    if (tab_compact(TAB)) {
+    if (tab_no_clocks(TAB)) {
         // time_until_available_machine[m] == time_until_finish_current_op_jobs[the job running on m] (both are set to
         // the op's duration at :446-449 and count down together at :521-530), 0 for an idle machine.  scr: kWave ints
         scr[c.lane] = 0;
         wave_lds_sync();
 #pragma unroll
         for (int s = 0; s < JPL; ++s)
-            if (e.left[s] > 0 && e.cur[s] >= 0) scr[e.cur[s] >> 16] = e.left[s];
+            if (e.left[s] > 0 && e.cur[s] >= 0) scr[(e.cur[s] >> 16) & (kWave - 1)] = e.left[s];
         wave_lds_sync();
         e.tm = c.lane < c.M ? scr[c.lane] : 0;
         wave_lds_sync();                                                 // scr is the observation image later on
@@ -684,6 +708,15 @@ __device__ __forceinline__ RawEnv<JPL> pack_env(const Env<JPL> &e, const Ctx &c)
                                       (one ? JSS_FC_FLAG_F4_ONE : 0u) | ((unsigned)e.perf[s] << JSS_FC_PERF_SHIFT)),
                                 (int)((unsigned)e.left[s] | ((unsigned)(one ? 0 : e.f4[s]) << 16)), e.idle[s], e.idle_last[s]);
             r.hi[s] = make_int4(0, 0, 0, 0);
+        } else if (tab_medium(TAB)) {
+            const bool one = e.f4[s] == JSS_F4_ONE;
+            const unsigned cur = e.cur[s] >= 0 ? (unsigned)e.cur[s] : 0u, nxt = e.nxt[s] >= 0 ? (unsigned)e.nxt[s] : 0u;
+            const unsigned nxt2 = e.nxt2[s] >= 0 ? (unsigned)e.nxt2[s] : 0u;
+            r.lo[s] = make_int4((int)((unsigned)e.todo[s] | (lg ? JSS_FM_FLAG_LEGAL : 0u) | (bl ? JSS_FM_FLAG_BLOCKED : 0u) |
+                                      (one ? JSS_FM_FLAG_F4_ONE : 0u) | (cur << JSS_FM_CUR_SHIFT)),
+                                (int)((unsigned)e.left[s] | ((unsigned)(one ? 0 : e.f4[s]) << 16)),
+                                (int)((unsigned)e.perf[s] | (nxt << 21)), (int)((nxt >> 11) | (nxt2 << 10)));
+            r.hi[s] = make_int4(e.idle[s], e.idle_last[s], 0, 0);
         } else {
             r.lo[s] = make_int4(e.todo[s] | (lg ? JSS_FLAG_LEGAL : 0) | (bl ? JSS_FLAG_BLOCKED : 0) |
                                     (e.nxt2[s] >= 0 ? (int)((unsigned)e.nxt2[s] << JSS_NEXT2_SHIFT) : 0), e.cur[s], e.left[s], e.perf[s]);
@@ -699,7 +732,7 @@ template <int JPL, int TAB>
 __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p, const Header &hd,
                                           const RawEnv<JPL> &raw, bool all_rows) {
     const int jm = p.d.jmax;
-    int32_t *jb = p.s.job + (size_t)c.b * jm * (tab_compact(TAB) ? JSS_NFC : JSS_NF);
+    int32_t *jb = p.s.job + (size_t)c.b * jm * tab_record_ints(TAB);
     if (c.lane == 0) {
         *reinterpret_cast<int4 *>(p.s.env + (size_t)c.b * JSS_NH) =
             make_int4(e.t, hd.episode, hd.step, (e.err & 0xFF) | (e.noop ? JSS_STATUS_NOOP : 0));
@@ -710,7 +743,7 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
             *reinterpret_cast<int4 *>(cp + 8) = make_int4(as_int(c.r_sum), as_int(c.r_m), 0, 0);
         }
     }
-    if (tab_compact(TAB)) {
+    if (tab_no_clocks(TAB)) {
         // no machine clocks in memory (unpack_env)
     } else if (all_rows) {
         if (c.lane < p.d.mmax) st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
@@ -722,6 +755,16 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         const int4 lo = now.lo[s], hi = now.hi[s];
+        if (tab_medium(TAB)) {           // the thirds of the record that changed
+            const unsigned jo = (unsigned)j * (JSS_NFM * 4u);
+            const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
+            if (all_rows ? j < jm : j < c.J) {
+                if (all_rows || lo.x != lo0.x || lo.y != lo0.y) st_off<int2>(jb, jo, make_int2(lo.x, lo.y));
+                if (all_rows || lo.z != lo0.z || lo.w != lo0.w) st_off<int2>(jb, jo + 8u, make_int2(lo.z, lo.w));
+                if (all_rows || hi.x != hi0.x || hi.y != hi0.y) st_off<int2>(jb, jo + 16u, make_int2(hi.x, hi.y));
+            }
+            continue;
+        }
         if (tab_compact(TAB)) {
             const unsigned jo = (unsigned)j * (JSS_NFC * 4u);
             const int4 lo0 = raw.lo[s];

@@ -373,14 +373,15 @@ class BatchedJssEnv:
         if self.kernel not in _abi.KERNEL:
             raise ValueError(f"kernel must be one of {list(_abi.KERNEL)}")
         # 24-byte medium records (the three cached ops in 21 bits each, no machine clocks) for batches of different instances.
-        # The library takes them for every shape the packed kernels serve (jobs, machines <= 32); by default they are used
+        # The library takes them for every shape with machines <= 32 (both kernel flavours); by default they are used
         # where they measure faster than full records: the 16-lane groups (jobs, machines <= 16: +8-10 % on 15 x 15; with 32-lane
         # groups the three 8-byte accesses and the unpacking cost more than the bytes save, -2 % on 20 x 20 --
         # profiles/README.md).  `compact=False` / records="full" asks for full records everywhere.
-        fits = n != 1 and self.kernel == "auto" and pk.jmax <= 32 and pk.mmax <= 32
+        fits = n != 1 and pk.mmax <= 32                 # 21-bit ops: machines <= 32, any number of jobs, either kernel flavour
         if records == "medium" and not fits:
-            raise ValueError("medium job records need per-env instances with jobs, machines <= 32 and the packed kernels")
-        self.medium = records == "medium" or (records is None and compact is None and fits and pk.jmax <= 16 and pk.mmax <= 16)
+            raise ValueError("medium job records need a batch of different instances with machines <= 32")
+        self.medium = records == "medium" or (records is None and compact is None and fits and self.kernel == "auto"
+                                              and pk.jmax <= 16 and pk.mmax <= 16)
         self.record_ints = _abi.NFC if self.compact else _abi.NFM if self.medium else _abi.NF
         self.no_clocks = self.compact or self.medium           # time_until_available_machine is derived, not stored
 

@@ -1493,7 +1493,9 @@ def case_medium_equals_full(backend, batch=40, n_iter=500, seed=29):
     rng = np.random.default_rng(seed)
     sets = [[I.builtin_instance(nm) for nm in ("ta01", "ta02", "ta03")],                      # 15 x 15, env -> instance map (G16)
             [I.builtin_instance("ta21"), I.builtin_instance("ta11"), random_instance(rng, 32, 32, max_dur=200)],   # ragged, G32
-            [random_instance(rng, 7, 5, max_dur=9) for _ in range(batch)]]                     # one table per env
+            [random_instance(rng, 7, 5, max_dur=9) for _ in range(batch)],                     # one table per env
+            [I.builtin_instance("ta51"), I.builtin_instance("ta31"), random_instance(rng, 64, 32, max_dur=50)],    # one wavefront per env, ragged
+            [I.builtin_instance("ta71"), I.builtin_instance("ta61")]]                          # two jobs per lane (100 x 20), ragged
     for insts in sets:
         a = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=7, records="medium", _backend=backend)
         b = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=7, records="full", _backend=backend)

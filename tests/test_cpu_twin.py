@@ -253,14 +253,10 @@ def test_steps_and_session_edges(cpu):
 
 
 def test_medium_records_equal_full_records(cpu):
-    if getattr(cpu, "default_kernel", "auto") != "auto":
-        pytest.skip("medium records are a packed-kernel layout")
     P.case_medium_equals_full(cpu)
 
 
 def test_medium_records_at_the_limits(cpu):
-    if getattr(cpu, "default_kernel", "auto") != "auto":
-        pytest.skip("medium records are a packed-kernel layout")
     P.case_medium_limits(cpu)
 
 

@@ -359,14 +359,10 @@ def test_steps_and_session_edges(hip):
 
 
 def test_medium_records_equal_full_records(hip):
-    if getattr(hip, "default_kernel", "auto") != "auto":
-        pytest.skip("medium records are a packed-kernel layout")
     P.case_medium_equals_full(hip, batch=700, n_iter=900)
 
 
 def test_medium_records_at_the_limits(hip):
-    if getattr(hip, "default_kernel", "auto") != "auto":
-        pytest.skip("medium records are a packed-kernel layout")
     P.case_medium_limits(hip)
 
 

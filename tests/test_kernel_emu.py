@@ -162,14 +162,10 @@ def test_steps_and_session_edges(emu):
 
 
 def test_medium_records_equal_full_records(emu):
-    if getattr(emu, "default_kernel", "auto") != "auto":
-        pytest.skip("medium records are a packed-kernel layout")
     P.case_medium_equals_full(emu, batch=6, n_iter=90)
 
 
 def test_medium_records_at_the_limits(emu):
-    if getattr(emu, "default_kernel", "auto") != "auto":
-        pytest.skip("medium records are a packed-kernel layout")
     P.case_medium_limits(emu, jobs=4)
 
 
