@@ -400,7 +400,9 @@ def main():
         probe = agree_max(probe)
         if rank == 0:
             print(f"launch-mode probe (s per {n_probe} steps): " + ", ".join(f"{m} {t:.6f}" for m, t in zip(candidates, probe)), file=sys.stderr)
-        return candidates[probe.index(min(probe))]
+        order = sorted(range(len(candidates)), key=lambda i: probe[i])
+        pick_mode.ranking = [(candidates[i], probe[i]) for i in order]      # (the headline re-measures a close runner-up)
+        return candidates[order[0]]
 
     def measure(env, policy, steps, mode, n_iter=1, windows=None, run=None, prep=None):
         """Windows of `steps` steps each -- as many as it takes for the timed total to reach MIN_TIMED_SECONDS (between
@@ -710,6 +712,14 @@ def main():
     torch.cuda.synchronize()
     mode = pick_mode(env, args.policy, ["eager", "graph", "sub2", "sub3"])
     med, rows = measure(env, args.policy, args.steps, mode)
+    # The probe is five short windows per form: when the runner-up is within 15 % of the winner the two are too close to
+    # call from that, so both get the full measurement and the better median is the headline (every rank takes the same
+    # decision: the probe times and the medians are reduced over ranks).
+    ranking = getattr(pick_mode, "ranking", [])
+    if args.launch == "auto" and len(ranking) > 1 and ranking[1][1] <= 1.15 * ranking[0][1] and not hasattr(env, "buckets"):
+        med_b, rows_b = measure(env, args.policy, args.steps, ranking[1][0])
+        if agree_max([med_b["rate"] - med["rate"]])[0] > 0:
+            mode, med, rows = ranking[1][0], med_b, rows_b
     bucket_note = ", shape-bucketed (no padding)" if (args.bucketed and args.workload == "mixed") else \
         (", padded 100x20" if args.workload == "mixed" else "")
     inst0 = builtin_instance(args.instance)
