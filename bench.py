@@ -678,6 +678,11 @@ def main():
             env.rollout(policy, n_iter=1, autoreset=True)
         mode = pick_mode(env, policy, list(modes))
         med, rows = measure(env, policy, args.steps, mode)
+        ranking = getattr(pick_mode, "ranking", [])              # a close runner-up of the probe gets the full measurement too
+        if args.launch == "auto" and not bucketed and len(ranking) > 1 and ranking[0][0] == mode and ranking[1][1] <= 1.15 * ranking[0][1]:
+            med_b, rows_b = measure(env, policy, args.steps, ranking[1][0])
+            if agree_max([med_b["rate"] - med["rate"]])[0] > 0:
+                mode, med, rows = ranking[1][0], med_b, rows_b
         rf = roofline(med, alg, args.steps, env, None if bucketed else key, batch)
         out = {"workload": label + label_extra, "batch": batch, "policy": policy, "value": med["rate"],
                "min": rows[0]["rate"], "max": rows[-1]["rate"], "windows": len(rows), "unit": "env steps/s",
