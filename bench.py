@@ -274,6 +274,13 @@ def main():
         assert dist.get_world_size() == world
     on_host = use_pg and backend != "nccl"
 
+    # The side streams of the pipelined forms (sub-batches, shape buckets) are process-wide and shared (HipBackend.side_pool):
+    # they are created here, back to back, before anything else makes streams -- HIP deals streams onto its hardware queues
+    # in creation order, and a bucket stream created late in the run (after graph captures and session streams) has landed
+    # on the queue of another bucket's stream: the bucketed extra then measured 0.38 instead of 0.55 inside the full bench.
+    from jssenv_amd.env import HipBackend
+    HipBackend(dev).side_pool(4)
+
     def barrier():
         if use_pg:
             dist.barrier()
