@@ -327,6 +327,14 @@ def test_step_session_fits_the_baseline_batches(hip_auto):
             s.step(env.backend.torch.zeros(env.batch, dtype=env.backend.torch.int32, device=env.backend.device))
         st = s.host_status()
         assert st["env_sets_per_wavefront"] == want and st["session_timeouts"] == 0 and st["wait_timeouts"] == 0, (kw.get("batch"), st)
+    # what does not fit is refused up front (JSS_E_RESIDENT), not started and left to time out: config 5's padded batch --
+    # 32 768 envs, one wavefront each, two jobs per lane -- would need more than eight envs per wavefront
+    big = BatchedJssEnv([I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=32768, _backend=hip_auto)
+    big.reset()
+    with pytest.raises(RuntimeError, match="does not fit"):
+        big.session(depth=2)
+    assert big._session is None
+    big.rollout("random", n_iter=3)                      # the batch is untouched and usable
 
 
 def test_step_session_gives_up_instead_of_hanging(hip_auto):
