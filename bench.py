@@ -22,17 +22,24 @@ wall-clock number anybody can recompute from the line; the HIP-event figure is k
 
 Workload: BASELINE.json configs[1] shape (ta01, 15x15, one shared instance, random masked policy) at the
 north_star's target batch of 65 536 envs per GPU (weak scaling: every rank owns its own 65 536 envs, no data-path
-collective).  Extras on the same line (N = 1): the plain one-launch-per-step figure, jss_step alone with resident
-actions (step_only), the K-steps-per-launch trajectory mode, the B = 1 facade's microseconds per step(), 4x the batch
-(beyond the 256 MB Infinity Cache), per-env synthetic 15x15 tables, BASELINE configs 2-5, the fused 64-step rollout.
+collective).
+
+Output: the LAST line of stdout is ONE compact JSON object (< 4 KB: metric / value / ms_per_step / config / roofline /
+cpu_baseline + one roofline fraction per BASELINE config, `compact_line`); everything that was measured goes, unabridged,
+to bench_detail.json next to this file (and to gpurun_out/ when that directory exists).  A default run measures the
+headline, the plain one-launch-per-step form of it (the kernel duration rocprofv3 reports) and BASELINE configs 2-5 in
+their fused one-launch-per-step form.  `--extras` adds the side measurements of earlier rounds -- jss_step alone with
+resident actions (step_only), trajectory mode, jss_steps / step sessions with external actions, the B = 1 facade, 4x the
+batch, per-env synthetic 15x15 tables, the C-oracle and twin CPU baselines; `--no-extras` keeps the headline only.
 
 With N > 1 the same line also carries config4_sharded: BASELINE config 4 as it is defined -- synthetic 50x20, 65 536
 envs split over the N ranks by shard_bounds (strong scaling) -- measured after the weak-scaling headline.
 
-Extra objects: roofline (HBM), cpu_baseline = the Python / NumPy restatement of the reference's step() on one host
-core (kind "restatement": the stand-in for the reference's own speed, which cannot travel to this box),
-cpu_baseline_port (the C oracle, one env per thread) and cpu_baseline_twin (libjss_cpu.so, 1 core and all cores),
-all timed on this box's host cores in this run, rank 0, N = 1.
+Extra objects: roofline (HBM; frac = algorithmic bytes over the wall clock, frac_gpu_time over HIP events on the launch
+stream, single_launch = the one-launch-per-step form whose kernel duration rocprofv3 reports) and cpu_baseline = the
+Python / NumPy restatement of the reference's step() on ONE host core (kind "port": oracle/np_restatement.py, the stand-in
+for the reference's own speed, which cannot travel to this box), timed on this box in this run (rank 0, N = 1, ~10 s).
+--extras adds cpu_baseline_c_oracle (the C oracle, one env per thread) and cpu_baseline_twin (libjss_cpu.so).
 """
 import argparse
 import hashlib
@@ -122,7 +129,7 @@ def cpu_baseline_restatement(inst_name, seed, target_seconds=10.0, instance=None
     while time.perf_counter() - t0 < target_seconds:
         steps += random_masked_episode(env, rng)
     dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "env steps/s", "cores": 1, "kind": "restatement",
+    return {"value": steps / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
             "sample": f"{inst_name}, random masked policy (README.md:53-64) + step() to completion, whole episodes for "
                       f"{dt:.1f} s ({steps} env steps), single env, one core, Python {sys.version_info[0]}.{sys.version_info[1]} + NumPy",
             "implementation": "oracle/np_restatement.py (Python loops over NumPy arrays, like JSSEnv/envs/jss_env.py)"}
@@ -155,7 +162,7 @@ def cpu_baseline_port(inst_name, seed, target_seconds=8.0):
     _, cal_dt = run(cal_iters)
     iters = int(max(cal_iters, cal_iters * target_seconds / max(cal_dt, 1e-6)))
     steps, dt = run(iters)
-    return {"value": steps / dt, "unit": "env steps/s", "cores": threads, "kind": "port",
+    return {"value": steps / dt, "unit": "env steps/s", "cores": threads, "kind": "port (C oracle)",
             "sample": f"{inst_name} random-masked policy+step, {threads} envs x {iters} iterations "
                       f"({steps} env steps, {dt:.1f} s, one env per thread; 1 thread alone = {1.0 / per_step:.0f} steps/s)"}
 
@@ -188,6 +195,81 @@ def cpu_baseline_twin(inst_name, seed, target_seconds=4.0):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# The driver's line.  Round 4 printed everything on one 28 KB line and the driver's parser gave up on it: the line a
+# run ENDS with is now a fixed, small set of keys (tests/test_bench_line.py holds it under 4 KB); the rest is the detail file.
+# ------------------------------------------------------------------------------------------------------------
+COMPACT_MAX_BYTES = 4096
+CONFIG_KEYS = {    # detail-file key of a BASELINE config's side run -> its short name in the compact `configs` map
+    "config2_ta01_batch4096_random": "c2_ta01_b4096_random",
+    "config3_ta41_spt_batch16384": "c3_ta41_b16384_spt",
+    "config4_synthetic50x20_batch8192": "c4_syn50x20_b8192_one_gpu_share",
+    "config4_synthetic50x20_batch65536_one_gpu": "c4_syn50x20_b65536_one_gpu",
+    "config4_sharded": "c4_syn50x20_b65536_sharded",
+    "config5_mixed_padded_batch32768": "c5_mixed_b32768_padded",
+    "config5_mixed_bucketed_batch32768": "c5_mixed_b32768_bucketed",
+}
+
+
+def _sig(x, n=5):
+    """n significant digits (floats only): keeps the line short without changing what it says"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x == 0.0 or math.isnan(x) or math.isinf(x):
+        return x
+    return float(f"{x:.{n}g}")
+
+
+def _pick(d, keys, n=5):
+    return {k: _sig(d[k], n) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out, detail_files=()):
+    """The one JSON line the driver parses, from the full result dict `out` (pure function: tests/test_bench_line.py
+    feeds it a canned dict).  Required keys are always present; optional ones are dropped, last first, until the line
+    fits COMPACT_MAX_BYTES."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"), n=7)
+    cfg = out.get("config") or {}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:300], **_pick(cfg, ("batch_per_gpu", "global_batch", "policy", "parallelism"))}
+    line["config"]["launch"] = str(out.get("launch", ""))[:120]
+    rf = out.get("roofline") or {}
+    line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "frac_own_bytes", "frac_gpu_time", "traffic", "kernel",
+                                  "kernel_ms", "alg_bytes_per_env_step", "env_steps_per_launch", "wait_fraction",
+                                  "wave_cycles_per_env_step"))
+    single = out.get("single_launch_per_step")
+    if isinstance(single, dict) and single.get("value"):
+        # the plain form (ONE launch over the whole batch per step): the kernel duration rocprofv3 --kernel-trace reports
+        line["roofline"]["single_launch"] = _pick(single, ("value", "kernel_ms", "roofline_frac", "roofline_frac_gpu_time"))
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = None if not isinstance(cb, dict) else {**_pick(cb, ("value", "unit", "cores", "kind")),
+                                                                  "sample": str(cb.get("sample", ""))[:160]}
+    line["configs"], line["configs_env_steps_per_s"] = {}, {}
+    for key, shortname in CONFIG_KEYS.items():
+        ent = out.get(key)
+        if isinstance(ent, dict):
+            line["configs"][shortname] = _sig(ent.get("roofline_frac"), 4) if ent.get("value") else None
+            line["configs_env_steps_per_s"][shortname] = _sig(ent.get("value"), 4)
+    line["configs_note"] = "roofline.frac (wall clock, K steps per window) of each BASELINE config's fused one-launch-per-step form on one GPU"
+    line["windows"] = _pick(out.get("windows") or {}, ("n", "min", "max", "below_90pct_of_median"))
+    if out.get("mean_makespan") is not None:
+        line["mean_makespan"] = _sig(out["mean_makespan"])
+    if out.get("process_group"):
+        line["process_group"] = out["process_group"]
+    line["csrc_sha16"] = out.get("csrc_sha16")
+    line["detail"] = list(detail_files)
+    text = json.dumps(line, separators=(",", ":"))
+    for optional in ("configs_note", "windows", "configs_env_steps_per_s", "mean_makespan", "detail"):
+        if len(text) <= COMPACT_MAX_BYTES:
+            break
+        line.pop(optional, None)
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) > COMPACT_MAX_BYTES:                    # cannot happen with the bounded strings above; never print a long line
+        line["config"]["workload"] = line["config"]["workload"][:80]
+        line["cpu_baseline"] = _pick(cb or {}, ("value", "unit", "cores", "kind")) or None
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -216,6 +298,9 @@ def parse_args():
     ap.add_argument("--bucketed", action="store_true",
                     help="mixed workload only: one compact sub-batch per shape class (BucketedJssEnv) instead of "
                          "padding every env to 100x20")
+    ap.add_argument("--bucketed-launch", default="grid", choices=["grid", "streams"],
+                    help="--bucketed: ONE grid over all shape classes per step (jss_multi_rollout) or round 3's form, one launch "
+                         "per class and step on a stream per class (A/B)")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="debug: every rank uses cuda:0 (exercises the multi-process path on a 1-GPU box; use with "
@@ -224,7 +309,11 @@ def parse_args():
                     help="create the process group and run every barrier / all-reduce through it even with one rank "
                          "(executes the RCCL lines of the multi-GPU path on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="the headline only: no BASELINE configs 2-5, no side measurements")
+    ap.add_argument("--extras", action="store_true",
+                    help="also the side measurements (step_only, trajectory, external-action forms, facade, 4x batch, synthetic "
+                         "15x15, the C-oracle / twin CPU baselines): minutes of extra run time, detail file only")
+    ap.add_argument("--detail", default=None, help="where the unabridged JSON goes (default: bench_detail.json next to bench.py)")
     return ap.parse_args()
 
 
@@ -310,7 +399,7 @@ def main():
         if workload == "mixed" and bucketed:
             from jssenv_amd import BucketedJssEnv
             insts = [builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
-            e = BucketedJssEnv(insts, batch=batch, device=dev, seed=args.seed, env_id_base=first_env)
+            e = BucketedJssEnv(insts, batch=batch, device=dev, seed=args.seed, env_id_base=first_env, launch=args.bucketed_launch)
             e.reset()
             e.rollout(policy, n_iter=333, autoreset=True)
             e.zero_counters()
@@ -451,6 +540,8 @@ def main():
 
     def kernel_name(env):
         if hasattr(env, "buckets"):
+            if env.launch == "grid":
+                return "jss_multi_kernel<kRollout1>: one grid over the shape classes (16-lane groups, 32-lane groups, wave, wave x2)"
             return "four launches per step: jss_packed_kernel<16|32,kRollout1,*>, jss_kernel<1|2,kRollout1,*>"
         tab = ("kTabLdsC" if env.compact else "kTabLds") if env.n_tables == 1 else ("kTabGlobalM" if getattr(env, "medium", False) else "kTabGlobal")
         jm, mm = env.jmax, env.mmax
@@ -694,7 +785,8 @@ def main():
         out = {"workload": label + label_extra, "batch": batch, "policy": policy, "value": med["rate"],
                "min": rows[0]["rate"], "max": rows[-1]["rate"], "windows": len(rows), "unit": "env steps/s",
                "ms_per_step": med["seconds"] / args.steps * 1e3, "roofline_frac_gpu_time": rf["frac_gpu_time"],
-               "launch": ("one launch per shape bucket per step, every bucket on its own HIP stream" if bucketed else launch_label(mode)),
+               "launch": (("ONE launch per step over all shape classes (jss_multi_rollout)" if args.bucketed_launch == "grid" else
+                           "one launch per shape bucket per step, every bucket on its own HIP stream") if bucketed else launch_label(mode)),
                "kernel": rf["kernel"], "roofline_frac": rf["frac"],
                "roofline_frac_of_measured_peak": rf["frac_of_measured_peak"], "alg_bytes_per_env_step": alg,
                "traffic": rf["traffic"], "mean_makespan": med["makespan_sum"] / med["episodes"] if med["episodes"] else None}
@@ -742,7 +834,8 @@ def main():
         "data": ("ta01 (the reference's Taillard instance; no dataset involved)" if args.workload == "shared" and args.instance == "ta01"
                  else "synthetic" if args.workload.startswith("synthetic") else "reference instances (ta01-ta80)"),
         "windows": window_stats(rows, args.steps),
-        "launch": ("one launch per shape bucket per step, every bucket on its own HIP stream (C launch loop per bucket)"
+        "launch": (("ONE launch per step over all shape classes (jss_multi_rollout, C launch loop)" if args.bucketed_launch == "grid" else
+                    "one launch per shape bucket per step, every bucket on its own HIP stream (C launch loop)")
                    if hasattr(env, "buckets") else launch_label(mode)),
         "config": {"workload": f"{wl_label}{bucket_note}, {args.policy} masked policy fused with step(), "
                                f"{'batch %d envs per GPU' % B if args.scaling == 'weak' else 'batch %d envs in total (%d on this rank)' % (args.batch, B)}, "
@@ -764,12 +857,13 @@ def main():
                                              "kernel_ms": med1["kernel_ms"], "launch": launch_label(m1),
                                              "roofline_frac": roofline(med1, alg_per_step, args.steps, env, key, B)["frac"],
                                              "roofline_frac_gpu_time": roofline(med1, alg_per_step, args.steps, env, key, B)["frac_gpu_time"]}
+    if args.extras and not hasattr(env, "buckets"):
         # fused multi-step rollout: 64 iterations per launch, state in registers, outputs once per launch
         n_l = max(4, args.steps // 16)
         medf, _ = measure(env, args.policy, n_l, "eager", n_iter=64, windows=3)
         out["fused_rollout"] = {"value": medf["rate"], "unit": "env steps/s", "iterations_per_launch": 64, "launches": n_l,
                                 "note": "policy+step x64 per launch, observation written once per launch"}
-    if not args.no_extras and world == 1 and not hasattr(env, "buckets"):
+    if args.extras and world == 1 and not hasattr(env, "buckets"):
         out["step_only"] = step_only_measure(env, args.policy, alg_per_step, B)
         out["trajectory"] = traj_measure(env, args.policy, alg_per_step)
         out["external_actions"] = external_action_forms(env, args.policy, alg_per_step, args.steps)
@@ -832,23 +926,27 @@ def main():
             env.close()
         del env
         env = None
+        x = bool(args.extras)                 # trajectory mode and the external-action forms of a config: --extras only
         extras = [
-            ("batch_x4", dict(workload="shared", batch=4 * B, policy=args.policy, instance=args.instance, modes=("eager", "sub2", "sub3"),
-                              label_extra=" -- 4x the batch (about 200 MB of state and outputs with compact records, plus the 236 MB solution tensor written one word per env step)")),
-            ("synthetic15x15_per_env_tables", dict(workload="synthetic15x15", batch=B, policy=args.policy)),
             ("config2_ta01_batch4096_random", dict(workload="shared", batch=4096, policy="random", modes=("eager", "graph"),
-                                                   with_trajectory=True, with_external=True)),
-            ("config3_ta41_spt_batch16384", dict(workload="shared", batch=16384, policy="SPT", instance="ta41", with_trajectory=True,
-                                                 with_external=True)),
-            ("config4_synthetic50x20_batch8192", dict(workload="synthetic50x20", batch=8192, policy="random", with_trajectory=True,
-                                                      with_external=True)),
+                                                   with_trajectory=x, with_external=x)),
+            ("config3_ta41_spt_batch16384", dict(workload="shared", batch=16384, policy="SPT", instance="ta41", with_trajectory=x,
+                                                 with_external=x)),
+            ("config4_synthetic50x20_batch8192", dict(workload="synthetic50x20", batch=8192, policy="random", with_trajectory=x,
+                                                      with_external=x)),
             ("config4_synthetic50x20_batch65536_one_gpu", dict(workload="synthetic50x20", batch=65536, policy="random",
                                                                label_extra=" -- all of config 4 on one GPU")),
             ("config5_mixed_padded_batch32768", dict(workload="mixed", batch=32768, policy="random", label_extra=", padded 100x20",
-                                                     with_trajectory=True, with_external=True)),
+                                                     with_trajectory=x, with_external=x)),
             ("config5_mixed_bucketed_batch32768", dict(workload="mixed", batch=32768, policy="random", bucketed=True,
                                                        label_extra=", shape-bucketed (no padding)")),
         ]
+        if x:
+            extras += [
+                ("batch_x4", dict(workload="shared", batch=4 * B, policy=args.policy, instance=args.instance, modes=("eager", "sub2", "sub3"),
+                                  label_extra=" -- 4x the batch (about 200 MB of state and outputs with compact records, plus the 236 MB solution tensor written one word per env step)")),
+                ("synthetic15x15_per_env_tables", dict(workload="synthetic15x15", batch=B, policy=args.policy)),
+            ]
         for name, kw in extras:
             try:     # an extra that fails (memory on a busy box, ...) is reported, it does not cost the headline
                 out[name] = side_run(kw.pop("workload"), kw.pop("batch"), kw.pop("policy"), **kw)
@@ -879,28 +977,44 @@ def main():
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), **host_cores()}
     out["csrc_sha16"] = csrc_hash()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "shared":
-        for name, fn in (("cpu_baseline", cpu_baseline_restatement), ("cpu_baseline_port", cpu_baseline_port),
-                         ("cpu_baseline_twin", cpu_baseline_twin)):
+        legs = [("cpu_baseline", cpu_baseline_restatement)]
+        if args.extras:
+            legs += [("cpu_baseline_c_oracle", cpu_baseline_port), ("cpu_baseline_twin", cpu_baseline_twin)]
+        for name, fn in legs:
             try:     # a host-side hiccup (no compiler for a stale checker build, ...) must not cost the GPU measurement
                 out[name] = fn(args.instance, args.seed)
                 out[name]["host"] = host_cores()
             except Exception as exc:
                 out[name] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
-        try:     # the other BASELINE shapes at the reference's speed: ta41 (config 3), synthetic 50x20 (config 4), ta80 (config 5's largest)
-            from jssenv_amd.instances import taillard_instance
-            per = {}
-            for label, name, inst in (("config3_ta41", "ta41", None), ("config4_synthetic50x20", "synthetic 50x20 (time seed 1, machine seed 2)",
-                                                                        taillard_instance(50, 20, 1, 2)), ("config5_ta80", "ta80", None)):
-                r = cpu_baseline_restatement(name, args.seed, target_seconds=4.0, instance=inst)
-                per[label] = {"value": r["value"], "unit": r["unit"], "cores": 1, "kind": "restatement", "sample": r["sample"]}
-            out["cpu_baseline_per_config"] = per
-        except Exception as exc:
-            out["cpu_baseline_per_config"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if args.extras:
+            try:     # the other BASELINE shapes at the reference's speed: ta41 (config 3), synthetic 50x20 (config 4), ta80 (config 5's largest)
+                from jssenv_amd.instances import taillard_instance
+                per = {}
+                for label, name, inst in (("config3_ta41", "ta41", None), ("config4_synthetic50x20", "synthetic 50x20 (time seed 1, machine seed 2)",
+                                                                            taillard_instance(50, 20, 1, 2)), ("config5_ta80", "ta80", None)):
+                    r = cpu_baseline_restatement(name, args.seed, target_seconds=4.0, instance=inst)
+                    per[label] = {"value": r["value"], "unit": r["unit"], "cores": 1, "kind": r["kind"], "sample": r["sample"]}
+                out["cpu_baseline_per_config"] = per
+            except Exception as exc:
+                out["cpu_baseline_per_config"] = {"error": f"{type(exc).__name__}: {exc}"}
     elif rank == 0:
         out["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # everything, unabridged, to the detail file(s); ONE compact line -- the last line of stdout -- for the driver
+        detail = json.dumps(out)
+        targets = [args.detail or os.path.join(ROOT, "bench_detail.json")]
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and not args.detail:
+            targets.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+        written = []
+        for t in targets:
+            try:
+                with open(t, "w") as fh:
+                    fh.write(detail + "\n")
+                written.append(os.path.relpath(t, ROOT))
+            except OSError as exc:
+                print(f"bench.py: could not write {t}: {exc}", file=sys.stderr)
+        print(compact_line(out, detail_files=written), flush=True)
     # orderly teardown: graphs were local to measure(); drop the envs (and their side streams) while the
     # runtime is still fully alive
     torch.cuda.synchronize()

@@ -81,7 +81,7 @@
 extern "C" {
 #endif
 
-#define JSS_ABI_VERSION 8
+#define JSS_ABI_VERSION 9
 
 #define JSS_MAX_JOBS 128
 #define JSS_MAX_MACHINES 64
@@ -330,8 +330,10 @@ int jss_trajectory(const JssDesc *desc, const JssState *state, const JssOut *out
 /* n_steps x jss_step per launch: actions[k * B + i] = the action of env i in step k (the codes of jss_step: job, J = NOPE,
  * JSS_ACTION_SKIP, JSS_ACTION_RESET).  State, `out` and the counters end exactly as after n_steps jss_step calls with
  * actions + k * B; the state is read and written ONCE.  With `traj` (may be NULL; any of its streams may be NULL) slot k
- * holds what the k-th jss_step call would have left in `out`: real_obs / action_mask AFTER step k, reward and done of step
- * k (envs skipped in step k: their unchanged values); traj->action is not written. */
+ * holds real_obs / action_mask AFTER step k and the reward / done of step k; for an env that step k did not step
+ * (JSS_ACTION_SKIP, JSS_ACTION_RESET) the slot records reward 0 and done = "no legal action in the state it is in" -- not
+ * the carried-over values jss_step would leave in `out` (an env skipped because it is done records done 1, a restarted one
+ * done 0).  traj->action is not written. */
 int jss_steps(const JssDesc *desc, const JssState *state, const JssOut *out, const JssTraj *traj, const int32_t *actions,
               int32_t n_steps, void *stream);
 
@@ -349,7 +351,10 @@ int jss_steps(const JssDesc *desc, const JssState *state, const JssOut *out, con
  *   post       jss_session_post (a small kernel on the CALLER's stream, e.g. behind its policy network) writes the granules
  *              of steps [first_step, first_step + n_steps) from an int32 [n_steps][B] action buffer
  *   wait       jss_session_wait (a one-workgroup kernel on the caller's stream) returns once every wavefront has
- *              published `steps_done` steps: kernels enqueued behind it see those steps' outputs
+ *              published `steps_done` steps.  `out` is ONE set of buffers that every step overwrites: kernels enqueued
+ *              behind the wait see step `steps_done`'s outputs, whole, only if nothing beyond it has been posted (the
+ *              resident kernel does not hold step s + 1's stores back for a reader of step s); with steps posted ahead
+ *              the outputs are defined again once the caller has waited for everything it posted
  *   close      jss_session_close posts JSS_ACTION_CLOSE for step `next_step`: the resident kernel writes the state back
  *              (job records, header, machine clocks) and adds its counters; after the session's stream has drained the
  *              batch is an ordinary batch again.  State tensors and counters are NOT current while a session is open.
@@ -418,6 +423,26 @@ int jss_policy_step_steps(const JssDesc *desc, const JssState *state, const JssO
 int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states,
                             const JssOut *const *outs, int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps,
                             int32_t flags, void *const *streams);
+
+/* ---- several independent env sets in ONE launch ----------------------------------------------------------------
+ * The shape classes of a ragged population (jssenv_amd.BucketedJssEnv: one compact batch per class -- 16-lane groups,
+ * 32-lane groups, one wavefront per env, two jobs per lane) stepped without padding and without one launch (and one
+ * stream) per class: ONE grid per call covers every set, a workgroup finding its set by its index.  Each call does to
+ * every set i exactly what the single-set call does with descs[i] / states[i] / outs[i] -- jss_multi_reset = jss_reset
+ * (JssEnv.reset, jss_env.py:145-181), jss_multi_step = jss_step / jss_step_autoreset (JssEnv.step, :403-481;
+ * flags = JSS_ROLLOUT_AUTORESET or 0), jss_multi_policy = jss_policy, jss_multi_rollout = n_steps x jss_rollout(n_iter = 1)
+ * (n_steps launches) -- all on `stream`, results identical.  The fused grid covers sets with per-env instance tables
+ * (n_tables > 1; full records, or medium records on the 16- / 32-lane shapes), 2 to 6 of them; any other combination is
+ * issued as one plain launch per set on the same stream (same results).  `which` (jss_multi_reset) may be NULL, and so may
+ * its entries: every env of that set.  1 <= n_sets <= 16. */
+int jss_multi_reset(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
+                    const uint8_t *const *which, void *stream);
+int jss_multi_step(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const int32_t *const *actions,
+                   const JssOut *const *outs, int32_t flags, void *stream);
+int jss_multi_policy(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, int kind, uint64_t seed,
+                     uint32_t explore_q16, int32_t *const *actions, void *stream);
+int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
+                      int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, void *stream);
 
 #ifdef JSS_PROFILING
 /* Instrumented builds only (tools/build_instrumented.py compiles with -DJSS_PROFILING; the shipped library does

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 STATE_LAYOUT = 7     # version of the state tensors' layout (checkpoints): unchanged since ABI v7
 MAX_JOBS, MAX_MACHINES = 128, 64
 F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_NEXT, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -55,7 +55,8 @@ MAX_SUB_BATCHES = 16
 
 SYMBOLS = ("jss_abi_version", "jss_error_string", "jss_backend", "jss_reset", "jss_step", "jss_advance", "jss_policy",
            "jss_rollout", "jss_rollout_steps", "jss_rollout_steps_multi", "jss_trajectory", "jss_sync_check",
-           "jss_step_autoreset", "jss_policy_step_steps", "jss_steps", "jss_session_open", "jss_session_post", "jss_session_wait", "jss_session_step", "jss_session_close")
+           "jss_step_autoreset", "jss_policy_step_steps", "jss_steps", "jss_session_open", "jss_session_post", "jss_session_wait", "jss_session_step", "jss_session_close",
+           "jss_multi_reset", "jss_multi_step", "jss_multi_policy", "jss_multi_rollout")
 
 _p = C.c_void_p
 
@@ -116,6 +117,13 @@ def bind(lib):
     lib.jss_rollout_steps_multi.restype = C.c_int
     lib.jss_rollout_steps_multi.argtypes = [C.c_int32, C.POINTER(D), C.POINTER(S), C.POINTER(O), C.c_int, C.c_uint64, C.c_uint32,
                                             C.c_int32, C.c_int32, C.POINTER(_p)]
+    PD, PS, PO, PP = C.POINTER(D), C.POINTER(S), C.POINTER(O), C.POINTER(_p)
+    lib.jss_multi_reset.restype, lib.jss_multi_reset.argtypes = C.c_int, [C.c_int32, PD, PS, PO, PP, _p]
+    lib.jss_multi_step.restype, lib.jss_multi_step.argtypes = C.c_int, [C.c_int32, PD, PS, PP, PO, C.c_int32, _p]
+    lib.jss_multi_policy.restype = C.c_int
+    lib.jss_multi_policy.argtypes = [C.c_int32, PD, PS, C.c_int, C.c_uint64, C.c_uint32, PP, _p]
+    lib.jss_multi_rollout.restype = C.c_int
+    lib.jss_multi_rollout.argtypes = [C.c_int32, PD, PS, PO, C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, _p]
     lib.jss_trajectory.restype = C.c_int
     lib.jss_trajectory.argtypes = [D, S, O, C.POINTER(JssTraj), C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, _p]
     lib.jss_sync_check.restype, lib.jss_sync_check.argtypes = C.c_int, [_p]

@@ -98,6 +98,23 @@ struct Params {
     int32_t norm_slot_ints;           // packed kernel, kTabGlobal: ints between two slots' normaliser tables
 };
 
+// The kernels take their Params by value (the kernel-argument segment), but read them through a POINTER to that segment:
+// a by-value struct argument handed on by reference is first copied into a private object, which the optimiser then turns
+// into "every field loaded in the entry block" -- some 60 scalar registers live from the first instruction to each field's
+// last use.  That, not the algorithm, was what the one-wavefront-per-env kernels ran out of SGPRs on (rounds 2-4: 16-58
+// SGPR values parked in VGPR lanes in the step / rollout kernels, scratch in the trajectory ones).  Read in place, a field is
+// a scalar load next to its use: jss_kernel<2, kRollout1, kTabGlobal> 54 -> 0 spilled SGPRs, <1, kStep, kTabGlobal> 16 -> 0
+// at unchanged occupancy (tools/kernel_resources.py).  The explicit arguments start at offset 0 of the segment.
+// (Host pass and the test emulator: the argument itself.)
+// (-DJSS_PARAMS_BY_VALUE: A/B builds of the old form)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JSS_PARAMS_BY_VALUE)
+#define JSS_PARAMS_IN_PLACE(p, arg) \
+    (void)(arg);                    \
+    const Params &p = *reinterpret_cast<const Params *>(__builtin_amdgcn_kernarg_segment_ptr())
+#else
+#define JSS_PARAMS_IN_PLACE(p, arg) const Params &p = (arg)
+#endif
+
 #ifdef JSS_PROFILING
 #define JSS_ABLATED(p, bit) (((p).ablate & (bit)) != 0)
 #else

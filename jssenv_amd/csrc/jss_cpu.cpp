@@ -932,4 +932,50 @@ int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const J
     return 0;
 }
 
+// several env sets per call (include/jss_hip.h jss_multi_*): the host twin has no launches to fuse -- set after set
+int jss_multi_reset(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
+                    const uint8_t *const *which, void *stream) {
+    if (!descs || !states || !outs) return JSS_E_NULL;
+    if (n_sets < 1 || n_sets > 16) return JSS_E_SHAPE;
+    for (int i = 0; i < n_sets; ++i) {
+        const int rc = jss_reset(descs[i], states[i], outs[i], which ? which[i] : nullptr, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int jss_multi_step(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const int32_t *const *actions,
+                   const JssOut *const *outs, int32_t flags, void *stream) {
+    if (!descs || !states || !outs || !actions) return JSS_E_NULL;
+    if (n_sets < 1 || n_sets > 16) return JSS_E_SHAPE;
+    for (int i = 0; i < n_sets; ++i) {
+        const int rc = (flags & JSS_ROLLOUT_AUTORESET) ? jss_step_autoreset(descs[i], states[i], actions[i], outs[i], stream)
+                                                       : jss_step(descs[i], states[i], actions[i], outs[i], stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int jss_multi_policy(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, int kind, uint64_t seed,
+                     uint32_t explore_q16, int32_t *const *actions, void *stream) {
+    if (!descs || !states || !actions) return JSS_E_NULL;
+    if (n_sets < 1 || n_sets > 16) return JSS_E_SHAPE;
+    for (int i = 0; i < n_sets; ++i) {
+        const int rc = jss_policy(descs[i], states[i], kind, seed, explore_q16, actions[i], stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
+                      int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, void *stream) {
+    if (!descs || !states || !outs) return JSS_E_NULL;
+    if (n_sets < 1 || n_sets > 16 || n_steps < 0) return JSS_E_SHAPE;
+    for (int i = 0; i < n_sets; ++i) {       // n_steps x rollout(n_iter = 1) == rollout(n_iter = n_steps) on the state; `out` holds the last step either way
+        const int rc = jss_rollout(descs[i], states[i], outs[i], kind, seed, explore_q16, n_steps, flags & JSS_ROLLOUT_AUTORESET, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 }  // extern "C"

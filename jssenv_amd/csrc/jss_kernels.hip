@@ -255,7 +255,7 @@ __global__ void jss_session_post_kernel(unsigned long long *mail, const int32_t 
 // returns once every active wavefront has published `steps_done` steps (one workgroup sweeps the progress words);
 // bounded: gives up -- status[1] += 1 -- after the session's timeout or as soon as a wavefront of the session has
 __device__ __forceinline__ void session_wait(const int32_t *progress, int32_t *status, int active, int steps_done, long long timeout_ticks) {
-    __shared__ int behind;
+    __shared__ int behind;     // 1: somebody has not published `steps_done` yet; 2: give up (decided by thread 0 for the workgroup)
     long long t0 = 0;
     for (unsigned spins = 0;; ++spins) {
         if (threadIdx.x == 0) behind = 0;
@@ -264,20 +264,25 @@ __device__ __forceinline__ void session_wait(const int32_t *progress, int32_t *s
         for (int i = (int)threadIdx.x; i < active; i += (int)blockDim.x) mine |= fresh_load(progress + i) < steps_done ? 1 : 0;
         if (mine) behind = 1;
         __syncthreads();
-        const int b = behind;
+        if (threadIdx.x == 0 && behind) {
+            // ONE thread reads the status word and the clock and decides for everybody: wavefronts that looked for themselves
+            // (each at its own instant, with its own t0) could disagree, and one of them would leave the others at the barrier
+            bool give_up = fresh_load(status + 0) != 0;                      // a wavefront of the session timed out: it is dead
+            if ((spins & 63u) == 63u) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > timeout_ticks) give_up = true;
+            }
+            if (give_up) {
+                atomicAdd(status + 1, 1);
+                behind = 2;
+            }
+        }
         __syncthreads();
-        if (!b) return;
+        const int b = behind;
+        __syncthreads();                                                     // (everybody has read it before thread 0 clears it)
+        if (b != 1) return;
         __builtin_amdgcn_s_sleep(1);
-        bool give_up = fresh_load(status + 0) != 0;                          // a wavefront of the session timed out: it is dead
-        if ((spins & 63u) == 63u) {
-            const long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            else if (now - t0 > timeout_ticks) give_up = true;
-        }
-        if (give_up) {                                                       // (uniform: every thread reads the same words)
-            if (threadIdx.x == 0) atomicAdd(status + 1, 1);
-            return;
-        }
     }
 }
 __global__ void jss_session_wait_kernel(const int32_t *progress, int32_t *status, int active, int steps_done, long long timeout_ticks) {
@@ -328,6 +333,119 @@ Params sub_batch(const Params &p, int start, int count) {
     q.o.done = p.o.done + s0;
     q.o.makespan = p.o.makespan + s0;
     return q;
+}
+
+// ---- several independent env sets in ONE grid (jss_multi_*) ------------------------------------------------------
+// The shape classes of a ragged population (jssenv_amd.BucketedJssEnv: 16-lane groups, 32-lane groups, one wavefront per
+// env, two jobs per lane) are compact batches of their own.  Launched one by one they need one launch per class and step
+// and -- to overlap -- one stream each, at the mercy of how HIP deals streams onto hardware queues (round 4: 0.37-0.55 of
+// the roofline for the same work, depending on the box).  Here ONE grid covers them all: a workgroup finds its env set by
+// its index (block ranges, scalar compares on kernel arguments) and runs that set's body -- the same device functions
+// the plain kernels are made of -- on its own Params.  The sets with the longest-lived wavefronts come first in the
+// grid, so that the short ones fill the tail.  Per-env-table layouts only (an LDS-staged shared table would add four
+// more bodies); other sets make the entry points fall back to one launch per set on the same stream.
+constexpr int kMultiMaxSets = 6;
+enum MultiFlavour { kMfW2G = 0, kMfW1G = 1, kMfP32G = 2, kMfP32M = 3, kMfP16G = 4, kMfP16M = 5, kMfNone = 6 };   // grid order
+struct MultiParams {
+    Params p[kMultiMaxSets];
+    int32_t block_end[kMultiMaxSets];   // first workgroup index behind set i
+    int32_t flavour[kMultiMaxSets];
+    int32_t n_sets;
+};
+
+constexpr int multi_min_blocks(int mode) { return mode == kStep ? 6 : mode == kRollout1 ? 7 : 8; }
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock, multi_min_blocks(MODE)) void jss_multi_kernel(MultiParams mp) {
+    HIP_DYNAMIC_SHARED(int32_t, lds)
+    const int blk = (int)blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < kMultiMaxSets; ++i)
+        if (i + 1 < mp.n_sets && blk >= mp.block_end[i]) k = i + 1;
+    const int block = blk - (k ? mp.block_end[k - 1] : 0);
+    const Params &p = mp.p[k];
+    switch (mp.flavour[k]) {
+    case kMfW2G: wave_block<2, MODE, kTabGlobal, false>(p, block, lds); break;   // (one body: 66 VGPRs, no spills at 7 waves / SIMD)
+    case kMfW1G: wave_block<1, MODE, kTabGlobal>(p, block, lds); break;
+    case kMfP32G: packed_block<32, MODE, kTabGlobal>(p, block, lds); break;
+    case kMfP32M: packed_block<32, MODE, kTabGlobalM>(p, block, lds); break;
+    case kMfP16G: packed_block<16, MODE, kTabGlobal>(p, block, lds); break;
+    default: packed_block<16, MODE, kTabGlobalM>(p, block, lds); break;
+    }
+}
+
+int multi_flavour(const JssDesc &d) {
+    if (d.n_tables == 1) return kMfNone;                                  // shared table: LDS-staged bodies are not in the grid
+    const int G = packed_group(d);
+    const bool medium = d.record_ints == JSS_NFM;
+    if (G == 16) return medium ? kMfP16M : kMfP16G;
+    if (G == 32) return medium ? kMfP32M : kMfP32G;
+    if (medium) return kMfNone;
+    return d.jmax <= kWave ? kMfW1G : kMfW2G;
+}
+
+// `ps[0..n)`: fully filled Params of the sets (everything but the launch-derived LDS fields).  One fused launch per step when
+// every set has a body in the grid, otherwise one plain launch per set and step, all on `stream`.
+template <int MODE>
+int launch_multi(Params *ps, int n, int n_steps, void *stream) {
+    bool fused = n >= 2 && n <= kMultiMaxSets;
+    for (int i = 0; i < n && fused; ++i) fused = multi_flavour(ps[i].d) != kMfNone;
+    if (!fused) {
+        LaunchPlan lps[16];
+        for (int i = 0; i < n; ++i) {
+            const int rc = plan<MODE>(ps[i], lps[i]);
+            if (rc) return rc;
+        }
+        for (int s = 0; s < n_steps; ++s)
+            for (int i = 0; i < n; ++i) {
+                const int rc = fire(ps[i], lps[i], stream);
+                if (rc) return rc;
+            }
+        return 0;
+    }
+    int order[kMultiMaxSets];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i)                                          // insertion sort by flavour (= grid order), stable
+        for (int j = i; j > 0 && multi_flavour(ps[order[j]].d) < multi_flavour(ps[order[j - 1]].d); --j) {
+            const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+        }
+    static MultiParams mp;                                               // (2.3 KB: not on the stack of every caller)
+    static std::mutex mp_mutex;
+    std::lock_guard<std::mutex> lock(mp_mutex);
+    size_t shmem = 0;
+    int blocks = 0, m = 0;
+    for (int q = 0; q < n; ++q) {
+        Params &p = ps[order[q]];
+        if (p.d.batch == 0) continue;
+        LaunchPlan lp;
+        const int rc = plan<MODE>(p, lp);
+        if (rc) return rc;
+        blocks += (p.d.batch + lp.envs_per_block - 1) / lp.envs_per_block;
+        mp.p[m] = p;
+        mp.block_end[m] = blocks;
+        mp.flavour[m] = multi_flavour(p.d);
+        if (lp.shmem > shmem) shmem = lp.shmem;
+        ++m;
+    }
+    if (m == 0) return 0;
+    mp.n_sets = m;
+    for (int s = 0; s < n_steps; ++s) {                                  // (the arguments are copied at every launch)
+        hipLaunchKernelGGL(jss_multi_kernel<MODE>, dim3(blocks), dim3(kBlock), shmem, reinterpret_cast<hipStream_t>(stream), mp);
+        const int rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int check_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs, bool need_out) {
+    if (!descs || !states || (need_out && !outs)) return JSS_E_NULL;
+    if (n_sets < 1 || n_sets > 16) return JSS_E_SHAPE;
+    for (int i = 0; i < n_sets; ++i) {
+        const int rc = check_args(descs[i], states[i], need_out ? outs[i] : nullptr, need_out);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 }  // namespace
@@ -472,12 +590,14 @@ int jss_session_open(const JssDesc *desc, const JssState *state, const JssOut *o
         if (rc != JSS_E_RESIDENT) break;
     }
     if (rc) return rc;
-    {
+    hipLaunchKernelGGL(lp.fn, dim3(blocks), dim3(kBlock), lp.shmem, reinterpret_cast<hipStream_t>(stream), p);
+    const int lrc = (int)hipGetLastError();
+    if (lrc) return lrc;
+    {   // registered only once the resident kernel is really on its way: wait / step of a session that never opened -> JSS_E_SESSION
         std::lock_guard<std::mutex> lock(g_sessions_mutex);
         g_sessions[session->progress] = SessionInfo{active, p.slots, p.timeout_ticks};
     }
-    hipLaunchKernelGGL(lp.fn, dim3(blocks), dim3(kBlock), lp.shmem, reinterpret_cast<hipStream_t>(stream), p);
-    return (int)hipGetLastError();
+    return 0;
 }
 
 int jss_session_post(const JssDesc *desc, const JssSession *session, const int32_t *actions, int32_t first_step,
@@ -526,6 +646,11 @@ int jss_session_close(const JssDesc *desc, const JssSession *session, int32_t ne
     if (!desc || !session || !session->mail) return JSS_E_NULL;
     if (next_step < 0) return JSS_E_SESSION;
     // (the caller has waited for every step it posted: the slot of next_step is free)
+    {   // the session is over for the host: wait / step on it answer JSS_E_SESSION from here on (the progress / status buffers
+        // may be freed by the caller once its stream has drained)
+        std::lock_guard<std::mutex> lock(g_sessions_mutex);
+        g_sessions.erase(session->progress);
+    }
     hipLaunchKernelGGL(jss_session_post_kernel, dim3((desc->batch + kBlock - 1) / kBlock), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), reinterpret_cast<unsigned long long *>(session->mail),
                        static_cast<const int32_t *>(nullptr), desc->batch, session->depth, next_step, 1);
@@ -604,6 +729,64 @@ int jss_policy_step_steps(const JssDesc *desc, const JssState *state, const JssO
         }
     const int jrc = fork_join ? join_streams(*ev, streams, n) : 0;
     return rc ? rc : jrc;
+}
+
+int jss_multi_reset(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
+                    const uint8_t *const *which, void *stream) {
+    int rc = check_multi(n_sets, descs, states, outs, true);
+    if (rc) return rc;
+    Params ps[16];
+    for (int i = 0; i < n_sets; ++i) {
+        ps[i] = {};
+        ps[i].d = *descs[i]; ps[i].s = *states[i]; ps[i].o = *outs[i]; ps[i].which = which ? which[i] : nullptr;
+    }
+    return launch_multi<kReset>(ps, n_sets, 1, stream);
+}
+
+int jss_multi_step(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const int32_t *const *actions,
+                   const JssOut *const *outs, int32_t flags, void *stream) {
+    int rc = check_multi(n_sets, descs, states, outs, true);
+    if (rc) return rc;
+    if (!actions) return JSS_E_NULL;
+    Params ps[16];
+    for (int i = 0; i < n_sets; ++i) {
+        if (!actions[i]) return JSS_E_NULL;
+        ps[i] = {};
+        ps[i].d = *descs[i]; ps[i].s = *states[i]; ps[i].o = *outs[i]; ps[i].actions = actions[i];
+        ps[i].flags = flags & JSS_ROLLOUT_AUTORESET;
+    }
+    return launch_multi<kStep>(ps, n_sets, 1, stream);
+}
+
+int jss_multi_policy(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, int kind, uint64_t seed,
+                     uint32_t explore_q16, int32_t *const *actions, void *stream) {
+    int rc = check_multi(n_sets, descs, states, nullptr, false);
+    if (rc) return rc;
+    if (!actions) return JSS_E_NULL;
+    Params ps[16];
+    for (int i = 0; i < n_sets; ++i) {
+        if (!actions[i]) return JSS_E_NULL;
+        if ((rc = check_kind(descs[i], kind))) return rc;
+        ps[i] = {};
+        ps[i].d = *descs[i]; ps[i].s = *states[i]; ps[i].actions_out = actions[i]; ps[i].kind = kind; ps[i].seed = seed;
+        ps[i].explore_q16 = explore_q16;
+    }
+    return launch_multi<kPolicy>(ps, n_sets, 1, stream);
+}
+
+int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
+                      int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, void *stream) {
+    int rc = check_multi(n_sets, descs, states, outs, true);
+    if (rc) return rc;
+    if (n_steps < 0) return JSS_E_SHAPE;
+    Params ps[16];
+    for (int i = 0; i < n_sets; ++i) {
+        if ((rc = check_kind(descs[i], kind))) return rc;
+        ps[i] = {};
+        ps[i].d = *descs[i]; ps[i].s = *states[i]; ps[i].o = *outs[i]; ps[i].kind = kind; ps[i].seed = seed;
+        ps[i].explore_q16 = explore_q16; ps[i].n_iter = 1; ps[i].flags = flags & JSS_ROLLOUT_AUTORESET;
+    }
+    return launch_multi<kRollout1>(ps, n_sets, n_steps, stream);
 }
 
 int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states,

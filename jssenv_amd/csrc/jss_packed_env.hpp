@@ -957,13 +957,10 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
 #ifndef JSS_PACKED_MEDIUM_MIN_BLOCKS
 #define JSS_PACKED_MEDIUM_MIN_BLOCKS 8
 #endif
+// One workgroup's share of a packed launch: `block` = its index among the workgroups of THIS env set (blockIdx.x of a
+// plain launch; a workgroup of the fused multi-set grid -- jss_multi_kernel -- passes its index within its own set).
 template <int G, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, (MODE == kTraj || MODE == kSteps) ? (tab_global(TAB) ? JSS_PTRAJ_GLOBAL_MIN_BLOCKS : JSS_PTRAJ_LDS_MIN_BLOCKS)
-                                     : MODE == kRollout ? (tab_global(TAB) ? 4 : 5)
-                                     : (tab_medium(TAB) && MODE == kRollout1) ? JSS_PACKED_MEDIUM_MIN_BLOCKS
-                                     : ((tab_global(TAB) && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
-void jss_packed_kernel(Params p) {
-    HIP_DYNAMIC_SHARED(int32_t, lds)
+__device__ __forceinline__ void packed_block(const Params &p, int block, int32_t *lds) {
     constexpr int E = kWave / G;                      // envs per wave
     constexpr int EB = E * kWavesPerBlock;            // envs per workgroup
     const int lane = threadIdx.x & (kWave - 1);
@@ -977,7 +974,7 @@ void jss_packed_kernel(Params p) {
     c.gl = lane & (G - 1);
     c.gbase = lane & ~(G - 1);
     c.norm = lds + p.norm_off_ints + wave * kWave + c.gbase;             // kTabGlobal: my group's six normalisers
-    c.first_env = blockIdx.x * EB + wave * E;                            // wave-uniform
+    c.first_env = block * EB + wave * E;                                 // wave-uniform
     const bool wave_dead = c.first_env >= p.d.batch;                     // only in the last workgroup
     const int e_in_wave = lane / G;
     c.alive = c.first_env + e_in_wave < p.d.batch;
@@ -1058,6 +1055,17 @@ void jss_packed_kernel(Params p) {
         p_store_obs<G, TAB>(e, c, p, p.o.real_obs + fe * p.d.jmax * 7, scratch, wave_whole);
 }
 
+template <int G, int MODE, int TAB>
+__global__ __launch_bounds__(kBlock, (MODE == kTraj || MODE == kSteps) ? (tab_global(TAB) ? JSS_PTRAJ_GLOBAL_MIN_BLOCKS : JSS_PTRAJ_LDS_MIN_BLOCKS)
+                                     : MODE == kRollout ? (tab_global(TAB) ? 4 : 5)
+                                     : (tab_medium(TAB) && MODE == kRollout1) ? JSS_PACKED_MEDIUM_MIN_BLOCKS
+                                     : ((tab_global(TAB) && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
+void jss_packed_kernel(Params p_arg) {
+    HIP_DYNAMIC_SHARED(int32_t, lds)
+    JSS_PARAMS_IN_PLACE(p, p_arg);
+    packed_block<G, MODE, TAB>(p, (int)blockIdx.x, lds);
+}
+
 
 // ---------------------------------------------------------------------------------------
 // The resident step-session kernel (include/jss_hip.h, jss_session_*), packed flavour.
@@ -1136,8 +1144,9 @@ __device__ __forceinline__ PRaw<G> p_unpark(const int4 *park, int slot, int lane
 }
 
 template <int G, int TAB>
-__global__ __launch_bounds__(kBlock, 6) void jss_packed_session_kernel(Params p) {
+__global__ __launch_bounds__(kBlock, 6) void jss_packed_session_kernel(Params p_arg) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
+    JSS_PARAMS_IN_PLACE(p, p_arg);
     constexpr int E = kWave / G;
     constexpr int MODE = kSession;
     const int lane = threadIdx.x & (kWave - 1);

@@ -1098,20 +1098,22 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
 constexpr int wave_min_blocks(int jpl, int mode) {
     return mode == kTraj ? (jpl == 2 ? JSS_TRAJ2_MIN_BLOCKS : JSS_TRAJ1_MIN_BLOCKS)
          : mode == kRollout ? (jpl == 2 ? 5 : 7)
-         : mode == kStep ? (jpl == 2 ? 5 : 8)
+         : mode == kStep ? (jpl == 2 ? 6 : 8)
          : mode == kSteps ? (jpl == 2 ? 4 : 6)
          : mode == kRollout1 ? (jpl == 2 ? JSS_WAVE2_MIN_BLOCKS : JSS_WAVE_MIN_BLOCKS)
          : (jpl == 2 ? 7 : 8);
 }
-template <int JPL, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel(Params p) {
-    HIP_DYNAMIC_SHARED(int32_t, lds)
+// One workgroup's share of a launch (`block`: see packed_block).  NARROW: a two-jobs-per-lane instantiation also holds the
+// one-job-per-lane body for the envs of a ragged batch that fit it (below); the fused multi-set grid, whose two-jobs-per-lane
+// class holds nothing but J > 64 instances, leaves it out.
+template <int JPL, int MODE, int TAB, bool NARROW = true>
+__device__ __forceinline__ void wave_block(const Params &p, int block, int32_t *lds) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // obs image of this wave, 16-byte aligned (table_lds_ints and obs_wave_floats are multiples of 4)
     float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;
 
-    const int b_raw = blockIdx.x * kWavesPerBlock + wave;                 // one env per wave
+    const int b_raw = block * kWavesPerBlock + wave;                      // one env per wave
     const bool alive = b_raw < p.d.batch;
     const int b = alive ? b_raw : p.d.batch - 1;
     Ctx c;
@@ -1145,11 +1147,18 @@ __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel
         wave_main<JPL, kReset, TAB>(p, c, h, ragged, a_in, lds, scratch);
     } else {
         // (J == 64 stays on the full-width body: the NOPE flag of its mask row lives at index 64, slot 1's first lane)
-        if (JPL == 2 && ragged && MODE != kSteps && __builtin_amdgcn_readfirstlane(h.J) < kWave)
+        if (NARROW && JPL == 2 && ragged && MODE != kSteps && __builtin_amdgcn_readfirstlane(h.J) < kWave)
             wave_main<1, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
         else
             wave_main<JPL, MODE, TAB>(p, c, h, ragged, a_in, lds, scratch);
     }
+}
+
+template <int JPL, int MODE, int TAB>
+__global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel(Params p_arg) {
+    HIP_DYNAMIC_SHARED(int32_t, lds)
+    JSS_PARAMS_IN_PLACE(p, p_arg);
+    wave_block<JPL, MODE, TAB>(p, (int)blockIdx.x, lds);
 }
 
 
@@ -1200,8 +1209,9 @@ __device__ __forceinline__ RawEnv<JPL> unpark_env(const int4 *park, int slot, in
 }
 
 template <int JPL, int TAB>
-__global__ __launch_bounds__(kBlock, JPL == 1 ? 6 : 4) void jss_session_kernel(Params p) {
+__global__ __launch_bounds__(kBlock, JPL == 1 ? 6 : 4) void jss_session_kernel(Params p_arg) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
+    JSS_PARAMS_IN_PLACE(p, p_arg);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;

@@ -697,8 +697,10 @@ class BatchedJssEnv:
         action codes as ``step`` takes them (job, J = NOPE, -1 = skip, -2 = reset) -- a recorded trace, a planned
         open-loop sequence.  The state is read and written once.  ``record`` names the per-step streams to keep,
         step-major: ``real_obs`` (K, B, J, 7) and ``action_mask`` (K, B, J + 1) AFTER each step, ``reward`` / ``done``
-        (K, B).  Returns the dict of recorded buffers (reusable through ``buffers``); the env's own outputs hold the
-        last step."""
+        (K, B) -- for an env that a step skips (-1) or restarts (-2) the recorded reward is 0 and the recorded done says
+        whether the state it is in has a legal action (``step``'s own ``reward`` / ``done`` tensors keep the carried-over
+        values instead).  Returns the dict of recorded buffers (reusable through ``buffers``); the env's own outputs hold
+        the last step."""
         if not self._is_reset:
             raise RuntimeError("call reset() before steps()")
         be = self.backend
@@ -898,8 +900,14 @@ class BatchedJssEnv:
     def _saved_tensors(self):                      # a compact / medium batch has no machine clocks to save: they are derived
         return tuple(k for k in self._STATE_TENSORS if k != "machine_state" or not self.no_clocks)
 
+    def _no_open_session(self, what):
+        if self._session is not None and not self._session.closed:
+            raise RuntimeError(f"{what}: a step session is open on this env -- the state lives in its resident kernel and the "
+                               "tensors in memory are stale; close() the session first")
+
     def state_dict(self):
         """Host copy of everything needed to resume: state + last outputs + the batch description."""
+        self._no_open_session("state_dict")
         n = self.backend.numpy
         d = {k: n(getattr(self, k)) for k in self._saved_tensors()}
         d["meta"] = {"abi": _abi.STATE_LAYOUT, "record_ints": self.record_ints, "batch": self.batch, "jmax": self.jmax, "mmax": self.mmax, "seed": self.seed,
@@ -910,6 +918,7 @@ class BatchedJssEnv:
         return d
 
     def load_state_dict(self, d):
+        self._no_open_session("load_state_dict")
         m = d["meta"]
         if int(m.get("abi", 0)) != _abi.STATE_LAYOUT:
             raise ValueError(f"checkpoint was written with state layout v{m.get('abi')}, this build is v{_abi.STATE_LAYOUT}")
@@ -983,6 +992,7 @@ class BatchedJssEnv:
     def host_tensors(self):
         """NumPy copies of the state and output tensors (not ``solution``).  A small batch comes over in ONE
         device -> host copy of the arena they were carved from."""
+        self._no_open_session("host_tensors")
         be = self.backend
         if getattr(self, "host_arena", False):        # the arena IS host memory: wait for the kernels, look at it
             be.sync()

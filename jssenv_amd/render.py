@@ -112,18 +112,22 @@ def gantt_frame(env, size=(960, 540), horizon=None, prefer_plotly=True):
 
 
 def save_gif(frames, path, fps: float = 10.0):
-    """Write ``frames`` ((H, W, 3) uint8 arrays) as an animated GIF: imageio when importable (the reference's writer),
-    Pillow otherwise.  Returns the number of frames written."""
+    """Write ``frames`` ((H, W, 3) uint8 arrays) as an animated GIF at ``fps`` frames per second: through Pillow (which is
+    also what imageio's GIF plug-in writes with), imageio itself only where Pillow is missing.  Returns the number of frames."""
     frames = [f for f in frames if f is not None]
     if not frames:
         raise ValueError("no frames to write (nothing was scheduled)")
     try:
-        import imageio
-        imageio.mimsave(str(path), frames, duration=1.0 / fps)
+        from PIL import Image          # one writer, one unit: Pillow's duration is milliseconds per frame
     except ImportError:
-        from PIL import Image
-        imgs = [Image.fromarray(f) for f in frames]
-        imgs[0].save(str(path), save_all=True, append_images=imgs[1:], duration=int(1000.0 / fps), loop=0)
+        # imageio's own GIF writer: `duration` is seconds per frame up to 2.27 and MILLISECONDS from 2.28 on (the v3 pillow
+        # plug-in) -- the same literal would play a thousand times too fast on one side of that line
+        import imageio
+        new_units = tuple(int(x) for x in imageio.__version__.split(".")[:2] if x.isdigit()) >= (2, 28)
+        imageio.mimsave(str(path), frames, duration=(1000.0 if new_units else 1.0) / fps)
+        return len(frames)
+    imgs = [Image.fromarray(f) for f in frames]
+    imgs[0].save(str(path), save_all=True, append_images=imgs[1:], duration=int(round(1000.0 / fps)), loop=0)
     return len(frames)
 
 

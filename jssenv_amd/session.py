@@ -18,9 +18,19 @@ While a session is open, synchronize YOUR stream (``torch.cuda.current_stream().
 ``torch.cuda.synchronize()`` waits for every stream, the resident kernel's included, and that kernel only ends when the
 session is closed (it would return when the kernel's own timeout fires, with the session dead).
 
-Between open and close the state tensors (job records, header, machine clocks) and the counters in memory are stale;
-the outputs (``real_obs``, ``action_mask``, ``reward``, ``done``, ``makespan``, ``solution``) are current after every
-``wait``.  Other calls on the env raise while a session is open.
+Between open and close the state tensors (job records, header, machine clocks) and the counters in memory are stale, and
+every other call on the env (``step``, ``rollout``, ``state_dict``, ``host_tensors`` ...) raises.
+
+The outputs (``real_obs``, ``action_mask``, ``reward``, ``done``, ``makespan``, ``solution``) are single buffers that the
+resident kernel overwrites step after step: they hold step n's values -- whole, untorn -- for the kernels enqueued behind a
+``wait`` that leaves NOTHING in flight (``wait()`` of everything posted, or ``step()``).  After ``wait(n)`` with more than n
+steps posted the kernel is already writing step n + 1 over them: their content is undefined until the caller has waited
+for everything it posted (``outputs_current`` says which).  A caller that posts ahead and wants every step's outputs uses
+``BatchedJssEnv.steps(actions, record=...)`` instead, which keeps them per step.
+
+A session whose resident kernel saw no mail for ``timeout_ms`` (a long learner update, a debugger, a device-wide
+synchronisation) has written its state back and left: ``step`` / ``wait`` notice within ``check_every`` calls (an
+asynchronous copy of the status words, no host synchronisation) and raise instead of handing out stale observations.
 """
 from __future__ import annotations
 
@@ -32,7 +42,7 @@ from . import _abi
 
 
 class StepSession:
-    def __init__(self, env, depth: int = 16, timeout_ms: int = 10000, slots: int = 0):
+    def __init__(self, env, depth: int = 16, timeout_ms: int = 10000, slots: int = 0, check_every: int = 64):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         if not env._is_reset:
@@ -52,6 +62,12 @@ class StepSession:
         self.closed = False
         self._stream = None
         torch = getattr(be, "torch", None)
+        # liveness probe: every `check_every` exchanges the status words are copied to pinned host memory behind the caller's
+        # work (asynchronous); the copy of the previous probe is looked at when its event has fired
+        self.check_every, self._calls, self._probe = max(1, int(check_every)), 0, None
+        if torch is not None:
+            self._status_host = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+            self._probe_event = torch.cuda.Event()
         d, s, o = env._refs()
         with be.on_device():
             if torch is not None:
@@ -91,6 +107,35 @@ class StepSession:
         self.posted += n
         return self.posted
 
+    @property
+    def outputs_current(self) -> bool:
+        """True when the env's output tensors hold exactly the last waited-for step (nothing posted beyond it)."""
+        return self.posted == self.waited
+
+    def _alive(self):
+        """Raise if the resident kernel has given the session up (see the module docstring); costs a host-side event query,
+        and one 16-byte asynchronous copy every `check_every` calls."""
+        be = self.be
+        torch = getattr(be, "torch", None)
+        if torch is None:                        # host twin / emulator: synchronous, the status words are host memory
+            st = be.numpy(self.status)
+            dead, waits = int(st[0]), int(st[1])
+        else:
+            dead = waits = 0
+            if self._probe is not None and self._probe_event.query():
+                dead, waits = int(self._status_host[0]), int(self._status_host[1])
+                self._probe = None
+            self._calls += 1
+            if self._probe is None and self._calls % self.check_every == 0:
+                with be.on_device():
+                    self._status_host.copy_(self.status, non_blocking=True)
+                    self._probe_event.record(torch.cuda.current_stream(be.device))
+                self._probe = True
+        if dead or waits:
+            raise RuntimeError(f"the step session is dead: {dead} wavefront(s) of its resident kernel saw no actions for timeout_ms "
+                               f"and left, {waits} wait(s) gave up -- the outputs are stale from there on; close(check=False) it "
+                               "and open a new one")
+
     def _as_actions(self, actions):
         be = self.be
         if isinstance(actions, np.ndarray) or not hasattr(be, "torch"):
@@ -107,12 +152,14 @@ class StepSession:
         return a
 
     def wait(self, steps=None):
-        """Stream-ordered wait on the current stream until ``steps`` steps (default: everything posted) are finished and
-        their outputs visible to the kernels enqueued behind it.  Does not block the host."""
+        """Stream-ordered wait on the current stream until ``steps`` steps (default: everything posted) are finished.  Does
+        not block the host.  The env's output tensors are defined for the kernels enqueued behind it only when this leaves
+        nothing in flight (``steps`` == everything posted): see the module docstring."""
         be, env = self.be, self.env
         n = self.posted if steps is None else int(steps)
         if n > self.posted or n < self.waited:
             raise ValueError(f"cannot wait for {n} steps: {self.waited} already waited for, {self.posted} posted")
+        self._alive()
         with be.on_device():
             rc = be.lib.jss_session_wait(C.byref(env._desc), C.byref(self._sess), n, be.stream())
         _abi.check(be.lib, rc, "jss_session_wait")
@@ -128,6 +175,8 @@ class StepSession:
             raise ValueError(f"expected actions of shape ({env.batch},), got {tuple(actions.shape)}")
         if self.posted != self.waited:
             self.wait()
+        else:
+            self._alive()
         a = self._as_actions(actions)
         with be.on_device():
             rc = be.lib.jss_session_step(C.byref(env._desc), C.byref(self._sess), be.ptr(a), self.posted, be.stream())
@@ -143,7 +192,10 @@ class StepSession:
         if self.closed:
             return
         be, env = self.be, self.env
-        self.wait()
+        if self.posted != self.waited:          # (not through wait(): a dead session must still be closable)
+            with be.on_device():
+                be.lib.jss_session_wait(C.byref(env._desc), C.byref(self._sess), self.posted, be.stream())
+            self.waited = self.posted
         with be.on_device():
             rc = be.lib.jss_session_close(C.byref(env._desc), C.byref(self._sess), self.posted, be.stream())
             _abi.check(be.lib, rc, "jss_session_close")

@@ -513,9 +513,26 @@ def case_bucketed_equals_padded(backend, n_envs=24, n_iter=260, seed=13):
     bucketed.reset()
     padded.rollout("random", n_iter=n_iter)
     bucketed.rollout("random", n_iter=n_iter)
-    padded.rollout_steps("random", steps=7, n_sub=2)        # the step-per-launch forms on top: sub-batches / per-bucket streams
-    bucketed.rollout_steps("random", steps=7, chunk=3)      # three chunks: 3 + 3 + 1 steps, dealt round-robin over the buckets
+    padded.rollout_steps("random", steps=7, n_sub=2)        # the step-per-launch forms on top: sub-batches / ONE grid over the classes
+    bucketed.rollout_steps("random", steps=7)               # 7 launches of jss_multi_rollout's fused grid
     n_iter += 7
+    # the un-fused calls, each one launch over all classes: policy -> actions per class -> step (with next-step auto-reset)
+    for _ in range(5):
+        padded.step(padded.policy("random"), autoreset=True)
+        acts = bucketed.policy("random")
+        res = bucketed.step(acts, autoreset=True)
+        assert set(res) == set(acts) == {0, 1, 2, 3}
+    # round 3's form (one launch per class and step, every class on its own stream) stays available and identical
+    legacy = BucketedJssEnv(insts, batch=n_envs, seed=seed, env_id_base=500, launch="streams", _backend=backend)
+    legacy.reset()
+    legacy.rollout("random", n_iter=n_iter - 7)
+    legacy.rollout_steps("random", steps=7)
+    for _ in range(5):
+        legacy.step(legacy.policy("random"), autoreset=True)
+    for i in range(n_envs):
+        a, b = legacy.host_state(i), bucketed.host_state(i)
+        assert a["clock"] == b["clock"] and (a["job_state"] == b["job_state"]).all() and (a["obs"] == b["obs"]).all(), f"env {i}"
+    assert legacy.stats() == bucketed.stats()
     for i in range(n_envs):
         a, b = padded.host_state(i), bucketed.host_state(i)
         assert a["clock"] == b["clock"] and (a["job_state"] == b["job_state"]).all(), f"env {i}"
@@ -523,11 +540,11 @@ def case_bucketed_equals_padded(backend, n_envs=24, n_iter=260, seed=13):
         assert np.abs(a["obs"] - b["obs"]).max() == 0 and a["episode"] == b["episode"]
     sa, sb = padded.stats(), bucketed.stats()
     assert sa == sb and sa["steps"] > 0
-    # and both agree with the oracle
+    # and both agree with the oracle (the five policy + step pairs with next-step auto-reset are five more rollout iterations)
     for i in (0, 5, 7, 23):
         o = OracleEnv(insts[i % len(insts)], strict=True)
         o.reset()
-        o.rollout("random", seed, 500 + i, n_iter, episode=1)
+        o.rollout("random", seed, 500 + i, n_iter + 5, episode=1)
         assert_matches_oracle(bucketed.host_state(i), o, f"bucketed env {i}")
 
 
@@ -975,6 +992,10 @@ FULL_SIZE_CONFIGS = [   # (label, BatchedJssEnv kwargs factory, policy, iteratio
     ("config 5: mixed ta01-80 x 32768, random",
      lambda: dict(instances=[I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=32768), "random", 300, 0.0),
     ("headline: ta01 x 65536, random", lambda: dict(instances="ta01", batch=65536), "random", 280, 0.0),
+    # the other two batches bench.py times: per-env 15x15 tables at 65 536 envs (24-byte medium records, <16,5,3>) and ALL
+    # of config 4 on one GPU (indices 5, 6: appended, the launch-form table of tests/test_hip_parity.py goes by index)
+    ("syn15x15: synthetic 15x15 x 65536, random", lambda: dict(instances=I.synthetic_packed(65536, 15, 15)), "random", 260, 0.0),
+    ("config 4 whole: synthetic 50x20 x 65536, random", lambda: dict(instances=I.synthetic_packed(65536, 50, 20)), "random", 150, 0.0),
 ]
 
 
@@ -1068,10 +1089,17 @@ def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=
     env = BatchedJssEnv(seed=seed, env_id_base=env_id_base, _backend=backend, **kw)
     env.reset()
     drive_steps(env, kind, iters, form=form, explore=explore, autoreset=autoreset, n_sub=n_sub)
-    label = f"{label} [{form}]"
+    assert_batch_equals_oracle(env, kind, seed, iters, f"{label} [{form}]", explore=explore, autoreset=autoreset)
+    return env
+
+
+def assert_batch_equals_oracle(env, kind, seed, iters, label, explore=0.0, autoreset=True):
+    """Every env of `env` -- `iters` x (policy + step) after a fresh reset -- against orc_rollout_batch (see
+    case_every_env_vs_oracle).  Works for a bucket of a BucketedJssEnv too: explicit global env ids key the RNG."""
     n = env.backend.numpy
     toe = None if env.n_tables == 1 or env.n_tables == env.batch and env._table_of_env is None else env.table_of_env_host
-    want = rollout_batch(env.packed, env.batch, kind, seed, iters, table_of_env=toe, env_id_base=env_id_base,
+    ids = None if env._env_ids is None else n(env._env_ids)
+    want = rollout_batch(env.packed, env.batch, kind, seed, iters, table_of_env=toe, env_id_base=env.env_id_base, env_ids=ids,
                          explore=explore, autoreset=autoreset)
     hdr, js = n(env.env_header), n(env.job_state)
     assert np.array_equal(hdr[:, _abi.H_CLOCK], want["clock"]), f"{label}: clock"
@@ -1095,6 +1123,26 @@ def case_every_env_vs_oracle(backend, label, kw, kind, iters, explore=0.0, seed=
     err = np.abs(n(env.real_obs).astype(np.float64) - want["obs"]).max()
     assert err <= OBS_TOL, f"{label}: observation max |diff| {err}"
     assert want["counters"][:, 0].min() > 0
+    return want
+
+
+def case_bucketed_every_env_vs_oracle(backend, n_envs=32768, iters=160, seed=6, env_id_base=123, launch="grid", kind="random",
+                                      unfused_tail=0):
+    """BASELINE config 5 without padding, at the benchmarked size: the mixed ta01-ta80 population as shape classes, stepped by
+    ONE grid per step (jss_multi_rollout; launch="streams": one launch per class and step), EVERY env of every class against
+    the C oracle.  unfused_tail: that many more steps through jss_multi_policy + jss_multi_step(autoreset), which -- the
+    policy being the same counter RNG -- are that many more iterations of the same rollout."""
+    from jssenv_amd.bucketed import BucketedJssEnv
+    insts = [I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
+    env = BucketedJssEnv(insts, batch=n_envs, seed=seed, env_id_base=env_id_base, launch=launch, _backend=backend)
+    assert sum(b.batch for _, b in env._each()) == n_envs and len(env._each()) == 4
+    env.reset()
+    env.rollout_steps(kind, steps=iters)
+    for _ in range(unfused_tail):
+        env.step(env.policy(kind), autoreset=True)
+    env.synchronize()
+    for k, b in env._each():
+        assert_batch_equals_oracle(b, kind, seed, iters + unfused_tail, f"mixed ta01-80 x {n_envs}, shape class {k} ({b.batch} envs) [{launch}]")
     return env
 
 
@@ -1519,10 +1567,9 @@ def case_medium_equals_full(backend, batch=40, n_iter=500, seed=29):
                 if x.shape == live.shape:
                     x, y = np.where(live, x, 0), np.where(live, y, 0)
                 assert np.array_equal(x, y), f"medium vs full records: attribute {name}"
-        toe = a.table_of_env_host if a._table_of_env is not None else None
-        want = rollout_batch(a.packed, a.batch, "random", seed, n_iter, table_of_env=toe, env_id_base=7)
-        assert np.array_equal(a.backend.numpy(a.env_header)[:, _abi.H_CLOCK], want["clock"])
-        assert np.array_equal(a.backend.numpy(a.solution), want["solution"]) and np.array_equal(a.backend.numpy(a.counters), want["counters"])
+        # every env against the oracle: clock, RNG position, the six per-job arrays, machine clocks, solution, mask, blocked
+        # flags, counters, error flags, the float32 observation
+        assert_batch_equals_oracle(a, "random", seed, n_iter, f"medium records, {len(insts)} instances x {batch} envs")
         d = a.state_dict()                                   # checkpoint round trip of the medium layout
         c = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=7, records="medium", _backend=backend)
         c.load_state_dict(d)

@@ -130,20 +130,27 @@ def test_bench_eight_ranks_on_one_gpu():
     the per-window SUM/MAX reductions and the config-4-sharded extra that only exists with N > 1."""
     import json
     import subprocess
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(), "detail.json")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-device", "--dist-backend", "gloo",
-           "--steps", "5", "--warmup", "1", "--batch", "4096", "--no-cpu-baseline"]
+           "--steps", "5", "--warmup", "1", "--batch", "4096", "--no-cpu-baseline", "--detail", detail]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
+    assert res.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096     # the driver's line: last, and small
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["steps"] == 5 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 8 * 4096 and out["value"] > 0
-    assert abs(out["roofline"]["frac"] - out["value"] / 8 * out["roofline"]["alg_bytes_per_env_step"] / 8e12) < 1e-9
-    c4 = out["config4_sharded"]
+    assert abs(out["roofline"]["frac"] - out["value"] / 8 * out["roofline"]["alg_bytes_per_env_step"] / 8e12) < 1e-4 * out["roofline"]["frac"]
+    assert out["configs"]["c4_syn50x20_b65536_sharded"] > 0
+    full = json.load(open(detail))                       # everything, unabridged
+    assert full["value"] == pytest.approx(out["value"], rel=1e-5)
+    c4 = full["config4_sharded"]
     assert c4.get("value"), c4
     assert c4["global_batch"] == 65536 and c4["batch"] == 8192 and c4["n_gpus"] == 8 and c4["scaling"] == "strong"
+    assert out["configs"]["c4_syn50x20_b65536_sharded"] == pytest.approx(c4["roofline_frac"], rel=1e-3)
 
 
 _RCCL_WORLD1 = r'''

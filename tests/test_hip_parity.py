@@ -161,6 +161,14 @@ def test_bucketed_equals_padded(hip):
     P.case_bucketed_equals_padded(hip, n_envs=400, n_iter=900)
 
 
+@pytest.mark.parametrize("launch", ["grid", "streams"])
+def test_bucketed_full_size_every_env_equals_the_oracle(hip_auto, launch):
+    """BASELINE config 5 without padding at the benchmarked 32 768 envs: ONE grid per step over the four shape classes
+    (jss_multi_kernel<kRollout1>), every env of every class against the C oracle; then the un-fused calls (jss_multi_policy,
+    jss_multi_step with next-step auto-reset) on top.  launch="streams" = round 3's one-launch-per-class form."""
+    P.case_bucketed_every_env_vs_oracle(hip_auto, n_envs=32768, iters=160, launch=launch, unfused_tail=12 if launch == "grid" else 0)
+
+
 def test_rules_with_exploration(hip):
     """the rules' 10 % NOPE exploration (dispatching.py:113) drawn from the counter RNG on the device"""
     env, orcs = P.case_batch_lockstep(hip, ["ta01", "ta21"], batch=4, n_steps=1200, kind="SPT", check_every=9, explore=0.1)
@@ -376,3 +384,4 @@ def test_medium_records_at_the_limits(hip):
 
 def test_policy_step_steps_equals_the_loop(hip):
     P.case_policy_step_steps(hip, batch=5000, steps=30)
+    P.case_policy_step_steps(hip, batch=65536, steps=12, warm=60)       # the benchmarked batch (bench.py policy_then_step_pipelined)

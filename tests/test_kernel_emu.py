@@ -92,6 +92,11 @@ def test_bucketed_equals_padded(emu):
     P.case_bucketed_equals_padded(emu, n_envs=24, n_iter=60)
 
 
+def test_fused_grid_over_the_shape_classes_every_env_equals_the_oracle(emu):
+    """jss_multi_kernel<kRollout1 / kPolicy / kStep / kReset>: ta01-ta80 as four shape classes in ONE grid per call"""
+    P.case_bucketed_every_env_vs_oracle(emu, n_envs=80, iters=20, unfused_tail=3)
+
+
 def test_rules_with_exploration(emu):
     """the rules' 10 % NOPE exploration (dispatching.py:113) drawn from the counter RNG on the device"""
     env, orcs = P.case_batch_lockstep(emu, ["ta01", "ta21"], batch=4, n_steps=70, kind="SPT", check_every=9, explore=0.1)
