@@ -255,6 +255,8 @@ def compact_line(out, detail_files=()):
         line["mean_makespan"] = _sig(out["mean_makespan"])
     if out.get("process_group"):
         line["process_group"] = out["process_group"]
+    if out.get("host_issue_us_per_launch") is not None:
+        line["host_issue_us_per_launch"] = _sig(float(out["host_issue_us_per_launch"]), 3)
     line["csrc_sha16"] = out.get("csrc_sha16")
     line["detail"] = list(detail_files)
     text = json.dumps(line, separators=(",", ":"))
@@ -337,7 +339,7 @@ def main():
     import torch
     import torch.distributed as dist
     from jssenv_amd import BatchedJssEnv, builtin_instance
-    from jssenv_amd.distributed import reduce_counters, shard_bounds
+    from jssenv_amd.distributed import reduce_counters, select_device, shard_bounds
     from jssenv_amd.instances import synthetic_packed
 
     rank = int(os.environ.get("RANK", "0"))
@@ -347,10 +349,10 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the GPU path has no CPU fallback")
-    if args.share_device:
-        local_rank = 0
-    elif torch.cuda.device_count() < world:
-        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
+    try:
+        local_rank = select_device(local_rank, world, torch.cuda.device_count(), share_device=args.share_device)
+    except (RuntimeError, ValueError) as exc:
+        raise SystemExit(f"bench.py: {exc}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = args.dist_backend or "nccl"   # "nccl" is RCCL on ROCm
@@ -483,6 +485,18 @@ def main():
 
     def pick_mode(env, policy, candidates):
         if hasattr(env, "buckets"):
+            if env.launch == "grid" and args.launch in ("auto", "sub2", "sub3"):
+                # parts per shape class (a grid per part and step, parts on their own streams): fastest on a short probe
+                choices = (1, 2, 3) if args.launch == "auto" else (int(args.launch[3:]),)
+                n_probe, probe = max(20, min(60, args.steps)), []
+                for n in choices:
+                    env.n_sub = n
+                    window(env, policy, n_probe, 1, "eager")
+                    probe.append(min(window(env, policy, n_probe, 1, "eager")[0] for _ in range(5)))
+                probe = agree_max(probe)
+                env.n_sub = choices[min(range(len(choices)), key=lambda i: probe[i])]
+                if rank == 0:
+                    print("bucketed parts-per-class probe: " + ", ".join(f"{n} {t:.6f}" for n, t in zip(choices, probe)), file=sys.stderr)
             return "eager"
         if args.launch != "auto":
             return args.launch
@@ -785,7 +799,7 @@ def main():
         out = {"workload": label + label_extra, "batch": batch, "policy": policy, "value": med["rate"],
                "min": rows[0]["rate"], "max": rows[-1]["rate"], "windows": len(rows), "unit": "env steps/s",
                "ms_per_step": med["seconds"] / args.steps * 1e3, "roofline_frac_gpu_time": rf["frac_gpu_time"],
-               "launch": (("ONE launch per step over all shape classes (jss_multi_rollout)" if args.bucketed_launch == "grid" else
+               "launch": ((f"one grid over all shape classes per step and part, {getattr(env, 'n_sub', 1)} part(s) per class (jss_multi_rollout)" if args.bucketed_launch == "grid" else
                            "one launch per shape bucket per step, every bucket on its own HIP stream") if bucketed else launch_label(mode)),
                "kernel": rf["kernel"], "roofline_frac": rf["frac"],
                "roofline_frac_of_measured_peak": rf["frac_of_measured_peak"], "alg_bytes_per_env_step": alg,
@@ -824,6 +838,21 @@ def main():
         med_b, rows_b = measure(env, args.policy, args.steps, ranking[1][0])
         if agree_max([med_b["rate"] - med["rate"]])[0] > 0:
             mode, med, rows = ranking[1][0], med_b, rows_b
+    # Host side of a window: what the C launch loop costs per launch (no synchronisation inside: the hardware queue holds a
+    # whole window).  With N ranks on one host this is what must stay below the kernel time per launch -- MAX over ranks.
+    host_issue_us = None
+    if hasattr(env, "bind_rollout_steps") and getattr(env.backend, "name", "") == "hip":
+        n_sub_i = int(mode[3:]) if mode.startswith("sub") else 1
+        issue = env.bind_rollout_steps(args.policy, steps=args.steps, n_sub=n_sub_i, autoreset=True, caller_orders_streams=True)
+        best = float("inf")
+        for _ in range(7):
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            issue()
+            best = min(best, time.perf_counter() - t0)
+            torch.cuda.synchronize()
+        host_issue_us = agree_max([best / (args.steps * n_sub_i) * 1e6])[0]
     bucket_note = ", shape-bucketed (no padding)" if (args.bucketed and args.workload == "mixed") else \
         (", padded 100x20" if args.workload == "mixed" else "")
     inst0 = builtin_instance(args.instance)
@@ -834,7 +863,7 @@ def main():
         "data": ("ta01 (the reference's Taillard instance; no dataset involved)" if args.workload == "shared" and args.instance == "ta01"
                  else "synthetic" if args.workload.startswith("synthetic") else "reference instances (ta01-ta80)"),
         "windows": window_stats(rows, args.steps),
-        "launch": (("ONE launch per step over all shape classes (jss_multi_rollout, C launch loop)" if args.bucketed_launch == "grid" else
+        "launch": ((f"one grid over all shape classes per step and part, {getattr(env, 'n_sub', 1)} part(s) per class (jss_multi_rollout, C launch loop)" if args.bucketed_launch == "grid" else
                     "one launch per shape bucket per step, every bucket on its own HIP stream (C launch loop)")
                    if hasattr(env, "buckets") else launch_label(mode)),
         "config": {"workload": f"{wl_label}{bucket_note}, {args.policy} masked policy fused with step(), "
@@ -843,6 +872,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": args.batch * world if args.scaling == "weak" else args.batch,
                    "parallelism": f"env-shard x{world}", "policy": args.policy},
         "roofline": roofline(med, alg_per_step, args.steps, env, None if hasattr(env, "buckets") else key, B),
+        "host_issue_us_per_launch": host_issue_us,
         "episodes_finished": med["episodes"],
         "mean_makespan": med["makespan_sum"] / med["episodes"] if med["episodes"] else None,
         "mean_reward_per_step": (med["reward_num"] / inst0.max_time_op / med["steps"]) if (med["steps"] and args.workload == "shared") else None,

@@ -215,6 +215,13 @@ extern "C" {
  * two <= 64 -- the factors for which factor * job_length is exact in the reference's doubles, so that the device's exact
  * fraction comparison (p * job_length - q * now) / remaining sees the reference's order AND its ties.  0 = 3 / 2. */
 #define JSS_POLICY_CR_FACTOR(p, q) (JSS_POLICY_CR | ((p) << 8) | ((q) << 16))
+/* CriticalRatio with ANY due-date factor the reference accepts (a Python float, dispatching.py:337-360): the factor travels as
+ * the double JssDesc.cr_factor and the selector evaluates the reference's own float64 expression -- fl(fl(fl(length * factor)
+ * - now) / remaining), IEEE round-to-nearest, no contraction -- so order and ties are the reference's bit for bit.  Accepted by
+ * the calls whose policy is a launch of its own (jss_policy, jss_multi_policy, jss_policy_step_steps); the fused rollouts
+ * (jss_rollout, jss_rollout_steps, jss_trajectory, jss_multi_rollout) keep the integer-exact p / q form above and answer
+ * JSS_E_KIND: their kernels carry no float64 code. */
+#define JSS_POLICY_CR_F64 (JSS_POLICY_CR | (1 << 24))
 
 /* jss_rollout flags */
 #define JSS_ROLLOUT_AUTORESET 1 /* an env found done is reset instead of stepped (iteration not counted) */
@@ -258,6 +265,7 @@ typedef struct JssDesc {
     int32_t record_ints;         /* ints per job record: 0 or JSS_NF = full records; JSS_NFC = compact records
                                     (n_tables == 1 only, else JSS_E_SHAPE); JSS_NFM = medium records (n_tables > 1 and
                                     mmax <= 32, else JSS_E_SHAPE)                           */
+    double cr_factor;            /* CriticalRatio's due_date_factor for kind = JSS_POLICY_CR_F64 (> 0); ignored otherwise */
 } JssDesc;
 
 typedef struct JssState {
@@ -431,7 +439,7 @@ int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const J
  * every set i exactly what the single-set call does with descs[i] / states[i] / outs[i] -- jss_multi_reset = jss_reset
  * (JssEnv.reset, jss_env.py:145-181), jss_multi_step = jss_step / jss_step_autoreset (JssEnv.step, :403-481;
  * flags = JSS_ROLLOUT_AUTORESET or 0), jss_multi_policy = jss_policy, jss_multi_rollout = n_steps x jss_rollout(n_iter = 1)
- * (n_steps launches) -- all on `stream`, results identical.  The fused grid covers sets with per-env instance tables
+ * (n_steps launches per part, see below) -- results identical.  The fused grid covers sets with per-env instance tables
  * (n_tables > 1; full records, or medium records on the 16- / 32-lane shapes), 2 to 6 of them; any other combination is
  * issued as one plain launch per set on the same stream (same results).  `which` (jss_multi_reset) may be NULL, and so may
  * its entries: every env of that set.  1 <= n_sets <= 16. */
@@ -441,8 +449,12 @@ int jss_multi_step(int32_t n_sets, const JssDesc *const *descs, const JssState *
                    const JssOut *const *outs, int32_t flags, void *stream);
 int jss_multi_policy(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, int kind, uint64_t seed,
                      uint32_t explore_q16, int32_t *const *actions, void *stream);
+/* n_sub, streams, JSS_ROLLOUT_FORK_JOIN as jss_rollout_steps: with n_sub > 1 every set is cut into n_sub contiguous parts
+ * (at multiples of 64 envs; at most 4 are used) and part i of ALL sets is one grid per step on streams[i], so that one part's
+ * drain overlaps another's fill; n_sub = 1 is one grid per step on streams[0]. */
 int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
-                      int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, void *stream);
+                      int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub,
+                      void *const *streams);
 
 #ifdef JSS_PROFILING
 /* Instrumented builds only (tools/build_instrumented.py compiles with -DJSS_PROFILING; the shipped library does

@@ -46,6 +46,9 @@ def cr_kind(due_date_factor: float = 1.5):
     return POLICY["CR"] | (f.numerator << 8) | (f.denominator << 16)
 
 
+POLICY_CR_F64 = POLICY["CR"] | (1 << 24)    # JSS_POLICY_CR_F64: the factor travels as the double JssDesc.cr_factor
+
+
 def policy_code(kind):
     """str | int -> the int the C ABI takes."""
     return POLICY[kind] if isinstance(kind, str) else int(kind)
@@ -65,7 +68,7 @@ class JssDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("jmax", C.c_int32), ("mmax", C.c_int32), ("n_tables", C.c_int32),
                 ("ops", _p), ("rem", _p), ("inst", _p), ("table_of_env", _p), ("env_ids", _p),
                 ("env_id_base", C.c_int64), ("kernel", C.c_int32), ("threads", C.c_int32),
-                ("jmin", C.c_int32), ("record_ints", C.c_int32)]
+                ("jmin", C.c_int32), ("record_ints", C.c_int32), ("cr_factor", C.c_double)]
 
 
 class JssState(C.Structure):
@@ -123,7 +126,7 @@ def bind(lib):
     lib.jss_multi_policy.restype = C.c_int
     lib.jss_multi_policy.argtypes = [C.c_int32, PD, PS, C.c_int, C.c_uint64, C.c_uint32, PP, _p]
     lib.jss_multi_rollout.restype = C.c_int
-    lib.jss_multi_rollout.argtypes = [C.c_int32, PD, PS, PO, C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, _p]
+    lib.jss_multi_rollout.argtypes = [C.c_int32, PD, PS, PO, C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, PP]
     lib.jss_trajectory.restype = C.c_int
     lib.jss_trajectory.argtypes = [D, S, O, C.POINTER(JssTraj), C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, _p]
     lib.jss_sync_check.restype, lib.jss_sync_check.argtypes = C.c_int, [_p]

@@ -84,6 +84,7 @@ class BucketedJssEnv:
             self.buckets[k] = sub
         self._backend = _backend
         self.launch = launch
+        self.n_sub = 1                               # parts per class in rollout_steps (see there)
         each = self._each()
         n_sets = len(each)
         D, S, O = C.POINTER(_abi.JssDesc), C.POINTER(_abi.JssState), C.POINTER(_abi.JssOut)
@@ -128,9 +129,12 @@ class BucketedJssEnv:
             b.rollout(kind, n_iter=n_iter, seed=self._seed(seed), autoreset=autoreset, explore=explore)
 
     def rollout_steps(self, kind="random", steps=1, n_iter=1, seed=None, autoreset=True, explore=0.0,
-                      caller_orders_streams=False):
+                      caller_orders_streams=False, n_sub=None):
         """`steps` consecutive one-step rollouts of every env: `steps` launches, each ONE grid over all shape classes
-        (jss_multi_rollout), issued from a C loop.  Same results as `steps` x rollout(n_iter=1) of each bucket."""
+        (jss_multi_rollout), issued from a C loop.  Same results as `steps` x rollout(n_iter=1) of each bucket.
+        n_sub (default: the env's ``n_sub``, 1): every class is cut into n_sub contiguous parts and part i of ALL classes is
+        one grid per step on stream i (the current stream + the process-wide side streams), so that the drain of one
+        part's step overlaps the fill of another's -- what ``BatchedJssEnv.rollout_steps`` does for a single batch."""
         if n_iter != 1:
             for _ in range(steps):
                 self.rollout(kind, n_iter=n_iter, seed=seed, autoreset=autoreset, explore=explore)
@@ -148,7 +152,14 @@ class BucketedJssEnv:
                                                     be.stream_array(self._n_sets))
                 _abi.check(be.lib, rc, "jss_rollout_steps_multi")
                 return
-            rc = be.lib.jss_multi_rollout(self._n_sets, *self._sets, k, self._seed(seed), q16, int(steps), flags, be.stream())
+            n = max(1, min(4, int(self.n_sub if n_sub is None else n_sub)))
+            if hasattr(be, "stream_array"):
+                streams = be.stream_array(n)
+                if n > 1 and not caller_orders_streams:
+                    flags |= _abi.ROLLOUT_FORK_JOIN
+            else:
+                streams = (C.c_void_p * n)()
+            rc = be.lib.jss_multi_rollout(self._n_sets, *self._sets, k, self._seed(seed), q16, int(steps), flags, n, streams)
         _abi.check(be.lib, rc, "jss_multi_rollout")
 
     def policy(self, kind="random", seed=None, explore=0.0):

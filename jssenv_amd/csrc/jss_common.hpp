@@ -98,21 +98,31 @@ struct Params {
     int32_t norm_slot_ints;           // packed kernel, kTabGlobal: ints between two slots' normaliser tables
 };
 
-// The kernels take their Params by value (the kernel-argument segment), but read them through a POINTER to that segment:
-// a by-value struct argument handed on by reference is first copied into a private object, which the optimiser then turns
-// into "every field loaded in the entry block" -- some 60 scalar registers live from the first instruction to each field's
-// last use.  That, not the algorithm, was what the one-wavefront-per-env kernels ran out of SGPRs on (rounds 2-4: 16-58
-// SGPR values parked in VGPR lanes in the step / rollout kernels, scratch in the trajectory ones).  Read in place, a field is
-// a scalar load next to its use: jss_kernel<2, kRollout1, kTabGlobal> 54 -> 0 spilled SGPRs, <1, kStep, kTabGlobal> 16 -> 0
-// at unchanged occupancy (tools/kernel_resources.py).  The explicit arguments start at offset 0 of the segment.
-// (Host pass and the test emulator: the argument itself.)
-// (-DJSS_PARAMS_BY_VALUE: A/B builds of the old form)
+// Where a kernel reads its Params from.  They arrive by value (the kernel-argument segment); handed on by reference, a
+// by-value struct is first copied into a private object, which the optimiser turns into "every field loaded in the entry
+// block": some 60 scalar registers live from the first instruction to each field's last use.  That -- not the algorithm --
+// is what makes the one-wavefront-per-env kernels overrun their SGPR budget (16-58 SGPR values parked in VGPR lanes in the
+// step / rollout kernels, up to 236 and some scratch in the trajectory ones).  Read IN PLACE, through a pointer to the segment,
+// a field is a scalar load next to its use and the spills are gone: jss_kernel<2, kRollout1, kTabGlobal> 54 -> 0 spilled
+// SGPRs, <1, kStep, kTabGlobal> 16 -> 0, every kRollout1 / kStep instantiation 0 at unchanged occupancy (tools/kernel_resources.py
+// on a -DJSS_PARAMS_ALL_IN_PLACE build).  It does not pay: the entry-block loads wait once, behind the state loads that
+// every wave waits for anyway, while an in-place load waits in the middle of the dependent chain.  Same-box A/B, round 5
+// (profiles/r05_misc/ab_params_in_place.txt): config 5 padded rollout +-0 %, its jss_step -3 %, config 4's share -2 %,
+// config 3's packed kernel -10 %, headline +-0.  A spilled SGPR is two VALU-lane moves among ~800 instructions; the wait
+// is what costs.  So the kernels keep the by-value form (in_place = false everywhere); only the fused multi-set grid
+// (jss_multi_kernel), whose workgroups pick one of several Params at run time, reads in place by construction.
+// The explicit arguments start at offset 0 of the segment.  (Host pass and the test emulator: the argument itself.
+// -DJSS_PARAMS_ALL_IN_PLACE: A/B builds.)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(JSS_PARAMS_BY_VALUE)
-#define JSS_PARAMS_IN_PLACE(p, arg) \
-    (void)(arg);                    \
+#ifdef JSS_PARAMS_ALL_IN_PLACE
+#define JSS_PARAMS_OF(p, arg, in_place) \
     const Params &p = *reinterpret_cast<const Params *>(__builtin_amdgcn_kernarg_segment_ptr())
 #else
-#define JSS_PARAMS_IN_PLACE(p, arg) const Params &p = (arg)
+#define JSS_PARAMS_OF(p, arg, in_place) \
+    const Params &p = (in_place) ? *reinterpret_cast<const Params *>(__builtin_amdgcn_kernarg_segment_ptr()) : (arg)
+#endif
+#else
+#define JSS_PARAMS_OF(p, arg, in_place) const Params &p = (arg)
 #endif
 
 #ifdef JSS_PROFILING
@@ -321,6 +331,44 @@ __device__ __forceinline__ CrKey cr_argmin(CrKey k) {   // butterfly inside alig
     return k;
 }
 constexpr int kCrNone = 1 << 20;
+
+// JSS_POLICY_CR_F64: the reference's float64 expression itself (dispatching.py:351-363, :391-398) -- due date = length *
+// factor, ratio = (due date - now) / remaining -- every operation rounded on its own (no fused multiply-add), so that the
+// doubles, their order and their ties are the reference's.  Smallest ratio first, lowest job index on ties (strict `<`, :399).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double cr_ratio_f64(int length, double factor, int now, int remaining) {
+    return __ddiv_rn(__dsub_rn(__dmul_rn((double)length, factor), (double)now), (double)remaining);
+}
+#else
+__device__ __forceinline__ double cr_ratio_f64(int length, double factor, int now, int remaining) {
+    volatile double due = (double)length * factor;      // (volatile: no contraction on the host pass either)
+    volatile double left = due - (double)now;
+    return left / (double)remaining;
+}
+#endif
+struct CrKeyF {
+    double ratio;
+    int idx;
+};
+__device__ __forceinline__ bool cr_better_f64(const CrKeyF &a, const CrKeyF &b) {
+    return a.ratio < b.ratio || (a.ratio == b.ratio && a.idx < b.idx);
+}
+template <int WIDTH>
+__device__ __forceinline__ CrKeyF cr_argmin_f64(CrKeyF k) {   // butterfly inside aligned groups of WIDTH lanes
+#pragma unroll
+    for (int off = WIDTH / 2; off > 0; off >>= 1) {
+        CrKeyF o;
+        union { double d; int w[2]; } mine, theirs;
+        mine.d = k.ratio;
+        theirs.w[0] = __shfl_xor(mine.w[0], off);
+        theirs.w[1] = __shfl_xor(mine.w[1], off);
+        o.ratio = theirs.d;
+        o.idx = __shfl_xor(k.idx, off);
+        if (cr_better_f64(o, k)) k = o;
+    }
+    return k;
+}
+constexpr double kCrInf = __builtin_huge_val();
 
 constexpr uint64_t kExploreSeedXor = 0x5851F42D4C957F2DULL;
 

@@ -441,9 +441,21 @@ int select_action(const Env &e, const Call &c, uint64_t env_id) {
     int best = -1;
     long long best_num = 0, best_den = 1;                                 // CR: exact fraction compare
     int best_v = 0;
+    const bool cr_f64 = kind == JSS_POLICY_CR && ((c.kind >> 24) & 1);    // JSS_POLICY_CR_F64: the reference's doubles themselves
+    double best_ratio = 0.0;
     for (int j = 0; j < e.J; ++j) {
         if (!e.legal(j)) continue;
         const int todo = e.todo(j);
+        if (cr_f64) {                                                     // dispatching.py:351-363, :391-399
+            volatile double due = (double)e.rem[j * e.stride] * c.d.cr_factor;       // (volatile: each operation rounded on its own)
+            volatile double left = due - (double)e.t();
+            const double ratio = left / (double)e.rem[j * e.stride + todo];
+            if (best < 0 || ratio < best_ratio) {
+                best = j;
+                best_ratio = ratio;
+            }
+            continue;
+        }
         if (kind == JSS_POLICY_CR) {                                      // dispatching.py:365-408, (p L - q t) / remaining
             const long long num = cr_p * e.rem[j * e.stride] - cr_q * e.t(), den = e.rem[j * e.stride + todo];
             if (best < 0 || num * best_den < best_num * den) {
@@ -697,9 +709,13 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
     return 0;
 }
 
-int check_kind(const JssDesc *d, int kind_arg) {
+// f64_ok: the calls whose policy is a launch of its own on the GPU (JSS_POLICY_CR_F64, include/jss_hip.h): same answers here
+int check_kind(const JssDesc *d, int kind_arg, bool f64_ok = false) {
     const int kind = kind_arg & 0xFF, fp = (kind_arg >> 8) & 0xFF, fq = (kind_arg >> 16) & 0xFF;
-    if (kind_arg < 0 || (kind_arg >> 24) || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+    if (kind_arg < 0 || (kind_arg >> 25) || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+    if ((kind_arg >> 24) & 1) {
+        if (!f64_ok || kind != JSS_POLICY_CR || fp || fq || !(d->cr_factor > 0.0) || !(d->cr_factor < 1e300)) return JSS_E_KIND;
+    }
     if (fp || fq) {                                  // a due-date factor p / q: CriticalRatio only, q a power of two <= 64
         if (kind != JSS_POLICY_CR || fp < 1 || fq < 1 || fq > 64 || (fq & (fq - 1))) return JSS_E_KIND;
     }
@@ -773,7 +789,7 @@ int jss_policy(const JssDesc *desc, const JssState *state, int kind, uint64_t se
     int rc = check_args(desc, state, nullptr, false);
     if (rc) return rc;
     if (!actions) return JSS_E_NULL;
-    if ((rc = check_kind(desc, kind))) return rc;
+    if ((rc = check_kind(desc, kind, true))) return rc;
     Call c;
     c.d = *desc; c.s = *state; c.o = JssOut(); c.actions_out = actions; c.kind = kind; c.seed = seed; c.explore_q16 = explore_q16;
     return run(c, kPolicy);
@@ -968,9 +984,11 @@ int jss_multi_policy(int32_t n_sets, const JssDesc *const *descs, const JssState
 }
 
 int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
-                      int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, void *stream) {
-    if (!descs || !states || !outs) return JSS_E_NULL;
-    if (n_sets < 1 || n_sets > 16 || n_steps < 0) return JSS_E_SHAPE;
+                      int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub,
+                      void *const *streams) {
+    if (!descs || !states || !outs || !streams) return JSS_E_NULL;
+    if (n_sets < 1 || n_sets > 16 || n_steps < 0 || n_sub < 1 || n_sub > 16) return JSS_E_SHAPE;
+    void *stream = nullptr;
     for (int i = 0; i < n_sets; ++i) {       // n_steps x rollout(n_iter = 1) == rollout(n_iter = n_steps) on the state; `out` holds the last step either way
         const int rc = jss_rollout(descs[i], states[i], outs[i], kind, seed, explore_q16, n_steps, flags & JSS_ROLLOUT_AUTORESET, stream);
         if (rc) return rc;

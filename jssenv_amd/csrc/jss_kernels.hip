@@ -39,9 +39,13 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
 
 int record_ints_of(const JssDesc &d) { return d.record_ints == JSS_NFC ? JSS_NFC : d.record_ints == JSS_NFM ? JSS_NFM : JSS_NF; }
 
-int check_kind(const JssDesc *d, int kind_arg) {
+// f64_ok: the call's policy is a launch of its own (the kernels that carry JSS_POLICY_CR_F64's float64 selector)
+int check_kind(const JssDesc *d, int kind_arg, bool f64_ok = false) {
     const int kind = kind_arg & 0xFF, fp = (kind_arg >> 8) & 0xFF, fq = (kind_arg >> 16) & 0xFF;
-    if (kind_arg < 0 || (kind_arg >> 24) || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+    if (kind_arg < 0 || (kind_arg >> 25) || kind >= JSS_N_POLICIES) return JSS_E_KIND;
+    if ((kind_arg >> 24) & 1) {                      // JSS_POLICY_CR_F64: the factor is JssDesc.cr_factor
+        if (!f64_ok || kind != JSS_POLICY_CR || fp || fq || !(d->cr_factor > 0.0) || !(d->cr_factor < 1e300)) return JSS_E_KIND;
+    }
     if (fp || fq) {                                  // a due-date factor p / q: CriticalRatio only, q a power of two <= 64
         if (kind != JSS_POLICY_CR || fp < 1 || fq < 1 || fq > 64 || (fq & (fq - 1))) return JSS_E_KIND;
     }
@@ -364,7 +368,11 @@ __global__ __launch_bounds__(kBlock, multi_min_blocks(MODE)) void jss_multi_kern
     for (int i = 0; i + 1 < kMultiMaxSets; ++i)
         if (i + 1 < mp.n_sets && blk >= mp.block_end[i]) k = i + 1;
     const int block = blk - (k ? mp.block_end[k - 1] : 0);
+#ifdef JSS_MULTI_PARAMS_COPY          // A/B builds: the set's Params copied up front (every field loaded in the entry block)
+    const Params p = mp.p[k];
+#else
     const Params &p = mp.p[k];
+#endif
     switch (mp.flavour[k]) {
     case kMfW2G: wave_block<2, MODE, kTabGlobal, false>(p, block, lds); break;   // (one body: 66 VGPRs, no spills at 7 waves / SIMD)
     case kMfW1G: wave_block<1, MODE, kTabGlobal>(p, block, lds); break;
@@ -386,9 +394,12 @@ int multi_flavour(const JssDesc &d) {
 }
 
 // `ps[0..n)`: fully filled Params of the sets (everything but the launch-derived LDS fields).  One fused launch per step when
-// every set has a body in the grid, otherwise one plain launch per set and step, all on `stream`.
+// every set has a body in the grid, otherwise one plain launch per set and step.  n_sub > 1: every set is cut into n_sub
+// contiguous parts (boundaries at multiples of 64 envs) and part i of ALL sets is one grid on streams[i] -- step s of a part
+// depends only on its own step s - 1, so one part's drain overlaps another's fill (what jss_rollout_steps does for one set).
+// Step-type modes only (sub_batch); fork_join as in jss_rollout_steps.
 template <int MODE>
-int launch_multi(Params *ps, int n, int n_steps, void *stream) {
+int launch_multi(Params *ps, int n, int n_steps, int n_sub, void *const *streams, bool fork_join) {
     bool fused = n >= 2 && n <= kMultiMaxSets;
     for (int i = 0; i < n && fused; ++i) fused = multi_flavour(ps[i].d) != kMfNone;
     if (!fused) {
@@ -399,7 +410,7 @@ int launch_multi(Params *ps, int n, int n_steps, void *stream) {
         }
         for (int s = 0; s < n_steps; ++s)
             for (int i = 0; i < n; ++i) {
-                const int rc = fire(ps[i], lps[i], stream);
+                const int rc = fire(ps[i], lps[i], streams[0]);
                 if (rc) return rc;
             }
         return 0;
@@ -410,32 +421,48 @@ int launch_multi(Params *ps, int n, int n_steps, void *stream) {
         for (int j = i; j > 0 && multi_flavour(ps[order[j]].d) < multi_flavour(ps[order[j - 1]].d); --j) {
             const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
         }
-    static MultiParams mp;                                               // (2.3 KB: not on the stack of every caller)
+    constexpr int kMaxParts = 4;
+    if (n_sub > kMaxParts) n_sub = kMaxParts;
+    static MultiParams mp[kMaxParts];                                    // (2 KB each: not on the stack of every caller)
     static std::mutex mp_mutex;
     std::lock_guard<std::mutex> lock(mp_mutex);
     size_t shmem = 0;
-    int blocks = 0, m = 0;
-    for (int q = 0; q < n; ++q) {
-        Params &p = ps[order[q]];
-        if (p.d.batch == 0) continue;
-        LaunchPlan lp;
-        const int rc = plan<MODE>(p, lp);
-        if (rc) return rc;
-        blocks += (p.d.batch + lp.envs_per_block - 1) / lp.envs_per_block;
-        mp.p[m] = p;
-        mp.block_end[m] = blocks;
-        mp.flavour[m] = multi_flavour(p.d);
-        if (lp.shmem > shmem) shmem = lp.shmem;
-        ++m;
+    int blocks[kMaxParts] = {}, parts = 0;
+    for (int part = 0; part < n_sub; ++part) {
+        MultiParams &m = mp[parts];
+        int nb = 0, k = 0;
+        for (int q = 0; q < n; ++q) {
+            Params &whole = ps[order[q]];
+            const int chunk = n_sub == 1 ? whole.d.batch : ((((whole.d.batch + n_sub - 1) / n_sub) + 63) & ~63);
+            const int start = part * chunk;
+            if (start >= whole.d.batch) continue;
+            LaunchPlan lp;
+            const int rc = plan<MODE>(whole, lp);                        // (fills the LDS layout fields of `whole`)
+            if (rc) return rc;
+            Params p = n_sub == 1 ? whole : sub_batch(whole, start, whole.d.batch - start < chunk ? whole.d.batch - start : chunk);
+            nb += (p.d.batch + lp.envs_per_block - 1) / lp.envs_per_block;
+            m.p[k] = p;
+            m.block_end[k] = nb;
+            m.flavour[k] = multi_flavour(p.d);
+            if (lp.shmem > shmem) shmem = lp.shmem;
+            ++k;
+        }
+        if (k == 0) continue;
+        m.n_sets = k;
+        blocks[parts++] = nb;
     }
-    if (m == 0) return 0;
-    mp.n_sets = m;
-    for (int s = 0; s < n_steps; ++s) {                                  // (the arguments are copied at every launch)
-        hipLaunchKernelGGL(jss_multi_kernel<MODE>, dim3(blocks), dim3(kBlock), shmem, reinterpret_cast<hipStream_t>(stream), mp);
-        const int rc = (int)hipGetLastError();
-        if (rc) return rc;
-    }
-    return 0;
+    if (parts == 0) return 0;
+    ForkJoinEvents *ev = nullptr;
+    int rc = 0;
+    fork_join = fork_join && parts > 1;
+    if (fork_join && ((rc = events_for(streams[0], &ev)) || (rc = fork_streams(*ev, streams, parts)))) return rc;
+    for (int s = 0; s < n_steps && !rc; ++s)                             // (the arguments are copied at every launch)
+        for (int i = 0; i < parts && !rc; ++i) {
+            hipLaunchKernelGGL(jss_multi_kernel<MODE>, dim3(blocks[i]), dim3(kBlock), shmem, reinterpret_cast<hipStream_t>(streams[i]), mp[i]);
+            rc = (int)hipGetLastError();
+        }
+    const int jrc = fork_join ? join_streams(*ev, streams, parts) : 0;
+    return rc ? rc : jrc;
 }
 
 int check_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs, bool need_out) {
@@ -523,7 +550,7 @@ int jss_policy(const JssDesc *desc, const JssState *state, int kind, uint64_t se
     int rc = check_args(desc, state, nullptr, false);
     if (rc) return rc;
     if (!actions) return JSS_E_NULL;
-    if ((rc = check_kind(desc, kind))) return rc;
+    if ((rc = check_kind(desc, kind, true))) return rc;
     Params p = {};
     p.d = *desc; p.s = *state; p.actions_out = actions; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
     return launch<kPolicy>(p, stream);
@@ -698,7 +725,7 @@ int jss_policy_step_steps(const JssDesc *desc, const JssState *state, const JssO
                           void *const *streams) {
     int rc = check_args(desc, state, out, true);
     if (rc) return rc;
-    if ((rc = check_kind(desc, kind))) return rc;
+    if ((rc = check_kind(desc, kind, true))) return rc;
     if (n_steps < 0 || n_sub < 1 || n_sub > 16) return JSS_E_SHAPE;
     if (!streams || !actions) return JSS_E_NULL;
     Params pp = {}, ps = {};
@@ -740,7 +767,7 @@ int jss_multi_reset(int32_t n_sets, const JssDesc *const *descs, const JssState 
         ps[i] = {};
         ps[i].d = *descs[i]; ps[i].s = *states[i]; ps[i].o = *outs[i]; ps[i].which = which ? which[i] : nullptr;
     }
-    return launch_multi<kReset>(ps, n_sets, 1, stream);
+    return launch_multi<kReset>(ps, n_sets, 1, 1, &stream, false);
 }
 
 int jss_multi_step(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const int32_t *const *actions,
@@ -755,7 +782,7 @@ int jss_multi_step(int32_t n_sets, const JssDesc *const *descs, const JssState *
         ps[i].d = *descs[i]; ps[i].s = *states[i]; ps[i].o = *outs[i]; ps[i].actions = actions[i];
         ps[i].flags = flags & JSS_ROLLOUT_AUTORESET;
     }
-    return launch_multi<kStep>(ps, n_sets, 1, stream);
+    return launch_multi<kStep>(ps, n_sets, 1, 1, &stream, false);
 }
 
 int jss_multi_policy(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, int kind, uint64_t seed,
@@ -766,19 +793,21 @@ int jss_multi_policy(int32_t n_sets, const JssDesc *const *descs, const JssState
     Params ps[16];
     for (int i = 0; i < n_sets; ++i) {
         if (!actions[i]) return JSS_E_NULL;
-        if ((rc = check_kind(descs[i], kind))) return rc;
+        if ((rc = check_kind(descs[i], kind, true))) return rc;
         ps[i] = {};
         ps[i].d = *descs[i]; ps[i].s = *states[i]; ps[i].actions_out = actions[i]; ps[i].kind = kind; ps[i].seed = seed;
         ps[i].explore_q16 = explore_q16;
     }
-    return launch_multi<kPolicy>(ps, n_sets, 1, stream);
+    return launch_multi<kPolicy>(ps, n_sets, 1, 1, &stream, false);
 }
 
 int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
-                      int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, void *stream) {
+                      int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub,
+                      void *const *streams) {
     int rc = check_multi(n_sets, descs, states, outs, true);
     if (rc) return rc;
-    if (n_steps < 0) return JSS_E_SHAPE;
+    if (n_steps < 0 || n_sub < 1 || n_sub > 16) return JSS_E_SHAPE;
+    if (!streams) return JSS_E_NULL;
     Params ps[16];
     for (int i = 0; i < n_sets; ++i) {
         if ((rc = check_kind(descs[i], kind))) return rc;
@@ -786,7 +815,7 @@ int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssStat
         ps[i].d = *descs[i]; ps[i].s = *states[i]; ps[i].o = *outs[i]; ps[i].kind = kind; ps[i].seed = seed;
         ps[i].explore_q16 = explore_q16; ps[i].n_iter = 1; ps[i].flags = flags & JSS_ROLLOUT_AUTORESET;
     }
-    return launch_multi<kRollout1>(ps, n_sets, n_steps, stream);
+    return launch_multi<kRollout1>(ps, n_sets, n_steps, n_sub, streams, (flags & JSS_ROLLOUT_FORK_JOIN) != 0);
 }
 
 int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states,

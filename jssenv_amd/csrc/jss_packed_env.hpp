@@ -92,6 +92,9 @@ __device__ __forceinline__ bool grp_any(bool p, int gbase) {
 // value of `v` on group lane `idx` (idx group-uniform or not, any lane may ask for any lane)
 template <int G>
 __device__ __forceinline__ int grp_read(int v, int idx, int gbase) {
+#ifdef JSS_EXP_NO_GRPREAD   // A/B builds only (WRONG results): every cross-lane read answers the lane's own value -- what a pass
+    return v;               // would cost if ALL of them were free (profiles/r05_misc/ablate_cross_lane.txt)
+#endif
     return __builtin_amdgcn_ds_bpermute((gbase + (idx & (G - 1))) << 2, v);
 }
 
@@ -462,7 +465,8 @@ __device__ __forceinline__ int p_step(PEnv<G> &e, const PCtx<G, TAB> &c, const P
 // ---------------------------------------------------------------------------------------
 // action selectors (group-uniform result; -1 when nothing is legal)
 // ---------------------------------------------------------------------------------------
-template <int G, int TAB>
+// F64: the instantiation also carries JSS_POLICY_CR_F64's float64 selector (the policy kernels only)
+template <int G, int TAB, bool F64 = false>
 __device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, uint64_t env_id,
                                         uint32_t episode, uint32_t step) {
     const int kind = p.kind & 0xFF;
@@ -479,7 +483,13 @@ __device__ __forceinline__ int p_select(const PEnv<G> &e, const PCtx<G, TAB> &c,
     } else {
         // remaining-work table row of my job: rem[k] = durations of ops k..M-1 (MWR / LWR / CR)
         const int32_t *rem = p.d.rem + (size_t)c.tid * p.region_ints + c.gl * p.d.mmax;
-        if (kind == JSS_POLICY_CR) {
+        if (F64 && kind == JSS_POLICY_CR && ((p.kind >> 24) & 1)) {
+            CrKeyF key;
+            key.ratio = e.legal ? cr_ratio_f64(rem[0], p.d.cr_factor, e.t, rem[e.todo]) : kCrInf;
+            key.idx = e.legal ? c.gl : kCrNone;
+            key = cr_argmin_f64<G>(key);
+            a = key.idx < kCrNone ? key.idx : c.J;                       // no job legal: NOPE
+        } else if (kind == JSS_POLICY_CR) {
             const int total = e.legal ? rem[0] : 0;                      // dispatching.py:373 job length
             const int remaining = e.legal ? rem[e.todo] : 1;             // :391
             CrKey key;
@@ -881,7 +891,7 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
     } else if (MODE == kPolicy) {
         const uint64_t env_id = (uint64_t)(p.d.env_ids ? ld_off<int64_t>(p.d.env_ids + fe, c.rel * 8u)
                                                        : p.d.env_id_base + (int64_t)(fe + c.rel));
-        const int a = p_select(e, c, p, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
+        const int a = p_select<G, TAB, true>(e, c, p, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
         if (c.alive && c.gl == 0) st_off<int>(p.actions_out + fe, c.rel * 4u, a);
     } else {  // kRollout / kRollout1 / kTraj
         const uint64_t env_id = (uint64_t)(p.d.env_ids ? ld_off<int64_t>(p.d.env_ids + fe, c.rel * 8u)
@@ -1060,9 +1070,10 @@ __global__ __launch_bounds__(kBlock, (MODE == kTraj || MODE == kSteps) ? (tab_gl
                                      : MODE == kRollout ? (tab_global(TAB) ? 4 : 5)
                                      : (tab_medium(TAB) && MODE == kRollout1) ? JSS_PACKED_MEDIUM_MIN_BLOCKS
                                      : ((tab_global(TAB) && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
-void jss_packed_kernel(Params p_arg) {
+void jss_packed_kernel(Params p) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
-    JSS_PARAMS_IN_PLACE(p, p_arg);
+    // (by value on purpose: these kernels fit their SGPR budget, and with every argument loaded up front -- behind the state
+    //  loads -- no scalar load waits in the middle of the dependent chain: JSS_PARAMS_OF in jss_common.hpp)
     packed_block<G, MODE, TAB>(p, (int)blockIdx.x, lds);
 }
 
@@ -1146,7 +1157,7 @@ __device__ __forceinline__ PRaw<G> p_unpark(const int4 *park, int slot, int lane
 template <int G, int TAB>
 __global__ __launch_bounds__(kBlock, 6) void jss_packed_session_kernel(Params p_arg) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
-    JSS_PARAMS_IN_PLACE(p, p_arg);
+    JSS_PARAMS_OF(p, p_arg, false);
     constexpr int E = kWave / G;
     constexpr int MODE = kSession;
     const int lane = threadIdx.x & (kWave - 1);

@@ -473,7 +473,8 @@ __device__ __forceinline__ int nth_set_bit(uint64_t mask, int n, int lane) {
     return __ffsll((unsigned long long)hit) - 1;
 }
 
-template <int JPL>
+// F64: the instantiation also carries JSS_POLICY_CR_F64's float64 selector (the policy kernels only)
+template <int JPL, bool F64 = false>
 __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, const Params &p, uint64_t env_id,
                                              uint32_t episode, uint32_t step) {
     const int kind = p.kind & 0xFF;
@@ -502,7 +503,22 @@ __device__ __forceinline__ int select_action(const Env<JPL> &e, const Ctx &c, co
     int a = -1;
     // remaining-work table of my env: rem[j][k] = durations of ops k..M-1 of job j (MWR / LWR / CR)
     const int32_t *rem = p.d.rem + (size_t)c.tid * p.region_ints;
-    if (kind == JSS_POLICY_CR) {                                         // dispatching.py:365-408
+    if (F64 && kind == JSS_POLICY_CR && ((p.kind >> 24) & 1)) {
+        CrKeyF best;
+        best.ratio = kCrInf;
+        best.idx = kCrNone;
+#pragma unroll
+        for (int s = 0; s < JPL; ++s) {
+            const int j = s * kWave + c.lane;
+            const bool lg = (e.legal[s] >> c.lane) & 1;
+            CrKeyF key;
+            key.ratio = lg ? cr_ratio_f64(rem[j * c.stride], p.d.cr_factor, e.t, rem[j * c.stride + e.todo[s]]) : kCrInf;
+            key.idx = lg ? j : kCrNone;
+            if (cr_better_f64(key, best)) best = key;
+        }
+        best = cr_argmin_f64<kWave>(best);
+        a = __builtin_amdgcn_readfirstlane(best.idx);
+    } else if (kind == JSS_POLICY_CR) {                                  // dispatching.py:365-408
         CrKey best;
         best.num = 0x3fffffff;
         best.den = 1;
@@ -1011,7 +1027,7 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
         else hole = advance(e, c);
         if (lane == 0 && p.hole) p.hole[b] = hole;
     } else if (MODE == kPolicy) {
-        const int a = select_action(e, c, p, (uint64_t)(p.d.env_ids ? p.d.env_ids[b] : p.d.env_id_base + b),
+        const int a = select_action<JPL, true>(e, c, p, (uint64_t)(p.d.env_ids ? p.d.env_ids[b] : p.d.env_id_base + b),
                                     (uint32_t)hd.episode, (uint32_t)hd.step);
         if (lane == 0) p.actions_out[b] = a;
         return;
@@ -1098,7 +1114,7 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
 constexpr int wave_min_blocks(int jpl, int mode) {
     return mode == kTraj ? (jpl == 2 ? JSS_TRAJ2_MIN_BLOCKS : JSS_TRAJ1_MIN_BLOCKS)
          : mode == kRollout ? (jpl == 2 ? 5 : 7)
-         : mode == kStep ? (jpl == 2 ? 6 : 8)
+         : mode == kStep ? (jpl == 2 ? 5 : 8)
          : mode == kSteps ? (jpl == 2 ? 4 : 6)
          : mode == kRollout1 ? (jpl == 2 ? JSS_WAVE2_MIN_BLOCKS : JSS_WAVE_MIN_BLOCKS)
          : (jpl == 2 ? 7 : 8);
@@ -1157,7 +1173,7 @@ __device__ __forceinline__ void wave_block(const Params &p, int block, int32_t *
 template <int JPL, int MODE, int TAB>
 __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel(Params p_arg) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
-    JSS_PARAMS_IN_PLACE(p, p_arg);
+    JSS_PARAMS_OF(p, p_arg, false);      // by value: measured faster than in place although it spills SGPRs (jss_common.hpp)
     wave_block<JPL, MODE, TAB>(p, (int)blockIdx.x, lds);
 }
 
@@ -1211,7 +1227,7 @@ __device__ __forceinline__ RawEnv<JPL> unpark_env(const int4 *park, int slot, in
 template <int JPL, int TAB>
 __global__ __launch_bounds__(kBlock, JPL == 1 ? 6 : 4) void jss_session_kernel(Params p_arg) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
-    JSS_PARAMS_IN_PLACE(p, p_arg);
+    JSS_PARAMS_OF(p, p_arg, false);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;

@@ -176,7 +176,9 @@ class LeastOperationsRemaining(DispatchingRule):                          # disp
 class CriticalRatio(DispatchingRule):                                     # dispatching.py:327-408
     """(due date - now) / remaining work, smallest first; due date = factor x job length, cached
     per job and dropped when ``current_time_step == 0`` (:373-374).  On a jssenv_amd env the arg-min runs on
-    the device as an exact fraction comparison (csrc ``cr_better``); the float path below serves other envs."""
+    the device -- as an exact fraction comparison (csrc ``cr_better``) for factors p / 2^k, as the reference's float64
+    expression (``cr_ratio_f64``) for any other: ``BatchedJssEnv.policy("CR", cr_factor=f)``; the float path below
+    serves other envs."""
 
     kind, larger_wins = "CR", False
 
@@ -193,13 +195,14 @@ class CriticalRatio(DispatchingRule):                                     # disp
 
     def _best_job(self, env, legal_actions) -> int:
         # on a jssenv_amd env the arg-min comes from the host snapshot of the step (the reference's float expression,
-        # vectorised) or from the device selector, which compares (p * job_length - q * now) / remaining exactly for
-        # factors p / q with q a power of two; any other factor takes the loop below
+        # vectorised) or from the device selectors: (p * job_length - q * now) / remaining compared exactly for factors
+        # p / q with q a power of two (these also run inside the fused rollouts), the reference's float64 expression
+        # itself for any other factor (JSS_POLICY_CR_F64, policy launches only); other envs take the loop below
         if hasattr(env, "_rule_best"):
             return env._rule_best("CR", legal_actions, due_date_factor=self.due_date_factor)
-        code = device_kind(self)
-        if code is not None and hasattr(env, "_policy"):
-            a = env._policy(code)
+        if hasattr(env, "_policy"):
+            code = device_kind(self)          # p / 2^k factors: the integer-exact selector; any other: the float64 one
+            a = env._policy(code) if code is not None else env._policy("CR", cr_factor=self.due_date_factor)
             return a if a < env.jobs else -1
         saved, self.kind = self.kind, None
         try:

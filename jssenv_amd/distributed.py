@@ -21,6 +21,18 @@ def shard_bounds(global_batch: int, world_size: int, rank: int) -> Tuple[int, in
     return start, start + base + (1 if rank < extra else 0)
 
 
+def select_device(local_rank: int, world_size: int, device_count: int, share_device: bool = False) -> int:
+    """The GPU index rank `local_rank` of a one-node job drives: its own (one process per GPU, no oversubscription) -- an error
+    when the node exposes fewer devices than ranks, unless ``share_device`` (debug: every rank on device 0)."""
+    if not 0 <= local_rank < max(1, world_size):
+        raise ValueError(f"local rank {local_rank} outside a job of {world_size} rank(s)")
+    if share_device:
+        return 0
+    if device_count < world_size:
+        raise RuntimeError(f"{world_size} ranks but only {device_count} GPU(s) visible: one process per GPU, no oversubscription")
+    return local_rank
+
+
 def init_from_env(backend: Optional[str] = None, force: bool = False):
     """Initialise torch.distributed from the torchrun environment (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_*).
     Returns (rank, world_size, local_rank).  No-op for a single process unless ``force`` (a world of one rank still
@@ -37,8 +49,9 @@ def init_from_env(backend: Optional[str] = None, force: bool = False):
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
         kwargs = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            kwargs["device_id"] = torch.device("cuda", local_rank)
+            dev = select_device(local_rank, world, torch.cuda.device_count())
+            torch.cuda.set_device(dev)
+            kwargs["device_id"] = torch.device("cuda", dev)
         dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local_rank
 

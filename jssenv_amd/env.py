@@ -431,7 +431,7 @@ class BatchedJssEnv:
         p = be.ptr
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._rem), p(self._inst), p(self._table_of_env), None,
                                   self.env_id_base, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)),
-                                  int(pk.jobs.min()), self.record_ints)
+                                  int(pk.jobs.min()), self.record_ints, 0.0)
         self._state = _abi.JssState(p(self.env_header), p(self.env_const), p(self.job_state),
                                     None if self.no_clocks else p(self.machine_state), p(self.solution),
                                     p(self.counters))
@@ -551,13 +551,22 @@ class BatchedJssEnv:
             _abi.check(be.lib, be.lib.jss_advance(d, s, be.ptr(w), be.ptr(self._hole), o, be.stream()), "jss_advance")
         return self._hole
 
-    def policy(self, kind: Union[str, int] = "random", seed: Optional[int] = None, explore: float = 0.0):
+    def policy(self, kind: Union[str, int] = "random", seed: Optional[int] = None, explore: float = 0.0,
+               cr_factor: Optional[float] = None):
         """Per-env action from the on-device selectors (random masked, FIFO, SPT, MWR, LWR, MOR, LOR, CR).
-        Returns the env's own (B,) int32 action buffer (overwritten by the next policy() call)."""
+        Returns the env's own (B,) int32 action buffer (overwritten by the next policy() call).
+        ``cr_factor``: CriticalRatio(due_date_factor=...) with ANY positive float (dispatching.py:337-360) -- the selector then
+        evaluates the reference's float64 expression itself (JSS_POLICY_CR_F64); without it "CR" is the default 1.5, and
+        ``_abi.cr_kind(f)`` codes the factors p / 2^k that also run inside the fused rollouts."""
         if not self._is_reset:
             raise RuntimeError("call reset() before policy()")
         be = self.backend
         k = _abi.policy_code(kind)
+        if cr_factor is not None:
+            if (k & 0xFF) != _abi.POLICY["CR"] or not 0.0 < float(cr_factor) < 1e300:
+                raise ValueError("cr_factor is CriticalRatio's due-date factor: a positive float, with kind 'CR'")
+            k = _abi.POLICY_CR_F64
+            self._desc.cr_factor = float(cr_factor)
         d, s, _ = self._refs()
         with be.on_device():
             _abi.check(be.lib, be.lib.jss_policy(d, s, k, self.seed if seed is None else int(seed),
@@ -1396,8 +1405,8 @@ class JssEnv(gymnasium_base("Env")):
         return int(np.argmax(key))           # first maximum = lowest index among ties
 
     # on-device action selectors for the dispatching module
-    def _policy(self, kind):
-        return int(self._b.backend.numpy(self._b.policy(kind))[0])
+    def _policy(self, kind, cr_factor=None):
+        return int(self._b.backend.numpy(self._b.policy(kind, cr_factor=cr_factor))[0])
 
 
 def make(env_id: str = "jss-v1", env_config=None, **kwargs):

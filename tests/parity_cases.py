@@ -514,7 +514,8 @@ def case_bucketed_equals_padded(backend, n_envs=24, n_iter=260, seed=13):
     padded.rollout("random", n_iter=n_iter)
     bucketed.rollout("random", n_iter=n_iter)
     padded.rollout_steps("random", steps=7, n_sub=2)        # the step-per-launch forms on top: sub-batches / ONE grid over the classes
-    bucketed.rollout_steps("random", steps=7)               # 7 launches of jss_multi_rollout's fused grid
+    bucketed.rollout_steps("random", steps=4)               # 4 launches of jss_multi_rollout's fused grid
+    bucketed.rollout_steps("random", steps=3, n_sub=3)      # and 3 steps with every class cut in three parts, a grid per part
     n_iter += 7
     # the un-fused calls, each one launch over all classes: policy -> actions per class -> step (with next-step auto-reset)
     for _ in range(5):
@@ -1137,7 +1138,8 @@ def case_bucketed_every_env_vs_oracle(backend, n_envs=32768, iters=160, seed=6, 
     env = BucketedJssEnv(insts, batch=n_envs, seed=seed, env_id_base=env_id_base, launch=launch, _backend=backend)
     assert sum(b.batch for _, b in env._each()) == n_envs and len(env._each()) == 4
     env.reset()
-    env.rollout_steps(kind, steps=iters)
+    env.rollout_steps(kind, steps=iters // 2)
+    env.rollout_steps(kind, steps=iters - iters // 2, n_sub=2)          # the pipelined form: two parts per class, a grid per part
     for _ in range(unfused_tail):
         env.step(env.policy(kind), autoreset=True)
     env.synchronize()
@@ -1427,6 +1429,62 @@ def case_session_emulator(backend, kw=None, K=14, kind="random", seed=5, warm=20
     for name in want:
         assert np.array_equal(got[name], want[name]), f"session (emulator, slots {status[3]}): {name} differs from {K} x jss_step"
     return status
+
+
+def case_cr_any_factor(backend, factors=(1.2, 1.3, 0.7, 1.0 / 3.0, 2.718281828459045), insts=("ta01", "ta31"), batch=5, steps=150, seed=9):
+    """CriticalRatio(due_date_factor = any float) on the device: `policy("CR", cr_factor=f)` (JSS_POLICY_CR_F64: the
+    reference's float64 expression evaluated by the selector) picks, state by state, the job the reference's rule picks
+    (dispatching.py:365-408, the package's rule class running its host loop on the oracle env) -- on a ragged batch, so
+    both kernel flavours' selectors are exercised.  The fused rollouts refuse the code (their kernels carry no float64)."""
+    from jssenv_amd import dispatching as D
+    assert _abi.cr_kind(1.2) is None and _abi.POLICY_CR_F64 == _abi.POLICY["CR"] | (1 << 24)
+    real = np.random.random
+    np.random.random = lambda *a, **k: 1.0               # no NOPE exploration on the host side
+    try:
+        instances = [I.builtin_instance(n) for n in insts]
+        for factor in factors:
+            env = BatchedJssEnv(instances, batch=batch, seed=seed, _backend=backend)
+            orcs = [OracleEnv(instances[i % len(instances)], strict=True) for i in range(batch)]
+            rules = [D.CriticalRatio(due_date_factor=factor) for _ in range(batch)]
+            env.reset()
+            for o in orcs:
+                o.reset()
+            rng = np.random.default_rng(seed)
+            for st in range(steps):
+                dev = np.asarray(env.backend.numpy(env.policy("CR", cr_factor=factor)))
+                acts = []
+                for i, o in enumerate(orcs):
+                    if o.nb_legal_actions == 0:
+                        acts.append(_abi.ACTION_SKIP)
+                        continue
+                    want = rules[i](o)
+                    assert dev[i] == want, f"factor {factor} step {st} env {i}: device {dev[i]} vs reference rule {want}"
+                    if st % 4 == i % 4:                  # every few steps another legal action, so that the envs drift apart
+                        want = int(rng.choice(np.flatnonzero(o.legal_actions)))
+                    o.step(want)
+                    acts.append(want)
+                env.step(np.asarray(acts, dtype=np.int32))
+        # the code is for policy launches: the fused rollouts answer JSS_E_KIND, a factor that is not a positive float is refused
+        be = env.backend
+        d, s_, o_ = env._refs()
+        env._desc.cr_factor = 1.2
+        assert be.lib.jss_rollout(d, s_, o_, _abi.POLICY_CR_F64, 0, 0, 1, 0, be.stream()) == _abi.E_KIND
+        env._desc.cr_factor = -1.0
+        assert be.lib.jss_policy(d, s_, _abi.POLICY_CR_F64, 0, 0, be.ptr(env._actions_out), be.stream()) == _abi.E_KIND
+        env._desc.cr_factor = 0.0
+        for bad in (0.0, -2.0, float("nan")):
+            try:
+                env.policy("CR", cr_factor=bad)
+                raise AssertionError("a non-positive due-date factor must be refused")
+            except ValueError:
+                pass
+        try:
+            env.policy("SPT", cr_factor=1.2)
+            raise AssertionError("cr_factor belongs to CR")
+        except ValueError:
+            pass
+    finally:
+        np.random.random = real
 
 
 def case_cr_due_date_factor(backend, factors=(2.0, 0.5, 1.25), inst="ta01", batch=6, steps=260, seed=4):

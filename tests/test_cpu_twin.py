@@ -249,6 +249,10 @@ def test_steps_and_step_session(cpu):
     P.case_session(cpu, dict(instances=["ta02", "ta51"], batch=7), K=20, kind="FIFO")
 
 
+def test_critical_ratio_any_due_date_factor_on_device(cpu):
+    P.case_cr_any_factor(cpu)
+
+
 def test_critical_ratio_due_date_factor_on_device(cpu):
     P.case_cr_due_date_factor(cpu)
 

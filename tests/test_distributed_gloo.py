@@ -92,6 +92,35 @@ def test_shard_bounds():
         shard_bounds(4, 2, 2)
 
 
+def test_each_rank_selects_its_own_gpu():
+    """Rank r of an N-GPU node drives device r (what only a real multi-GPU run executes with r > 0), fewer devices than
+    ranks is an error, --share-device puts everybody on device 0 -- and init_from_env("nccl") hands exactly that device to
+    torch.cuda.set_device and to the process group (torch mocked: no GPU, no rendezvous)."""
+    from unittest import mock
+    from jssenv_amd import distributed as D
+    assert [D.select_device(r, 8, 8) for r in range(8)] == list(range(8))
+    assert [D.select_device(r, 4, 8) for r in range(4)] == [0, 1, 2, 3]          # 4 ranks on an 8-GPU node
+    assert [D.select_device(r, 8, 1, share_device=True) for r in range(8)] == [0] * 8
+    with pytest.raises(RuntimeError, match="no oversubscription"):
+        D.select_device(3, 8, 4)
+    with pytest.raises(ValueError):
+        D.select_device(8, 8, 8)
+    for r in (0, 5, 7):
+        env = dict(RANK=str(r), WORLD_SIZE="8", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+        with mock.patch.dict(os.environ, env), mock.patch("torch.cuda.device_count", return_value=8), \
+                mock.patch("torch.cuda.set_device") as set_device, mock.patch("torch.distributed.is_initialized", return_value=False), \
+                mock.patch("torch.distributed.init_process_group") as init_pg:
+            assert D.init_from_env("nccl") == (r, 8, r)
+        set_device.assert_called_once_with(r)
+        (backend,), kw = init_pg.call_args
+        assert backend == "nccl" and kw["rank"] == r and kw["world_size"] == 8 and kw["device_id"] == torch.device("cuda", r)
+    with mock.patch.dict(os.environ, dict(RANK="6", WORLD_SIZE="8", LOCAL_RANK="6")), mock.patch("torch.cuda.device_count", return_value=4), \
+            mock.patch("torch.distributed.is_initialized", return_value=False), mock.patch("torch.distributed.init_process_group") as init_pg:
+        with pytest.raises(RuntimeError, match="8 ranks but only 4"):
+            D.init_from_env("nccl")
+        init_pg.assert_not_called()
+
+
 def test_two_ranks_equal_one_process_cpu_twin():
     """CPU (this container): the two ranks step their shards with libjss_cpu.so."""
     assert _two_ranks_equal_one_process("cpu", global_batch=37, iters=400).startswith("cpu")
@@ -151,6 +180,17 @@ def test_bench_eight_ranks_on_one_gpu():
     assert c4.get("value"), c4
     assert c4["global_batch"] == 65536 and c4["batch"] == 8192 and c4["n_gpus"] == 8 and c4["scaling"] == "strong"
     assert out["configs"]["c4_syn50x20_b65536_sharded"] == pytest.approx(c4["roofline_frac"], rel=1e-3)
+    # Preflight of the real 8-GPU run, host side: 8 ranks issuing at once under this box's CPU quota (every rank's runtime
+    # polls its completion signals, HSA_ENABLE_INTERRUPT=0) must still put a launch into its queue far faster than a GPU of
+    # its own would retire it -- the headline's kernels take >= 13 us per step of 2-3 launches (one rank alone: ~2.7 us per launch).
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--batch", "4096",
+                          "--no-cpu-baseline", "--no-extras", "--detail", detail + ".1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    alone = json.load(open(detail + ".1"))["host_issue_us_per_launch"]
+    crowded = full["host_issue_us_per_launch"]                               # MAX over the 8 ranks
+    assert 0 < alone < 6.0 and 0 < crowded < 6.5, (alone, crowded)
+    assert crowded < 3.0 * alone + 1.0, (alone, crowded)
+    assert full["host"]["hsa_enable_interrupt"] == "0" and out["host_issue_us_per_launch"] == pytest.approx(crowded, rel=0.01)
 
 
 _RCCL_WORLD1 = r'''

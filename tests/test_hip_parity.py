@@ -366,6 +366,10 @@ def test_step_session_gives_up_instead_of_hanging(hip_auto):
         assert np.array_equal(before[name], after[name]), name
 
 
+def test_critical_ratio_any_due_date_factor_on_device(hip):
+    P.case_cr_any_factor(hip)
+
+
 def test_critical_ratio_due_date_factor_on_device(hip):
     P.case_cr_due_date_factor(hip)
 

@@ -158,6 +158,10 @@ def test_step_session_times_out_instead_of_hanging(emu):
     P.case_session_emulator(emu, dict(instances="ta01", batch=9), K=3, timeout_only=True)
 
 
+def test_critical_ratio_any_due_date_factor_on_device(emu):
+    P.case_cr_any_factor(emu, factors=(1.2, 0.7), steps=50, batch=3)
+
+
 def test_critical_ratio_due_date_factor_on_device(emu):
     P.case_cr_due_date_factor(emu, steps=60, batch=3, factors=(2.0, 0.5))
 

@@ -22,6 +22,10 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, int n) {
         if (K == 6) { R4(asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh * 4));) }
         if (K == 7) { R4(asm volatile("s_add_u32 s20, s20, 1\n s_and_b32 s21, s21, s20\n s_add_u32 s22, s22, 1\n s_and_b32 s23, s23, s22\n s_add_u32 s24, s24, 1\n s_and_b32 s25, s25, s24\n s_add_u32 s26, s26, 1\n s_and_b32 s27, s27, s26" : : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc");) }
         if (K == 8) { R4(asm volatile("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 5\n v_readlane_b32 s22, %2, 7\n v_readlane_b32 s23, %3, 9\n v_readlane_b32 s24, %4, 11\n v_readlane_b32 s25, %5, 13\n v_readlane_b32 s26, %6, 15\n v_readlane_b32 s27, %7, 17" : : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");) }
+        // mixed streams in ONE wave: do the scalar and the vector unit overlap, or does a SIMD issue one instruction at a time?
+        if (K == 9) { R4(asm volatile("v_lshlrev_b32 %0, %8, %0\n s_add_u32 s20, s20, 1\n v_lshlrev_b32 %1, %8, %1\n s_and_b32 s21, s21, s20\n v_lshlrev_b32 %2, %8, %2\n s_add_u32 s22, s22, 1\n v_lshlrev_b32 %3, %8, %3\n s_and_b32 s23, s23, s22" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh) : "s20", "s21", "s22", "s23", "scc");) }
+        if (K == 10) { R4(asm volatile("v_lshlrev_b32 %0, %8, %0\n v_lshlrev_b32 %1, %8, %1\n v_lshlrev_b32 %2, %8, %2\n v_lshlrev_b32 %3, %8, %3\n s_add_u32 s20, s20, 1\n s_and_b32 s21, s21, s20\n s_add_u32 s22, s22, 1\n s_and_b32 s23, s23, s22" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh) : "s20", "s21", "s22", "s23", "scc");) }
+        if (K == 11) { R4(asm volatile("v_and_b32 %0, %8, %0\n v_or_b32 %1, %8, %1\n v_xor_b32 %2, %8, %2\n v_sub_u32 %3, %8, %3\n v_max_i32 %4, %8, %4\n v_min_i32 %5, %8, %5\n v_bfe_u32 %6, %6, %8, 5\n v_lshl_add_u32 %7, %7, 1, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh));) }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     const unsigned long long w1 = wall_clock64();
@@ -58,5 +62,6 @@ int main() {
     run<0>("v_add_u32", d, n_cu); run<1>("v_lshlrev_b32", d, n_cu); run<2>("v_cndmask_b32", d, n_cu); run<3>("v_min_i32_dpp", d, n_cu);
     run<4>("v_cmp_lt_u32", d, n_cu); run<5>("v_cvt_f32_i32+v_fma_f32", d, n_cu); run<6>("ds_bpermute_b32", d, n_cu); run<7>("s_add/s_and", d, n_cu);
     run<8>("v_readlane_b32", d, n_cu);
+    run<9>("v_lshl / s_op alternating", d, n_cu); run<10>("4 v_lshl then 4 s_op", d, n_cu); run<11>("and/or/xor/sub/max/min/bfe/lshl_add", d, n_cu);
     return 0;
 }
