@@ -795,7 +795,7 @@ def main():
             med_b, rows_b = measure(env, policy, args.steps, ranking[1][0])
             if agree_max([med_b["rate"] - med["rate"]])[0] > 0:
                 mode, med, rows = ranking[1][0], med_b, rows_b
-        rf = roofline(med, alg, args.steps, env, None if bucketed else key, batch)
+        rf = roofline(med, alg, args.steps, env, ("mixed_bucketed" if env.launch == "grid" else None) if bucketed else key, batch)
         out = {"workload": label + label_extra, "batch": batch, "policy": policy, "value": med["rate"],
                "min": rows[0]["rate"], "max": rows[-1]["rate"], "windows": len(rows), "unit": "env steps/s",
                "ms_per_step": med["seconds"] / args.steps * 1e3, "roofline_frac_gpu_time": rf["frac_gpu_time"],
@@ -871,7 +871,8 @@ def main():
                                f"full obs/mask/reward/done written every step, auto-restart",
                    "batch_per_gpu": B, "global_batch": args.batch * world if args.scaling == "weak" else args.batch,
                    "parallelism": f"env-shard x{world}", "policy": args.policy},
-        "roofline": roofline(med, alg_per_step, args.steps, env, None if hasattr(env, "buckets") else key, B),
+        "roofline": roofline(med, alg_per_step, args.steps, env,
+                             ("mixed_bucketed" if env.launch == "grid" else None) if hasattr(env, "buckets") else key, B),
         "host_issue_us_per_launch": host_issue_us,
         "episodes_finished": med["episodes"],
         "mean_makespan": med["makespan_sum"] / med["episodes"] if med["episodes"] else None,
