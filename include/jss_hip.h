@@ -468,6 +468,10 @@ int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssStat
 #define JSS_ABLATE_SELECT 8
 #define JSS_ABLATE_ADVANCE 16
 int jss_profiling_set(int option, int value);
+/* device buffer [B][16] uint64 (NULL = off): lane 0 of every wavefront of the one-wavefront-per-env kernels records the shader
+ * clock at its phase boundaries (slot 0 entry, 1 header words there, 2 state unpacked, 3 action selected, 7 / 8 / 9 inside step():
+ * after the allocation + event jump, _prioritization_non_final, _check_no_op, 4 step done, 5 state / mask stores issued, 6 end) */
+int jss_profiling_stamps(void *device_buffer);
 #endif
 
 #ifdef __cplusplus

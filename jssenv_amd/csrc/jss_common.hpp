@@ -96,6 +96,9 @@ struct Params {
     int32_t slots;                    // env sets per wavefront (1, 2, 4, 8)
     int32_t park_off_ints;            // LDS offset (ints) of the parked env sets: [wave][slot][kParkInt4][64 lanes] int4
     int32_t norm_slot_ints;           // packed kernel, kTabGlobal: ints between two slots' normaliser tables
+#ifdef JSS_PROFILING
+    unsigned long long *stamps;       // instrumented builds: [B][16] shader-clock stamps of the one-wavefront-per-env kernels (JSS_STAMP)
+#endif
 };
 
 // Where a kernel reads its Params from.  They arrive by value (the kernel-argument segment); handed on by reference, a
@@ -109,8 +112,11 @@ struct Params {
 // every wave waits for anyway, while an in-place load waits in the middle of the dependent chain.  Same-box A/B, round 5
 // (profiles/r05_misc/ab_params_in_place.txt): config 5 padded rollout +-0 %, its jss_step -3 %, config 4's share -2 %,
 // config 3's packed kernel -10 %, headline +-0.  A spilled SGPR is two VALU-lane moves among ~800 instructions; the wait
-// is what costs.  So the kernels keep the by-value form (in_place = false everywhere); only the fused multi-set grid
-// (jss_multi_kernel), whose workgroups pick one of several Params at run time, reads in place by construction.
+// is what costs.  So the one-step kernels keep the by-value form.  The exception is the one-wavefront-per-env RECORDER
+// (kTraj): by value it holds so much that 14-29 VGPRs live in scratch memory, and there reading in place wins -- trajectory
+// mode +6.5 % on config 4's share, +10 % on config 5 padded (profiles/r05_misc/ab_params_in_place.txt), +-0 on the packed
+// flavour, which stays by value.  The fused multi-set grid (jss_multi_kernel) copies its set's Params up front for the
+// same reason the one-step kernels take them by value (+3 % over in place).
 // The explicit arguments start at offset 0 of the segment.  (Host pass and the test emulator: the argument itself.
 // -DJSS_PARAMS_ALL_IN_PLACE: A/B builds.)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(JSS_PARAMS_BY_VALUE)
@@ -123,6 +129,21 @@ struct Params {
 #endif
 #else
 #define JSS_PARAMS_OF(p, arg, in_place) const Params &p = (arg)
+#endif
+
+// Instrumented builds: JSS_STAMP(p, env, k, dep) = lane 0 of env's wavefront records the shader clock in slot k once `dep` (a
+// value the phase before it produced) is available -- a phase timeline of the wave's life (tools/gpu_wave_timeline.py).
+#if defined(JSS_PROFILING) && defined(__HIP_DEVICE_COMPILE__)
+#define JSS_STAMP(p, env, k, dep)                                                                  \
+    do {                                                                                           \
+        if ((p).stamps) {                                                                          \
+            unsigned long long jss_t_;                                                             \
+            asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(jss_t_) : "v"(dep) : "memory"); \
+            if ((threadIdx.x & 63) == 0) (p).stamps[(size_t)(env) * 16 + (k)] = jss_t_;            \
+        }                                                                                          \
+    } while (0)
+#else
+#define JSS_STAMP(p, env, k, dep) do {} while (0)
 #endif
 
 #ifdef JSS_PROFILING

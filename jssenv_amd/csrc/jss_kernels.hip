@@ -99,6 +99,7 @@ int join_streams(const ForkJoinEvents &ev, void *const *streams, int n) {
 #ifdef JSS_PROFILING
 int g_ablate = 0;
 int g_lds_pad = 0;
+unsigned long long *g_stamps = nullptr;
 #endif
 
 // Kernel flavour for a batch shape: the packed kernel needs every env's jobs AND machines to fit
@@ -156,6 +157,7 @@ int plan(Params &p, LaunchPlan &lp) {
     }
 #ifdef JSS_PROFILING
     p.ablate = g_ablate;
+    p.stamps = g_stamps;
     lp.shmem += g_lds_pad;
 #endif
     if (lp.shmem > kMaxDynamicLds) return JSS_E_LDS;
@@ -368,10 +370,13 @@ __global__ __launch_bounds__(kBlock, multi_min_blocks(MODE)) void jss_multi_kern
     for (int i = 0; i + 1 < kMultiMaxSets; ++i)
         if (i + 1 < mp.n_sets && blk >= mp.block_end[i]) k = i + 1;
     const int block = blk - (k ? mp.block_end[k - 1] : 0);
-#ifdef JSS_MULTI_PARAMS_COPY          // A/B builds: the set's Params copied up front (every field loaded in the entry block)
-    const Params p = mp.p[k];
-#else
+    // The set's Params copied up front -- every field loaded in the entry block, behind the state loads, like a kernel that
+    // takes them by value -- rather than read in place at their uses (-DJSS_MULTI_PARAMS_IN_PLACE: no spilled SGPRs instead of
+    // 30, and 3 % slower: profiles/r05_misc/bucketed_grid_vs_streams.txt; the same trade as JSS_PARAMS_OF in jss_common.hpp)
+#ifdef JSS_MULTI_PARAMS_IN_PLACE
     const Params &p = mp.p[k];
+#else
+    const Params p = mp.p[k];
 #endif
     switch (mp.flavour[k]) {
     case kMfW2G: wave_block<2, MODE, kTabGlobal, false>(p, block, lds); break;   // (one body: 66 VGPRs, no spills at 7 waves / SIMD)
@@ -494,6 +499,10 @@ int jss_profiling_set(int option, int value) {
         return 0;
     }
     return JSS_E_KIND;
+}
+int jss_profiling_stamps(void *device_buffer) {      // [B][16] uint64 (NULL: off)
+    g_stamps = static_cast<unsigned long long *>(device_buffer);
+    return 0;
 }
 #endif
 

@@ -458,8 +458,11 @@ __device__ __forceinline__ int step_env(Env<JPL> &e, const Ctx &c, const Params 
         }
         if (!any_legal(e) && !JSS_ABLATED(p, JSS_ABLATE_ADVANCE)) jump(e, c, false, rn);   // :469-470 in one jump
     }
+    JSS_STAMP(p, c.b, 7, e.left[0] + e.t);
     if (!JSS_ABLATED(p, JSS_ABLATE_PRIORITIZE)) prioritize(e, c);        // :432 / :471
+    JSS_STAMP(p, c.b, 8, (int)e.legal[0]);
     if (!JSS_ABLATED(p, JSS_ABLATE_CHECK_NO_OP)) check_no_op(e, c);      // :433 / :472
+    JSS_STAMP(p, c.b, 9, e.noop);
     settle(e);                                                           // the refill jump() requested has had the rest of the step to land
     return rn;
 }
@@ -999,8 +1002,10 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
             hd.episode = in_vgpr(hd.episode);                            // store at the very end reads them -- out of the scalar
             hd.step = in_vgpr(hd.step);                                  // register file, which these kernels run out of
         }
+        JSS_STAMP(p, b, 1, c.J);
         unpack_env<JPL, TAB>(e, c, raw, __builtin_amdgcn_readfirstlane(h.clock), __builtin_amdgcn_readfirstlane(h.status),
                              reinterpret_cast<int32_t *>(scratch));
+        JSS_STAMP(p, b, 2, e.left[0] + e.idle[0] + e.tm);
     }
 
     if (MODE == kStep) {                                                 // (JSS_ACTION_RESET never gets here: jss_kernel)
@@ -1060,7 +1065,9 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
                 continue;
             }
             const int a = select_action(e, c, p, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
+            JSS_STAMP(p, b, 3, a);
             last_rn = step_env(e, c, p, a);
+            JSS_STAMP(p, b, 4, last_rn + e.fill[0]);
             hd.step += 1;
             n_steps += 1;
             sum_rn += last_rn;
@@ -1085,8 +1092,10 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
     }
     store_env<JPL, TAB>(e, c, p, hd, raw, fresh);
     store_mask(e, c, p.o.action_mask + (size_t)b * (p.d.jmax + 1), p.d.jmax);
+    JSS_STAMP(p, b, 5, e.t);
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
         store_obs(e, c, p.o.real_obs + (size_t)b * p.d.jmax * 7, scratch, fresh ? p.d.jmax : c.J);
+    JSS_STAMP(p, b, 6, e.t);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1135,6 +1144,7 @@ __device__ __forceinline__ void wave_block(const Params &p, int block, int32_t *
     Ctx c;
     c.b = b;
     c.lane = lane;
+    JSS_STAMP(p, b, 0, lane);
     const HeaderWords h = load_header(p, b);
     int a_in = JSS_ACTION_SKIP;
     if (MODE == kStep) {
@@ -1173,7 +1183,9 @@ __device__ __forceinline__ void wave_block(const Params &p, int block, int32_t *
 template <int JPL, int MODE, int TAB>
 __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel(Params p_arg) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
-    JSS_PARAMS_OF(p, p_arg, false);      // by value: measured faster than in place although it spills SGPRs (jss_common.hpp)
+    // by value where a launch is one step: measured faster than in place although it spills SGPRs; in place for the recorder,
+    // whose by-value form runs on scratch (jss_common.hpp: +6 % / +10 % on config 4's share / config 5 in trajectory mode)
+    JSS_PARAMS_OF(p, p_arg, MODE == kTraj);
     wave_block<JPL, MODE, TAB>(p, (int)blockIdx.x, lds);
 }
 
