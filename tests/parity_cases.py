@@ -1127,6 +1127,60 @@ def assert_batch_equals_oracle(env, kind, seed, iters, label, explore=0.0, autor
     return want
 
 
+def case_multi_entry_points(backend, steps=40):
+    """jss_multi_reset / policy / step / rollout over env sets the caller picked himself: (a) sets that all have a body in
+    the fused grid, (b) a mix with a shared-instance set (LDS-staged table: no body in the grid -> one plain launch per set
+    on the same stream) -- both bit-identical to the single-set calls on twin objects; argument errors."""
+    import ctypes as C
+    be = backend
+    D, S, O = C.POINTER(_abi.JssDesc), C.POINTER(_abi.JssState), C.POINTER(_abi.JssOut)
+    P = C.c_void_p
+    groups = {"fused grid": [dict(instances=["ta01", "ta02", "ta03"], batch=9), dict(instances=["ta21", "ta31"], batch=5),
+                             dict(instances=["ta51", "ta61"], batch=3), dict(instances=["ta71", "ta72"], batch=2)],
+              "fallback": [dict(instances="ta01", batch=6), dict(instances=["ta11", "ta12"], batch=4), dict(instances="ta51", batch=2)]}
+    for what, kws in groups.items():
+        a = [BatchedJssEnv(seed=4, env_id_base=100 * i, _backend=be, **kw) for i, kw in enumerate(kws)]
+        b = [BatchedJssEnv(seed=4, env_id_base=100 * i, _backend=be, **kw) for i, kw in enumerate(kws)]
+        n = len(a)
+        sets = ((D * n)(*[C.pointer(e._desc) for e in a]), (S * n)(*[C.pointer(e._state) for e in a]), (O * n)(*[C.pointer(e._out) for e in a]))
+        streams = (P * 2)(be.stream(), be.stream())
+        assert be.lib.jss_multi_reset(n, *sets, None, be.stream()) == 0
+        for e in a:
+            e._is_reset = True
+        for e in b:
+            e.reset()
+        assert be.lib.jss_multi_rollout(n, *sets, _abi.POLICY["SPT"], 4, 6554, steps, _abi.ROLLOUT_AUTORESET, 1, streams) == 0
+        acts = (P * n)(*[be.ptr(e._actions_out) for e in a])
+        for _ in range(5):
+            assert be.lib.jss_multi_policy(n, sets[0], sets[1], _abi.POLICY["random"], 4, 0, acts, be.stream()) == 0
+            assert be.lib.jss_multi_step(n, sets[0], sets[1], acts, sets[2], _abi.ROLLOUT_AUTORESET, be.stream()) == 0
+        # partial reset: only the sets whose mask says so, only the envs whose byte is set
+        which = [be.as_device(np.arange(e.batch) % 2, "uint8") if i != 1 else None for i, e in enumerate(a)]
+        keep = list(which)                                                   # (alive until the call has read them)
+        assert be.lib.jss_multi_reset(n, *sets, (P * n)(*[be.ptr(w) for w in which]), be.stream()) == 0
+        for i, e in enumerate(b):
+            e.rollout("SPT", n_iter=steps, seed=4, explore=6554 / 65536)
+            for _ in range(5):
+                e.step(e.policy("random", seed=4), autoreset=True)
+            e.reset(which=None if i == 1 else np.arange(e.batch) % 2)
+        for x, y in zip(a, b):
+            x.synchronize()
+            y.synchronize()
+            sx, sy = _state_snapshot(x), _state_snapshot(y)
+            for name in sx:
+                assert np.array_equal(sx[name], sy[name]), f"jss_multi_* ({what}) differs from the single-set calls in {name}"
+        del keep
+    # argument errors
+    assert be.lib.jss_multi_reset(0, *sets, None, be.stream()) == _abi.E_SHAPE and be.lib.jss_multi_reset(17, *sets, None, be.stream()) == _abi.E_SHAPE
+    assert be.lib.jss_multi_reset(n, None, sets[1], sets[2], None, be.stream()) == _abi.E_NULL
+    assert be.lib.jss_multi_step(n, sets[0], sets[1], None, sets[2], 0, be.stream()) == _abi.E_NULL
+    assert be.lib.jss_multi_policy(n, sets[0], sets[1], 99, 0, 0, acts, be.stream()) == _abi.E_KIND
+    assert be.lib.jss_multi_rollout(n, *sets, _abi.POLICY["random"], 0, 0, -1, 0, 1, streams) == _abi.E_SHAPE
+    assert be.lib.jss_multi_rollout(n, *sets, _abi.POLICY["random"], 0, 0, 1, 0, 0, streams) == _abi.E_SHAPE
+    assert be.lib.jss_multi_rollout(n, *sets, _abi.POLICY["random"], 0, 0, 1, 0, 1, None) == _abi.E_NULL
+    assert be.lib.jss_multi_rollout(n, *sets, _abi.POLICY_CR_F64, 0, 0, 1, 0, 1, streams) == _abi.E_KIND
+
+
 def case_bucketed_every_env_vs_oracle(backend, n_envs=32768, iters=160, seed=6, env_id_base=123, launch="grid", kind="random",
                                       unfused_tail=0):
     """BASELINE config 5 without padding, at the benchmarked size: the mixed ta01-ta80 population as shape classes, stepped by

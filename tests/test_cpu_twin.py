@@ -85,6 +85,10 @@ def test_bucketed_and_rollout_steps(cpu):
     P.case_bucketed_equals_padded(cpu, n_envs=48, n_iter=400)
 
 
+def test_multi_entry_points_equal_the_single_set_calls(cpu):
+    P.case_multi_entry_points(cpu)
+
+
 def test_bucketed_every_env_equals_the_oracle(cpu):
     """config 5 without padding through the jss_multi_* entry points, every env of every shape class against the oracle"""
     P.case_bucketed_every_env_vs_oracle(cpu, n_envs=400, iters=260, unfused_tail=7)

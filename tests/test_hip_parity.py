@@ -157,6 +157,10 @@ def test_vector_env_features(hip):
     P.case_vector_env_features(hip)
 
 
+def test_multi_entry_points_equal_the_single_set_calls(hip):
+    P.case_multi_entry_points(hip)
+
+
 def test_bucketed_equals_padded(hip):
     P.case_bucketed_equals_padded(hip, n_envs=400, n_iter=900)
 

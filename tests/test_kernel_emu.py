@@ -92,6 +92,10 @@ def test_bucketed_equals_padded(emu):
     P.case_bucketed_equals_padded(emu, n_envs=24, n_iter=60)
 
 
+def test_multi_entry_points_equal_the_single_set_calls(emu):
+    P.case_multi_entry_points(emu, steps=12)
+
+
 def test_fused_grid_over_the_shape_classes_every_env_equals_the_oracle(emu):
     """jss_multi_kernel<kRollout1 / kPolicy / kStep / kReset>: ta01-ta80 as four shape classes in ONE grid per call"""
     P.case_bucketed_every_env_vs_oracle(emu, n_envs=80, iters=20, unfused_tail=3)
