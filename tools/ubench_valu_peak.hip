@@ -26,6 +26,12 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, int n) {
         if (K == 9) { R4(asm volatile("v_lshlrev_b32 %0, %8, %0\n s_add_u32 s20, s20, 1\n v_lshlrev_b32 %1, %8, %1\n s_and_b32 s21, s21, s20\n v_lshlrev_b32 %2, %8, %2\n s_add_u32 s22, s22, 1\n v_lshlrev_b32 %3, %8, %3\n s_and_b32 s23, s23, s22" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh) : "s20", "s21", "s22", "s23", "scc");) }
         if (K == 10) { R4(asm volatile("v_lshlrev_b32 %0, %8, %0\n v_lshlrev_b32 %1, %8, %1\n v_lshlrev_b32 %2, %8, %2\n v_lshlrev_b32 %3, %8, %3\n s_add_u32 s20, s20, 1\n s_and_b32 s21, s21, s20\n s_add_u32 s22, s22, 1\n s_and_b32 s23, s23, s22" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh) : "s20", "s21", "s22", "s23", "scc");) }
         if (K == 11) { R4(asm volatile("v_and_b32 %0, %8, %0\n v_or_b32 %1, %8, %1\n v_xor_b32 %2, %8, %2\n v_sub_u32 %3, %8, %3\n v_max_i32 %4, %8, %4\n v_min_i32 %5, %8, %5\n v_bfe_u32 %6, %6, %8, 5\n v_lshl_add_u32 %7, %7, 1, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh));) }
+        // selects: v_cndmask with VCC, with an SGPR-pair mask, alternating with plain adds, and the mask rebuilt by a compare each time
+        if (K == 12) { R4(asm volatile("v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[20:21]\n v_cndmask_b32_e64 %4, %4, %8, s[20:21]\n v_cndmask_b32_e64 %5, %5, %8, s[20:21]\n v_cndmask_b32_e64 %6, %6, %8, s[20:21]\n v_cndmask_b32_e64 %7, %7, %8, s[20:21]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh) : "s20", "s21");) }
+        if (K == 13) { R4(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_add_u32 %1, %8, %1\n v_cndmask_b32 %2, %2, %8, vcc\n v_add_u32 %3, %8, %3\n v_cndmask_b32 %4, %4, %8, vcc\n v_add_u32 %5, %8, %5\n v_cndmask_b32 %6, %6, %8, vcc\n v_add_u32 %7, %8, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh) : "vcc");) }
+        if (K == 14) { R4(asm volatile("v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_u32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n v_cmp_lt_u32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_u32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh) : "vcc");) }
+        if (K == 15) { R4(asm volatile("v_cmp_lt_u32 s[20:21], %0, %8\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cmp_lt_u32 s[22:23], %2, %8\n v_cndmask_b32_e64 %3, %3, %8, s[22:23]\n v_cmp_lt_u32 s[24:25], %4, %8\n v_cndmask_b32_e64 %5, %5, %8, s[24:25]\n v_cmp_lt_u32 s[26:27], %6, %8\n v_cndmask_b32_e64 %7, %7, %8, s[26:27]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");) }
+        if (K == 16) { R4(asm volatile("v_min_u32 %0, %0, %8\n v_max_u32 %1, %1, %8\n v_bfi_b32 %2, %8, %2, %3\n v_and_or_b32 %3, %3, %8, %4\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh));) }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     const unsigned long long w1 = wall_clock64();
@@ -62,6 +68,8 @@ int main() {
     run<0>("v_add_u32", d, n_cu); run<1>("v_lshlrev_b32", d, n_cu); run<2>("v_cndmask_b32", d, n_cu); run<3>("v_min_i32_dpp", d, n_cu);
     run<4>("v_cmp_lt_u32", d, n_cu); run<5>("v_cvt_f32_i32+v_fma_f32", d, n_cu); run<6>("ds_bpermute_b32", d, n_cu); run<7>("s_add/s_and", d, n_cu);
     run<8>("v_readlane_b32", d, n_cu);
+    run<12>("v_cndmask_e64 sgpr mask", d, n_cu); run<13>("v_cndmask / v_add altern.", d, n_cu); run<14>("v_cmp vcc + v_cndmask", d, n_cu);
+    run<15>("v_cmp sgpr + v_cndmask_e64", d, n_cu); run<16>("min/max/bfi/and_or/4 v_mov", d, n_cu);
     run<9>("v_lshl / s_op alternating", d, n_cu); run<10>("4 v_lshl then 4 s_op", d, n_cu); run<11>("and/or/xor/sub/max/min/bfe/lshl_add", d, n_cu);
     return 0;
 }
