@@ -1136,7 +1136,7 @@ def case_multi_entry_points(backend, steps=40):
     D, S, O = C.POINTER(_abi.JssDesc), C.POINTER(_abi.JssState), C.POINTER(_abi.JssOut)
     P = C.c_void_p
     groups = {"fused grid": [dict(instances=["ta01", "ta02", "ta03"], batch=9), dict(instances=["ta21", "ta31"], batch=5),
-                             dict(instances=["ta51", "ta61"], batch=3), dict(instances=["ta71", "ta72"], batch=2)],
+                             dict(instances=["ta51", "ta61"], batch=3), dict(instances=["ta71", "ta52"], batch=4)],   # (last: ragged, 50 and 100 jobs: the grid's two-jobs-per-lane body has no narrow path)
               "fallback": [dict(instances="ta01", batch=6), dict(instances=["ta11", "ta12"], batch=4), dict(instances="ta51", batch=2)]}
     for what, kws in groups.items():
         a = [BatchedJssEnv(seed=4, env_id_base=100 * i, _backend=be, **kw) for i, kw in enumerate(kws)]
