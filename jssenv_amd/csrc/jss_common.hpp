@@ -262,6 +262,9 @@ __device__ __forceinline__ void stage_shared_table(int32_t *dst, const int32_t *
 // counters[4] += (steps, episodes, makespans, reward numerators) as result-less atomics: a plain `+=` is
 // a load the wave has to wait for (~600 cycles at the end of every wave); these are fire-and-forget.
 __device__ __forceinline__ void add_counters(int64_t *cn, int steps, int episodes, int makespan_sum, int reward_num) {
+#ifdef JSS_EXP_NO_COUNTERS   // A/B builds only: what the per-env counters cost (read the answer off ms_per_step: the rates need them)
+    return;
+#endif
     unsigned long long *u = reinterpret_cast<unsigned long long *>(cn);
     if (steps) atomicAdd(u + 0, (unsigned long long)(long long)steps);
     if (episodes) atomicAdd(u + 1, (unsigned long long)(long long)episodes);
