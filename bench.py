@@ -206,6 +206,7 @@ CONFIG_KEYS = {    # detail-file key of a BASELINE config's side run -> its shor
     "config4_synthetic50x20_batch65536_one_gpu": "c4_syn50x20_b65536_one_gpu",
     "config4_sharded": "c4_syn50x20_b65536_sharded",
     "config5_mixed_padded_batch32768": "c5_mixed_b32768_padded",
+    "config5_mixed_padded_by_shape_batch32768": "c5_mixed_b32768_padded_by_shape",
     "config5_mixed_bucketed_batch32768": "c5_mixed_b32768_bucketed",
 }
 
@@ -300,6 +301,9 @@ def parse_args():
     ap.add_argument("--bucketed", action="store_true",
                     help="mixed workload only: one compact sub-batch per shape class (BucketedJssEnv) instead of "
                          "padding every env to 100x20")
+    ap.add_argument("--by-shape", action="store_true",
+                    help="mixed workload only: the padded batch with its envs ordered by shape class (BatchedJssEnv(order='by_shape')): "
+                         "same padded tensors, stepped by ONE grid of class-specialised bodies instead of the padded extents' kernel")
     ap.add_argument("--bucketed-launch", default="grid", choices=["grid", "streams"],
                     help="--bucketed: ONE grid over all shape classes per step (jss_multi_rollout) or round 3's form, one launch "
                          "per class and step on a stream per class (A/B)")
@@ -397,7 +401,7 @@ def main():
         inst = builtin_instance(instance)
         return b_alg(inst.jobs, inst.machines), f"{instance} ({inst.jobs}x{inst.machines}) one instance shared by the batch", instance
 
-    def make_env(workload, batch, first_env, policy, instance="ta01", bucketed=False, spread=True):
+    def make_env(workload, batch, first_env, policy, instance="ta01", bucketed=False, spread=True, by_shape=False):
         if workload == "mixed" and bucketed:
             from jssenv_amd import BucketedJssEnv
             insts = [builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
@@ -414,7 +418,8 @@ def main():
             src = [builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
         else:
             src = builtin_instance(instance)
-        e = BatchedJssEnv(src, batch=batch, device=dev, seed=args.seed, env_id_base=first_env)
+        e = BatchedJssEnv(src, batch=batch, device=dev, seed=args.seed, env_id_base=first_env,
+                          order="by_shape" if (by_shape and workload == "mixed") else None)
         e.reset()
         if spread:
             # Spread the episode phases (a fresh batch is in lock step: every env at step 0) so the timed
@@ -557,6 +562,8 @@ def main():
             if env.launch == "grid":
                 return "jss_multi_kernel<kRollout1>: one grid over the shape classes (16-lane groups, 32-lane groups, wave, wave x2)"
             return "four launches per step: jss_packed_kernel<16|32,kRollout1,*>, jss_kernel<1|2,kRollout1,*>"
+        if getattr(env, "_classes", None) is not None:
+            return "jss_multi_kernel<kRollout1>: one grid of class-specialised bodies on the padded rows (order='by_shape')"
         tab = ("kTabLdsC" if env.compact else "kTabLds") if env.n_tables == 1 else ("kTabGlobalM" if getattr(env, "medium", False) else "kTabGlobal")
         jm, mm = env.jmax, env.mmax
         if max(jm, mm) <= 32:
@@ -781,11 +788,13 @@ def main():
         return out
 
     def side_run(workload, batch, policy, label_extra="", instance="ta01", bucketed=False, modes=("eager", "graph", "sub2", "sub3"),
-                 first_env=None, keep=False, with_trajectory=False, with_external=False):
+                 first_env=None, keep=False, with_trajectory=False, with_external=False, by_shape=False):
         """One extra workload on this GPU, same timing discipline as the headline."""
         alg, label, key = describe(workload, instance)
         env = make_env(workload, batch, first_env if first_env is not None else rank * batch, policy, instance=instance,
-                       bucketed=bucketed)
+                       bucketed=bucketed, by_shape=by_shape)
+        if by_shape:
+            key = "mixed_by_shape"
         for _ in range(args.warmup):
             env.rollout(policy, n_iter=1, autoreset=True)
         mode = pick_mode(env, policy, list(modes))
@@ -824,7 +833,9 @@ def main():
         B, first_env = hi - lo, lo
     else:
         B, first_env = args.batch, rank * args.batch
-    env = make_env(args.workload, B, first_env, args.policy, instance=args.instance, bucketed=args.bucketed)
+    env = make_env(args.workload, B, first_env, args.policy, instance=args.instance, bucketed=args.bucketed, by_shape=args.by_shape)
+    if args.by_shape and args.workload == "mixed":
+        key = "mixed_by_shape"
     for _ in range(args.warmup):
         env.rollout(args.policy, n_iter=1, autoreset=True)
     torch.cuda.synchronize()
@@ -854,7 +865,8 @@ def main():
             torch.cuda.synchronize()
         host_issue_us = agree_max([best / (args.steps * n_sub_i) * 1e6])[0]
     bucket_note = ", shape-bucketed (no padding)" if (args.bucketed and args.workload == "mixed") else \
-        (", padded 100x20" if args.workload == "mixed" else "")
+        (", padded 100x20, envs ordered by shape class" if (args.workload == "mixed" and args.by_shape) else
+         ", padded 100x20" if args.workload == "mixed" else "")
     inst0 = builtin_instance(args.instance)
     out = {
         "metric": "env steps/sec (batched)", "value": med["rate"], "unit": "env steps/s", "n_gpus": world,
@@ -969,6 +981,9 @@ def main():
                                                                label_extra=" -- all of config 4 on one GPU")),
             ("config5_mixed_padded_batch32768", dict(workload="mixed", batch=32768, policy="random", label_extra=", padded 100x20",
                                                      with_trajectory=x, with_external=x)),
+            ("config5_mixed_padded_by_shape_batch32768", dict(workload="mixed", batch=32768, policy="random", by_shape=True,
+                                                              modes=("eager", "sub2", "sub3"),
+                                                              label_extra=", padded 100x20, envs ordered by shape class: class-specialised bodies on the padded rows")),
             ("config5_mixed_bucketed_batch32768", dict(workload="mixed", batch=32768, policy="random", bucketed=True,
                                                        label_extra=", shape-bucketed (no padding)")),
         ]

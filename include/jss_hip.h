@@ -266,6 +266,13 @@ typedef struct JssDesc {
                                     (n_tables == 1 only, else JSS_E_SHAPE); JSS_NFM = medium records (n_tables > 1 and
                                     mmax <= 32, else JSS_E_SHAPE)                           */
     double cr_factor;            /* CriticalRatio's due_date_factor for kind = JSS_POLICY_CR_F64 (> 0); ignored otherwise */
+    int32_t jclass, mclass;      /* jss_multi_* only (0, 0 = jmax, mmax): the largest J / M among THIS set's envs when the set is a
+                                    range of a batch that is padded wider (a shape class of a ragged population inside ONE set of
+                                    padded tensors): the grid picks the set's body from the class -- 4 or 2 envs per wavefront,
+                                    one wavefront per env, two jobs per lane -- and takes the strides from jmax / mmax.  Such an
+                                    env keeps its class for life (table_of_env may move it between instances of the class only),
+                                    and the tensors must have been zero-filled: a class body touches the rows it owns, not
+                                    the padding behind them.  The single-set calls ignore both fields */
 } JssDesc;
 
 typedef struct JssState {

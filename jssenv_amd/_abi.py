@@ -68,7 +68,8 @@ class JssDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("jmax", C.c_int32), ("mmax", C.c_int32), ("n_tables", C.c_int32),
                 ("ops", _p), ("rem", _p), ("inst", _p), ("table_of_env", _p), ("env_ids", _p),
                 ("env_id_base", C.c_int64), ("kernel", C.c_int32), ("threads", C.c_int32),
-                ("jmin", C.c_int32), ("record_ints", C.c_int32), ("cr_factor", C.c_double)]
+                ("jmin", C.c_int32), ("record_ints", C.c_int32), ("cr_factor", C.c_double),
+                ("jclass", C.c_int32), ("mclass", C.c_int32)]
 
 
 class JssState(C.Structure):

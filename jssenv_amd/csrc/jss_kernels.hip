@@ -104,10 +104,14 @@ unsigned long long *g_stamps = nullptr;
 
 // Kernel flavour for a batch shape: the packed kernel needs every env's jobs AND machines to fit
 // a 16- or 32-lane group.
-int packed_group(const JssDesc &d) {
+// by_class: the fused multi-set grid, which honours JssDesc.jclass / mclass (a shape class inside wider padded tensors)
+int class_jobs(const JssDesc &d, bool by_class) { return by_class && d.jclass > 0 ? d.jclass : d.jmax; }
+int class_machines(const JssDesc &d, bool by_class) { return by_class && d.mclass > 0 ? d.mclass : d.mmax; }
+int packed_group(const JssDesc &d, bool by_class = false) {
     if (d.kernel == JSS_KERNEL_WAVE) return 0;
-    if (d.jmax <= 16 && d.mmax <= 16) return 16;
-    if (d.jmax <= 32 && d.mmax <= 32) return 32;
+    const int j = class_jobs(d, by_class), m = class_machines(d, by_class);
+    if (j <= 16 && m <= 16) return 16;
+    if (j <= 32 && m <= 32) return 32;
     return 0;
 }
 
@@ -136,14 +140,14 @@ constexpr size_t kMaxDynamicLds = 64 * 1024;   // available to a workgroup witho
 
 // Fills the launch-derived fields of `p` (LDS layout) from the whole batch's description.
 template <int MODE>
-int plan(Params &p, LaunchPlan &lp) {
+int plan(Params &p, LaunchPlan &lp, bool by_class = false) {
     const bool shared = p.d.n_tables == 1;
     p.region_ints = p.d.jmax * p.d.mmax;
     p.table_lds_ints = shared ? ((p.region_ints + 3) & ~3) : 0;
-    const int G = packed_group(p.d);
+    const int G = packed_group(p.d, by_class);
     if (G) {
         lp.envs_per_block = (kWave / G) * kWavesPerBlock;
-        p.obs_wave_floats = ((kWave / G) * p.d.jmax * 7 + 3) & ~3;
+        p.obs_wave_floats = ((kWave / G) * (p.d.jmax < G ? p.d.jmax : G) * 7 + 3) & ~3;      // (jmax > G: a class inside padded rows)
         p.mv_off_ints = p.table_lds_ints + kWavesPerBlock * p.obs_wave_floats;
         p.norm_off_ints = p.mv_off_ints + kBlock;                       // one int per lane (six used per group), kTabGlobal
         lp.shmem = sizeof(int32_t) * ((size_t)p.norm_off_ints + (shared ? 0 : kBlock));
@@ -161,7 +165,7 @@ int plan(Params &p, LaunchPlan &lp) {
     lp.shmem += g_lds_pad;
 #endif
     if (lp.shmem > kMaxDynamicLds) return JSS_E_LDS;
-    lp.fn = pick<MODE>(G, p.d.jmax <= kWave ? 1 : 2, shared, p.d.record_ints);
+    lp.fn = by_class ? nullptr : pick<MODE>(G, p.d.jmax <= kWave ? 1 : 2, shared, p.d.record_ints);   // (the grid has its own kernel)
     return 0;
 }
 
@@ -359,7 +363,7 @@ struct MultiParams {
     int32_t n_sets;
 };
 
-constexpr int multi_min_blocks(int mode) { return mode == kStep ? 6 : mode == kRollout1 ? 7 : 8; }
+constexpr int multi_min_blocks(int mode) { return mode == kStep ? 5 : mode == kRollout1 ? 7 : mode == kReset ? 6 : 8; }
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock, multi_min_blocks(MODE)) void jss_multi_kernel(MultiParams mp) {
@@ -381,21 +385,25 @@ __global__ __launch_bounds__(kBlock, multi_min_blocks(MODE)) void jss_multi_kern
     switch (mp.flavour[k]) {
     case kMfW2G: wave_block<2, MODE, kTabGlobal, false>(p, block, lds); break;   // (one body: 66 VGPRs, no spills at 7 waves / SIMD)
     case kMfW1G: wave_block<1, MODE, kTabGlobal>(p, block, lds); break;
-    case kMfP32G: packed_block<32, MODE, kTabGlobal>(p, block, lds); break;
+    case kMfP32G: packed_block<32, MODE, kTabGlobal, true>(p, block, lds); break;   // (full records: also classes inside padded rows)
     case kMfP32M: packed_block<32, MODE, kTabGlobalM>(p, block, lds); break;
-    case kMfP16G: packed_block<16, MODE, kTabGlobal>(p, block, lds); break;
+    case kMfP16G: packed_block<16, MODE, kTabGlobal, true>(p, block, lds); break;
     default: packed_block<16, MODE, kTabGlobalM>(p, block, lds); break;
     }
 }
 
 int multi_flavour(const JssDesc &d) {
     if (d.n_tables == 1) return kMfNone;                                  // shared table: LDS-staged bodies are not in the grid
-    const int G = packed_group(d);
+    const int G = packed_group(d, true);
     const bool medium = d.record_ints == JSS_NFM;
+    if (G && d.jmax > G && (medium || d.jclass > d.jmax || d.mclass > d.mmax)) return kMfNone;   // a class inside padded rows: full records
+    if (d.jclass > d.jmax || d.mclass > d.mmax) return kMfNone;
     if (G == 16) return medium ? kMfP16M : kMfP16G;
     if (G == 32) return medium ? kMfP32M : kMfP32G;
     if (medium) return kMfNone;
-    return d.jmax <= kWave ? kMfW1G : kMfW2G;
+    // one job per lane: J <= 64 -- but a 64-job env inside rows wider than 64 keeps its NOPE flag at byte 64 of the mask row,
+    // which only the two-jobs-per-lane body writes
+    return class_jobs(d, true) <= (d.jmax > kWave ? kWave - 1 : kWave) ? kMfW1G : kMfW2G;
 }
 
 // `ps[0..n)`: fully filled Params of the sets (everything but the launch-derived LDS fields).  One fused launch per step when
@@ -442,7 +450,7 @@ int launch_multi(Params *ps, int n, int n_steps, int n_sub, void *const *streams
             const int start = part * chunk;
             if (start >= whole.d.batch) continue;
             LaunchPlan lp;
-            const int rc = plan<MODE>(whole, lp);                        // (fills the LDS layout fields of `whole`)
+            const int rc = plan<MODE>(whole, lp, true);                  // (fills the LDS layout fields of `whole`; class-aware)
             if (rc) return rc;
             Params p = n_sub == 1 ? whole : sub_batch(whole, start, whole.d.batch - start < chunk ? whole.d.batch - start : chunk);
             nb += (p.d.batch + lp.envs_per_block - 1) / lp.envs_per_block;

@@ -626,14 +626,20 @@ __device__ __forceinline__ PHeader p_unpack(PEnv<G> &e, const PCtx<G, TAB> &c, c
 }
 
 // action mask rows of jmax + 1 bytes at `mk` (first env of the wave): legal jobs, the NOPE flag at index J, zeros behind it
-template <int G, int TAB, bool WT = false>
+// PADDED (here and below): the rows of the tensors may be wider than the lane group -- a class of small instances inside a batch
+// that is padded to a larger one (jmax > G; only the fused multi-set grid instantiates it).  Strides come from the layout (jmax,
+// mmax), extents from the group: the group touches rows / bytes < G only, what lies behind them was zero-filled by the allocation
+// and is nobody's to change as long as the env keeps its class.
+template <int G, int TAB, bool WT = false, bool PADDED = false>
 __device__ __forceinline__ void p_store_mask(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, uint8_t *mk) {
     if (!c.alive) return;
     const unsigned jm = (unsigned)p.d.jmax;
     const unsigned mo = c.rel * (jm + 1);
     if ((unsigned)c.gl <= jm)
         st_out<WT, uint8_t>(mk, mo + c.gl, (uint8_t)(c.jvalid ? (e.legal ? 1 : 0) : (c.gl == c.J ? e.noop : 0)));
-    if (jm == (unsigned)G && c.gl == 0) st_out<WT, uint8_t>(mk, mo + jm, (uint8_t)(c.J == G ? e.noop : 0));
+    if (PADDED && jm > (unsigned)G) {
+        if (c.J == G && c.gl == 0) st_out<WT, uint8_t>(mk, mo + G, (uint8_t)e.noop);      // the NOPE flag of a group-filling instance
+    } else if (jm == (unsigned)G && c.gl == 0) st_out<WT, uint8_t>(mk, mo + jm, (uint8_t)(c.J == G ? e.noop : 0));
 }
 
 // the observation's normalisers of my env (see PCtx)
@@ -736,10 +742,30 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
 // (J,7) float32 observation (jss_env.py:102-111).  Each lane writes its job's row into an LDS
 // image of the wave's E consecutive envs ([E][jmax][7], padding rows zero), which then goes out as
 // one linear copy -- dwordx4 per lane when the wave's block is whole and 16-byte sized.
-template <int G, int TAB, bool WT = false>
+template <int G, int TAB, bool WT = false, bool PADDED = false>
 __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, float *dst,
                                             float *scratch, bool wave_whole) {   // dst: block of the wave's first env
     constexpr int E = kWave / G;
+    if (PADDED && p.d.jmax > G) {
+        // rows of jmax * 7 floats in memory, an image of G rows per env in LDS: every env's first G rows leave on their own,
+        // 64 bytes per group and store (the rows behind J(env) as zeros; the rows behind G are never touched)
+        const PNorm nr = p_norm(c);
+        const float f_op = (float)c.max_time_op, f_jobs = (float)nr.max_time_jobs, f_sum = (float)nr.sum_op, f_m = (float)c.M;
+        float *mine = scratch + (c.gbase / G) * (G * 7);
+        float *row = mine + c.gl * 7;
+        row[0] = e.legal ? 1.0f : 0.0f;
+        row[1] = div_by((float)e.left, f_op, nr.r_op);
+        row[2] = div_by((float)e.todo, f_m, nr.r_m);
+        row[3] = div_by((float)e.perf, f_jobs, nr.r_jobs);
+        row[4] = e.f4 == JSS_F4_ONE ? 1.0f : div_by((float)e.f4, f_op, nr.r_op);
+        row[5] = div_by((float)e.idle_last, f_sum, nr.r_sum);
+        row[6] = div_by((float)e.idle, f_sum, nr.r_sum);
+        wave_lds_sync();
+        if (c.alive)
+            for (int i = c.gl; i < G * 7; i += G) st_out<WT, float>(dst, (c.rel * (unsigned)(p.d.jmax * 7) + i) * 4u, mine[i]);
+        wave_lds_sync();
+        return;
+    }
     const int row_floats = p.d.jmax * 7;
     const PNorm nr = p_norm(c);
     const float f_op = (float)c.max_time_op, f_jobs = (float)nr.max_time_jobs, f_sum = (float)nr.sum_op;
@@ -969,8 +995,9 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
 #endif
 // One workgroup's share of a packed launch: `block` = its index among the workgroups of THIS env set (blockIdx.x of a
 // plain launch; a workgroup of the fused multi-set grid -- jss_multi_kernel -- passes its index within its own set).
-template <int G, int MODE, int TAB>
+template <int G, int MODE, int TAB, bool PADDED = false>
 __device__ __forceinline__ void packed_block(const Params &p, int block, int32_t *lds) {
+    static_assert(!PADDED || (MODE != kTraj && MODE != kSteps && MODE != kSession), "the recorders write whole rows");
     constexpr int E = kWave / G;                      // envs per wave
     constexpr int EB = E * kWavesPerBlock;            // envs per workgroup
     const int lane = threadIdx.x & (kWave - 1);
@@ -1060,9 +1087,9 @@ __device__ __forceinline__ void packed_block(const Params &p, int block, int32_t
     const bool fresh = p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab, scratch, wave_whole);
     if (MODE == kPolicy) return;
     p_store(e, c, p, hd, raw, fresh);
-    p_store_mask<G, TAB>(e, c, p, p.o.action_mask + fe * (p.d.jmax + 1));
+    p_store_mask<G, TAB, false, PADDED>(e, c, p, p.o.action_mask + fe * (p.d.jmax + 1));
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
-        p_store_obs<G, TAB>(e, c, p, p.o.real_obs + fe * p.d.jmax * 7, scratch, wave_whole);
+        p_store_obs<G, TAB, false, PADDED>(e, c, p, p.o.real_obs + fe * p.d.jmax * 7, scratch, wave_whole);
 }
 
 template <int G, int MODE, int TAB>

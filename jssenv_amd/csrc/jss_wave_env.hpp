@@ -1094,8 +1094,8 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
     store_mask(e, c, p.o.action_mask + (size_t)b * (p.d.jmax + 1), p.d.jmax);
     JSS_STAMP(p, b, 5, e.t);
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
-        store_obs(e, c, p.o.real_obs + (size_t)b * p.d.jmax * 7, scratch, fresh ? p.d.jmax : c.J);
-    JSS_STAMP(p, b, 6, e.t);
+        store_obs(e, c, p.o.real_obs + (size_t)b * p.d.jmax * 7, scratch, fresh ? imin(p.d.jmax, JPL * kWave) : c.J);   // (a one-job-per-lane
+    JSS_STAMP(p, b, 6, e.t);                                     //  body inside wider rows owns the first 64: the fused grid's classes)
 }
 
 // ---------------------------------------------------------------------------------------

@@ -326,11 +326,19 @@ class BatchedJssEnv:
     batch      number of envs (defaults to len(instances)).
     kernel     "auto" (packed kernel when every env fits a 16/32-lane group) or "wave"
                (one wavefront per env); a per-env-object choice carried in JssDesc.
+    order      "by_shape": a ragged population in ONE set of padded tensors, stepped by class-specialised bodies.  The envs
+               are dealt onto the instances class by class (J, M <= 16, <= 32, J < 64, the rest: env i <- instance
+               sorted_by_class[i % n] -- every class a contiguous range of the batch) and reset / policy / step /
+               rollout(n_iter=1) / rollout_steps run as ONE grid over the classes (jss_multi_*, JssDesc.jclass: 4 or 2 envs
+               per wavefront for the small classes, one wavefront per env for the others) on the padded rows, instead of
+               the one kernel the padded extents would pick.  Same tensors, same layout, same results per env; an env
+               keeps its class for life (assign_instances: within the class).
     """
 
     def __init__(self, instances, batch: Optional[int] = None, device=None, env_id_base: int = 0,
                  table_of_env: Optional[Sequence[int]] = None, seed: int = 0, kernel: Optional[str] = None,
-                 compact: Optional[bool] = None, host_arena: bool = False, records: Optional[str] = None, _backend=None):
+                 compact: Optional[bool] = None, host_arena: bool = False, records: Optional[str] = None,
+                 order: Optional[str] = None, _backend=None):
         self._owns_backend = _backend is None
         self.backend = be = _backend if _backend is not None else make_backend(device)
         if isinstance(instances, PackedBatch):
@@ -351,6 +359,21 @@ class BatchedJssEnv:
         self.env_id_base = int(env_id_base)
         self.packed = pk
         self.jmax, self.mmax, self.n_tables = pk.jmax, pk.mmax, n
+        if order not in (None, "by_shape"):
+            raise ValueError("order must be None or 'by_shape'")
+        self._class_of_table = None
+        if order == "by_shape":
+            if n == 1 or table_of_env is not None:
+                raise ValueError("order='by_shape' deals the envs onto a LIST of instances itself (no table_of_env)")
+            # shape class of every instance (BucketedJssEnv's classes; a 64-job instance inside rows wider than 64 goes with
+            # the two-jobs-per-lane class: its NOPE flag lives at byte 64 of the mask row)
+            wide = 63 if pk.jmax > 64 else 64
+            cls = np.array([0 if (j <= 16 and m <= 16) else 1 if (j <= 32 and m <= 32) else 2 if j <= wide else 3
+                            for j, m in zip(pk.jobs.tolist(), pk.machines.tolist())])
+            by_class = np.argsort(cls, kind="stable")                    # instances class by class, given order inside a class
+            counts = np.bincount(np.arange(B) % n, minlength=n)[by_class]   # envs per instance as i % n would deal them
+            table_of_env = np.repeat(by_class, counts)
+            self._class_of_table = cls
         if table_of_env is None and n != 1 and n != B:
             table_of_env = np.arange(B) % n
         self.table_of_env_host = (np.zeros(B, dtype=np.int32) if n == 1 else
@@ -431,13 +454,52 @@ class BatchedJssEnv:
         p = be.ptr
         self._desc = _abi.JssDesc(B, J, M, n, p(self._ops), p(self._rem), p(self._inst), p(self._table_of_env), None,
                                   self.env_id_base, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)),
-                                  int(pk.jobs.min()), self.record_ints, 0.0)
+                                  int(pk.jobs.min()), self.record_ints, 0.0, 0, 0)
         self._state = _abi.JssState(p(self.env_header), p(self.env_const), p(self.job_state),
                                     None if self.no_clocks else p(self.machine_state), p(self.solution),
                                     p(self.counters))
         self._out = _abi.JssOut(p(self.real_obs), p(self.action_mask), p(self.reward), p(self.done), p(self.makespan))
         self._is_reset = False
         self._session = None                                     # an open StepSession: every other call raises meanwhile
+        self._classes = None
+        if self._class_of_table is not None:
+            self._build_class_views()
+
+    def _build_class_views(self):
+        """order='by_shape': one JssDesc / JssState / JssOut per shape class, each describing a contiguous range of THIS
+        batch's padded tensors (every per-env pointer moved to the class's first env; the instance tables shared)."""
+        be, B, J, M = self.backend, self.batch, self.jmax, self.mmax
+        cls_env = self._class_of_table[self.table_of_env_host]
+        assert (np.diff(cls_env) >= 0).all()
+        p = be.ptr
+        descs, states, outs, spans = [], [], [], []
+        for k in range(4):
+            idx = np.flatnonzero(cls_env == k)
+            if idx.size == 0:
+                continue
+            a, b = int(idx[0]), int(idx[-1]) + 1
+            assert b - a == idx.size
+            jc, mc = int(self.jobs_per_env[a:b].max()), int(self.machines_per_env[a:b].max())
+            off = lambda t, per_env: p(t) + a * per_env * t.dtype.itemsize if t is not None else None     # noqa: E731
+            d = _abi.JssDesc(b - a, J, M, self.n_tables, p(self._ops), p(self._rem), p(self._inst), off(self._table_of_env, 1), None,
+                             self.env_id_base + a, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)),
+                             int(self.jobs_per_env[a:b].min()), self.record_ints, 0.0, jc, mc)
+            st = _abi.JssState(off(self.env_header, _abi.NH), off(self.env_const, _abi.NC), off(self.job_state, J * self.record_ints),
+                               None if self.no_clocks else off(self.machine_state, M), off(self.solution, J * M), off(self.counters, 4))
+            o = _abi.JssOut(off(self.real_obs, J * 7), off(self.action_mask, J + 1), off(self.reward, 1), off(self.done, 1),
+                            off(self.makespan, 1))
+            descs.append(d), states.append(st), outs.append(o), spans.append((a, b, k))
+        n = len(descs)
+        D, S, O = C.POINTER(_abi.JssDesc), C.POINTER(_abi.JssState), C.POINTER(_abi.JssOut)
+        self._classes = {"n": n, "spans": spans, "keep": (descs, states, outs),
+                         "sets": ((D * n)(*[C.pointer(x) for x in descs]), (S * n)(*[C.pointer(x) for x in states]),
+                                  (O * n)(*[C.pointer(x) for x in outs]))}
+
+    def _class_ptrs(self, t):
+        """(void* * n): where each class's rows of the (B, ...) tensor `t` start"""
+        be = self.backend
+        per_env = int(np.prod(t.shape[1:])) if len(t.shape) > 1 else 1
+        return (C.c_void_p * self._classes["n"])(*[be.ptr(t) + a * per_env * t.dtype.itemsize for a, _, _ in self._classes["spans"]])
 
     def assign_instances(self, env_indices, table_indices):
         """Give envs ``env_indices`` the instances ``table_indices`` (indices into the ``instances`` this batch
@@ -452,6 +514,9 @@ class BatchedJssEnv:
         if env_indices.size and (env_indices.min() < 0 or env_indices.max() >= self.batch or
                                  table_indices.min() < 0 or table_indices.max() >= self.n_tables):
             raise ValueError("index out of range")
+        if self._class_of_table is not None and not np.array_equal(self._class_of_table[self.table_of_env_host[env_indices]],
+                                                                   self._class_of_table[table_indices]):
+            raise ValueError("order='by_shape': an env keeps its shape class for life -- give it an instance of the same class")
         self.table_of_env_host[env_indices] = table_indices
         self.jobs_per_env = self.packed.jobs[self.table_of_env_host]
         self.machines_per_env = self.packed.machines[self.table_of_env_host]
@@ -506,7 +571,11 @@ class BatchedJssEnv:
         d, s, o = self._refs()
         with be.on_device():
             w = self._mask_arg(which)
-            _abi.check(be.lib, be.lib.jss_reset(d, s, o, be.ptr(w), be.stream()), "jss_reset")
+            if self._classes is not None:        # order='by_shape': one grid over the shape classes
+                rc = be.lib.jss_multi_reset(self._classes["n"], *self._classes["sets"], None if w is None else self._class_ptrs(w), be.stream())
+                _abi.check(be.lib, rc, "jss_multi_reset")
+            else:
+                _abi.check(be.lib, be.lib.jss_reset(d, s, o, be.ptr(w), be.stream()), "jss_reset")
         self._is_reset = True
         return self._obs()
 
@@ -525,8 +594,14 @@ class BatchedJssEnv:
             a = self._stage(self._act_in, actions, "int32")   # the caller's int32 tensor itself, or a copy into our buffer
             # autoreset: envs that reported done last time are reset instead of stepped, in the same launch (the kernel
             # looks at the done flags itself: jss_step_autoreset)
-            fn = be.lib.jss_step_autoreset if autoreset else be.lib.jss_step
-            _abi.check(be.lib, fn(d, s, be.ptr(a), o, be.stream()), "jss_step")
+            if self._classes is not None:
+                cs = self._classes["sets"]
+                rc = be.lib.jss_multi_step(self._classes["n"], cs[0], cs[1], self._class_ptrs(a), cs[2],
+                                           _abi.ROLLOUT_AUTORESET if autoreset else 0, be.stream())
+                _abi.check(be.lib, rc, "jss_multi_step")
+            else:
+                fn = be.lib.jss_step_autoreset if autoreset else be.lib.jss_step
+                _abi.check(be.lib, fn(d, s, be.ptr(a), o, be.stream()), "jss_step")
         return self._obs(), self.reward, self.done, False, {}
 
     def step_raw(self, actions_ptr: int):
@@ -569,9 +644,17 @@ class BatchedJssEnv:
             self._desc.cr_factor = float(cr_factor)
         d, s, _ = self._refs()
         with be.on_device():
-            _abi.check(be.lib, be.lib.jss_policy(d, s, k, self.seed if seed is None else int(seed),
-                                                 int(round(explore * 65536)), be.ptr(self._actions_out), be.stream()),
-                       "jss_policy")
+            if self._classes is not None:
+                cs = self._classes["sets"]
+                for x in self._classes["keep"][0]:
+                    x.cr_factor = self._desc.cr_factor
+                rc = be.lib.jss_multi_policy(self._classes["n"], cs[0], cs[1], k, self.seed if seed is None else int(seed),
+                                             int(round(explore * 65536)), self._class_ptrs(self._actions_out), be.stream())
+                _abi.check(be.lib, rc, "jss_multi_policy")
+            else:
+                _abi.check(be.lib, be.lib.jss_policy(d, s, k, self.seed if seed is None else int(seed),
+                                                     int(round(explore * 65536)), be.ptr(self._actions_out), be.stream()),
+                           "jss_policy")
         return self._actions_out
 
     def rollout(self, kind: Union[str, int] = "random", n_iter: int = 1, seed: Optional[int] = None,
@@ -584,9 +667,15 @@ class BatchedJssEnv:
         flags = _abi.ROLLOUT_AUTORESET if autoreset else 0
         d, s, o = self._refs()
         with be.on_device():
-            _abi.check(be.lib, be.lib.jss_rollout(d, s, o, k, self.seed if seed is None else int(seed),
-                                                  int(round(explore * 65536)), int(n_iter), flags, be.stream()),
-                       "jss_rollout")
+            if self._classes is not None and int(n_iter) == 1:
+                streams = (C.c_void_p * 1)(be.stream())
+                rc = be.lib.jss_multi_rollout(self._classes["n"], *self._classes["sets"], k, self.seed if seed is None else int(seed),
+                                              int(round(explore * 65536)), 1, flags, 1, streams)
+                _abi.check(be.lib, rc, "jss_multi_rollout")
+            else:
+                _abi.check(be.lib, be.lib.jss_rollout(d, s, o, k, self.seed if seed is None else int(seed),
+                                                      int(round(explore * 65536)), int(n_iter), flags, be.stream()),
+                           "jss_rollout")
         return self._obs(), self.reward, self.done, False, {}
 
     def rollout_steps(self, kind: Union[str, int] = "random", steps: int = 1, n_sub: int = 2, seed: Optional[int] = None,
@@ -605,6 +694,13 @@ class BatchedJssEnv:
         d, s, o = self._refs()
         sd = self.seed if seed is None else int(seed)
         with be.on_device():
+            if self._classes is not None:       # order='by_shape': a grid over the shape classes per step and part
+                n = min(int(n_sub), 4)
+                streams = be.stream_array(n) if hasattr(be, "stream_array") else (C.c_void_p * n)()
+                rc = be.lib.jss_multi_rollout(self._classes["n"], *self._classes["sets"], k, sd, int(round(explore * 65536)), int(steps),
+                                              flags | (_abi.ROLLOUT_FORK_JOIN if n > 1 and hasattr(be, "stream_array") else 0), n, streams)
+                _abi.check(be.lib, rc, "jss_multi_rollout")
+                return self._obs(), self.reward, self.done, False, {}
             if hasattr(be, "stream_array"):     # the library forks / joins the side streams itself (two C calls per stream)
                 rc = be.lib.jss_rollout_steps(d, s, o, k, sd, int(round(explore * 65536)), int(steps),
                                               flags | _abi.ROLLOUT_FORK_JOIN, int(n_sub), be.stream_array(int(n_sub)))
@@ -660,6 +756,19 @@ class BatchedJssEnv:
             streams = be.stream_array(int(n_sub))
         fn, sd, q16, n_steps, n = be.lib.jss_rollout_steps, self.seed if seed is None else int(seed), int(round(explore * 65536)), int(steps), int(n_sub)
         lib = be.lib
+        if self._classes is not None:
+            n = min(n, 4)
+            with be.on_device():
+                streams = be.stream_array(n)
+            if n == 1:
+                flags &= ~_abi.ROLLOUT_FORK_JOIN
+            n_sets, sets, fm = self._classes["n"], self._classes["sets"], be.lib.jss_multi_rollout
+
+            def issue_classes():
+                rc = fm(n_sets, *sets, k, sd, q16, n_steps, flags, n, streams)
+                if rc:
+                    _abi.check(lib, rc, "jss_multi_rollout")
+            return issue_classes
 
         def issue():
             rc = fn(d, s, o, k, sd, q16, n_steps, flags, n, streams)

@@ -1181,6 +1181,66 @@ def case_multi_entry_points(backend, steps=40):
     assert be.lib.jss_multi_rollout(n, *sets, _abi.POLICY_CR_F64, 0, 0, 1, 0, 1, streams) == _abi.E_KIND
 
 
+def case_by_shape_padded(backend, n_envs=40, iters=60, seed=6, env_id_base=123, taillard=False, tail=4):
+    """order='by_shape': a ragged population in ONE set of padded tensors, stepped by the fused grid's class-specialised bodies
+    on the padded rows (JssDesc.jclass: packed 16- / 32-lane groups inside rows of jmax, one wavefront per env for the rest).
+    Every env equals the oracle -- including instances that FILL their lane group (J = 16, J = 32: the NOPE flag sits on the
+    group's edge) and a 64-job instance (which must go with the two-jobs-per-lane class) -- through the fused rollout in one and
+    in several parts, the un-fused policy -> step pair, a partial reset, an instance change inside a class, and calls that take
+    the plain padded kernel on the same tensors (multi-iteration rollout, trajectory)."""
+    rng = np.random.default_rng(seed)
+    if taillard:
+        insts = [I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
+    else:
+        insts = [I.builtin_instance("ta01"), random_instance(rng, 16, 9, max_dur=40), random_instance(rng, 7, 16, max_dur=30),
+                 I.builtin_instance("ta21"), random_instance(rng, 32, 20, max_dur=50), I.builtin_instance("ta41"),
+                 I.builtin_instance("ta51"), random_instance(rng, 63, 5, max_dur=20), random_instance(rng, 64, 4, max_dur=20),
+                 I.builtin_instance("ta71")]
+    env = BatchedJssEnv(insts, batch=n_envs, seed=seed, env_id_base=env_id_base, order="by_shape", _backend=backend)
+    cls = env._class_of_table[env.table_of_env_host]
+    assert (np.diff(cls) >= 0).all() and env._classes["n"] == 4 and sorted(np.bincount(env.table_of_env_host, minlength=len(insts))) == \
+        sorted(np.bincount(np.arange(n_envs) % len(insts), minlength=len(insts)))          # every instance as often as i % n would deal it
+    if not taillard:
+        assert cls[np.flatnonzero(env.jobs_per_env == 64)].tolist() == [3] * int((env.jobs_per_env == 64).sum())
+    env.reset()
+    env.rollout_steps("random", steps=iters // 2, n_sub=1)
+    env.rollout_steps("random", steps=iters - iters // 2, n_sub=3)
+    for _ in range(tail):
+        env.step(env.policy("random"), autoreset=True)
+    done = iters + tail
+    assert_batch_equals_oracle(env, "random", seed, done, f"by_shape x {n_envs}")
+    # the plain padded kernel on the same tensors (whatever the class bodies left in the padding rows is nobody's business)
+    env.rollout("random", n_iter=7)
+    env.trajectory("random", steps=5, record=("action",))
+    env.rollout("random", n_iter=1)
+    done += 13
+    assert_batch_equals_oracle(env, "random", seed, done, f"by_shape x {n_envs}, mixed with the padded kernel")
+    # partial reset through the grid: exactly the chosen envs restart
+    n = env.backend.numpy
+    before = n(env.env_header)[:, _abi.H_EPISODE].copy()
+    which = (np.arange(n_envs) % 3 == 0).astype(np.uint8)
+    env.reset(which=which)
+    after = n(env.env_header)
+    assert np.array_equal(after[:, _abi.H_EPISODE], before + which) and (after[which == 1][:, _abi.H_CLOCK] == 0).all()
+    # an env may change instance inside its class, not across classes
+    if not taillard:
+        i16 = int(np.flatnonzero(env.jobs_per_env == 16)[0])
+        env.assign_instances([i16], [0])                       # the 16 x 9 env becomes ta01 (class 0 both)
+        assert int(env.jobs_per_env[i16]) == 15
+        orc = OracleEnv(insts[0], strict=True)
+        orc.reset()
+        ep = int(n(env.env_header)[i16, _abi.H_EPISODE])
+        env.rollout_steps("random", steps=30, n_sub=2)
+        orc.rollout("random", seed, env_id_base + i16, 30, episode=ep)
+        assert_matches_oracle(env.host_state(i16), orc, "instance change inside a class")
+        try:
+            env.assign_instances([i16], [len(insts) - 1])
+            raise AssertionError("an env must keep its shape class")
+        except ValueError:
+            pass
+    return env
+
+
 def case_bucketed_every_env_vs_oracle(backend, n_envs=32768, iters=160, seed=6, env_id_base=123, launch="grid", kind="random",
                                       unfused_tail=0):
     """BASELINE config 5 without padding, at the benchmarked size: the mixed ta01-ta80 population as shape classes, stepped by

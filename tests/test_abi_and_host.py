@@ -60,7 +60,7 @@ def test_header_constants_match_python_mirror():
     assert defs["JSS_C_MAX_TIME_JOBS"] == _abi.C_MAX_TIME_JOBS and defs["JSS_C_RCP_MACHINES"] == _abi.C_RCP_MACHINES
     # the six normalisers sit in the same order in the instance record and in the per-env constants record
     assert defs["JSS_C_RCP_MACHINES"] - defs["JSS_C_MAX_TIME_JOBS"] == defs["JSS_I_RCP_MACHINES"] - defs["JSS_I_MAX_TIME_JOBS"] == 5
-    assert ctypes.sizeof(_abi.JssDesc) == 16 + 5 * 8 + 8 + 16 + 8 and ctypes.sizeof(_abi.JssState) == 48      # (+ double cr_factor)
+    assert ctypes.sizeof(_abi.JssDesc) == 16 + 5 * 8 + 8 + 16 + 8 + 8 and ctypes.sizeof(_abi.JssState) == 48      # (+ double cr_factor, + jclass, mclass)
     assert _abi.POLICY_CR_F64 == defs["JSS_POLICY_CR"] | (1 << 24) and "#define JSS_POLICY_CR_F64 (JSS_POLICY_CR | (1 << 24))" in hdr
     assert ctypes.sizeof(_abi.JssState) == 48 and ctypes.sizeof(_abi.JssOut) == 40
     assert ctypes.sizeof(_abi.JssTraj) == 40

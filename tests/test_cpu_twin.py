@@ -85,6 +85,10 @@ def test_bucketed_and_rollout_steps(cpu):
     P.case_bucketed_equals_padded(cpu, n_envs=48, n_iter=400)
 
 
+def test_ragged_population_in_padded_tensors_by_shape_class(cpu):
+    P.case_by_shape_padded(cpu, n_envs=200, iters=200)
+
+
 def test_multi_entry_points_equal_the_single_set_calls(cpu):
     P.case_multi_entry_points(cpu)
 

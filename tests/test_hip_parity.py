@@ -157,6 +157,16 @@ def test_vector_env_features(hip):
     P.case_vector_env_features(hip)
 
 
+def test_ragged_population_in_padded_tensors_by_shape_class(hip):
+    P.case_by_shape_padded(hip, n_envs=700, iters=300)
+
+
+def test_by_shape_padded_config5_full_size_every_env_equals_the_oracle(hip_auto):
+    """BASELINE config 5 in ONE set of padded tensors (100 x 20 rows), envs ordered by shape class, at the benchmarked 32 768:
+    class-specialised bodies of the fused grid on the padded rows, every env against the C oracle."""
+    P.case_by_shape_padded(hip_auto, n_envs=32768, iters=150, taillard=True)
+
+
 def test_multi_entry_points_equal_the_single_set_calls(hip):
     P.case_multi_entry_points(hip)
 

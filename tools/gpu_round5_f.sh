@@ -15,7 +15,7 @@ cp bench_detail.json $O/bench_default_detail.json
 for w in "ta01_single --launch eager" "ta01_sub2 --launch sub2" "ta01_b4096 --launch eager --batch 4096" "ta41 --launch eager --instance ta41 --policy SPT --batch 16384" \
          "syn15x15 --launch eager --workload synthetic15x15" "syn50x20 --launch eager --workload synthetic50x20 --batch 8192" \
          "syn50x20_b65536 --launch eager --workload synthetic50x20 --batch 65536" "mixed --launch eager --workload mixed --batch 32768" \
-         "mixed_bucketed --launch eager --workload mixed --batch 32768 --bucketed"; do
+         "mixed_bucketed --launch eager --workload mixed --batch 32768 --bucketed" "mixed_by_shape --launch eager --workload mixed --batch 32768 --by-shape"; do
   set -- $w; tag=$1; shift
   timeout 900 bash tools/gpu_profile.sh r05_$tag "$@" > $O/profile_$tag.log 2>&1
   tail -2 $O/profile_$tag.log

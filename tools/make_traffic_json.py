@@ -24,6 +24,7 @@ WORKLOADS = {
     "syn50x20_b8192": ("syn50x20", "jss_kernel<1, 5, 1>", "jss_kernel<1,kRollout1,kTabGlobal>", b_alg(50, 20), 8192),
     "mixed_b32768": ("mixed", "jss_kernel<2, 5, 1>", "jss_kernel<2,kRollout1,kTabGlobal> (one-job-per-lane body for J <= 64)", None, 32768),
     "mixed_bucketed_b32768": ("mixed_bucketed", "jss_multi_kernel<5>", "jss_multi_kernel<kRollout1>: one grid over the four shape classes", None, 32768),
+    "mixed_by_shape_b32768": ("mixed_by_shape", "jss_multi_kernel<5>", "jss_multi_kernel<kRollout1>: class-specialised bodies on the padded rows", None, 32768),
     "syn50x20_b65536": ("syn50x20_b65536", "jss_kernel<1, 5, 1>", "jss_kernel<1,kRollout1,kTabGlobal>", b_alg(50, 20), 65536),
 }
 

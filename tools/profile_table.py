@@ -21,7 +21,8 @@ LABEL = {"ta01_b65536": "headline: ta01 × 65 536, one launch per step", "ta01_b
          "ta01_b4096": "config 2: ta01 × 4 096", "syn15x15_b65536": "synthetic 15×15, per-env tables × 65 536",
          "ta41_b16384": "config 3: ta41 SPT × 16 384", "syn50x20_b8192": "config 4, one GPU's share: synthetic 50×20 × 8 192",
          "syn50x20_b65536": "config 4 whole on one GPU: synthetic 50×20 × 65 536", "mixed_b32768": "config 5 padded: mixed ta01–80 × 32 768",
-         "mixed_bucketed_b32768": "config 5, shape classes in ONE grid: mixed ta01–80 × 32 768"}
+         "mixed_bucketed_b32768": "config 5, shape classes in ONE grid: mixed ta01–80 × 32 768",
+         "mixed_by_shape_b32768": "config 5 padded, envs ordered by shape class, class bodies on the padded rows"}
 
 
 def kernel_avg_us(stats_csv, needle):
