@@ -26,8 +26,11 @@ class JssVectorEnv(gymnasium_base("VectorEnv")):
     """(a ``gymnasium.vector.VectorEnv`` when gymnasium is importable; its attributes are set here directly, the base
     class's constructor -- whose signature differs between gymnasium 0.29 and 1.x -- is not called)"""
 
-    def __init__(self, instances, num_envs: Optional[int] = None, device=None, to_numpy: bool = False, _backend=None):
-        self.env = BatchedJssEnv(instances, batch=num_envs, device=device, _backend=_backend)
+    def __init__(self, instances, num_envs: Optional[int] = None, device=None, to_numpy: bool = False, order: Optional[str] = None,
+                 _backend=None):
+        # order="by_shape": a list of instances of different shapes, the envs dealt onto them class by class and stepped by
+        # class-specialised kernel bodies on the padded tensors (BatchedJssEnv); `step` stays ONE launch (jss_multi_step)
+        self.env = BatchedJssEnv(instances, batch=num_envs, device=device, order=order, _backend=_backend)
         self.num_envs = self.env.batch
         self.to_numpy = to_numpy
         self.jobs_per_env = self.env.jobs_per_env

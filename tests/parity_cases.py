@@ -568,6 +568,41 @@ def case_vector_facade(backend):
     assert (finished >= 1).all() and (envs.makespan > 1000).all()
 
 
+def case_vector_facade_by_shape(backend, steps=120):
+    """The vector facade over a ragged population ordered by shape class: the gymnasium.vector calling convention, every step
+    one launch (jss_multi_step with next-step auto-reset), equal to the oracle env by env."""
+    from jssenv_amd.vector import JssVectorEnv
+    insts = [I.builtin_instance(n) for n in ("ta01", "ta21", "ta51", "ta71", "ta02")]
+    envs = JssVectorEnv(insts, num_envs=10, to_numpy=True, order="by_shape", _backend=backend)
+    toe = envs.env.table_of_env_host
+    assert sorted(toe.tolist()) == sorted((np.arange(10) % 5).tolist()) and list(envs.jobs_per_env) == sorted(envs.jobs_per_env)
+    obs, _ = envs.reset(seed=11)
+    assert obs["real_obs"].shape == (10, 100, 7) and obs["action_mask"].shape == (10, 101)
+    orcs = [OracleEnv(insts[t], strict=True) for t in toe]
+    for o in orcs:
+        o.reset()
+    rng = np.random.default_rng(3)
+    prev = np.zeros(10, dtype=bool)
+    for st in range(steps):
+        acts = []
+        for i, o in enumerate(orcs):
+            if prev[i]:
+                o.reset()                                    # next-step auto-reset: the action of a terminated env is ignored
+                acts.append(0)
+                continue
+            a = int(rng.choice(np.flatnonzero(o.legal_actions)))
+            assert obs["action_mask"][i, a]
+            o.step(a)
+            acts.append(a)
+        obs, rew, term, trunc, _ = envs.step(np.asarray(acts, dtype=np.int32))
+        for i, o in enumerate(orcs):
+            J = o.jobs
+            assert np.array_equal(obs["action_mask"][i, :J + 1], o.legal_actions != 0), (st, i)
+            assert np.abs(obs["real_obs"][i, :J].astype(np.float64) - o.state).max() <= OBS_TOL and not obs["real_obs"][i, J:].any()
+            assert bool(term[i]) == (o.nb_legal_actions == 0 and not prev[i])
+        prev = term.copy()
+
+
 def case_instance_resampling(backend):
     """assign_instances(): envs switch instance (and shape) between episodes; untouched envs keep running."""
     insts = [I.builtin_instance(n) for n in ("ta01", "ta11", "ta02")]

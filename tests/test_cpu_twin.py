@@ -85,6 +85,10 @@ def test_bucketed_and_rollout_steps(cpu):
     P.case_bucketed_equals_padded(cpu, n_envs=48, n_iter=400)
 
 
+def test_vector_facade_over_shape_classes(cpu):
+    P.case_vector_facade_by_shape(cpu)
+
+
 def test_ragged_population_in_padded_tensors_by_shape_class(cpu):
     P.case_by_shape_padded(cpu, n_envs=200, iters=200)
 

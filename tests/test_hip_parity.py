@@ -157,6 +157,10 @@ def test_vector_env_features(hip):
     P.case_vector_env_features(hip)
 
 
+def test_vector_facade_over_shape_classes(hip):
+    P.case_vector_facade_by_shape(hip)
+
+
 def test_ragged_population_in_padded_tensors_by_shape_class(hip):
     P.case_by_shape_padded(hip, n_envs=700, iters=300)
 

@@ -92,6 +92,10 @@ def test_bucketed_equals_padded(emu):
     P.case_bucketed_equals_padded(emu, n_envs=24, n_iter=60)
 
 
+def test_vector_facade_over_shape_classes(emu):
+    P.case_vector_facade_by_shape(emu, steps=40)
+
+
 def test_ragged_population_in_padded_tensors_by_shape_class(emu):
     P.case_by_shape_padded(emu, n_envs=20, iters=24, tail=2)
 
