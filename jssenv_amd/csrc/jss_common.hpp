@@ -112,10 +112,11 @@ struct Params {
 // every wave waits for anyway, while an in-place load waits in the middle of the dependent chain.  Same-box A/B, round 5
 // (profiles/r05_misc/ab_params_in_place.txt): config 5 padded rollout +-0 %, its jss_step -3 %, config 4's share -2 %,
 // config 3's packed kernel -10 %, headline +-0.  A spilled SGPR is two VALU-lane moves among ~800 instructions; the wait
-// is what costs.  So the one-step kernels keep the by-value form.  The exception is the one-wavefront-per-env RECORDER
-// (kTraj): by value it holds so much that 14-29 VGPRs live in scratch memory, and there reading in place wins -- trajectory
-// mode +6.5 % on config 4's share, +10 % on config 5 padded (profiles/r05_misc/ab_params_in_place.txt), +-0 on the packed
-// flavour, which stays by value.  The fused multi-set grid (jss_multi_kernel) copies its set's Params up front for the
+// is what costs.  So the one-step kernels keep the by-value form.  The exception are the one-wavefront-per-env kernels that
+// LOOP over steps with the state in registers (kTraj, kRollout, kSteps): by value every field stays live through the whole
+// loop (the recorder's two-jobs-per-lane form even keeps 14-29 VGPRs in scratch memory), and there reading in place wins --
+// trajectory mode +6.5 % on config 4's share, +10 % on config 5 padded, the 64-iteration rollout +6 % / +3 %, jss_steps +2.5 %
+// (profiles/r05_misc/ab_params_in_place.txt); +-0 on the packed flavour, which stays by value.  The fused multi-set grid (jss_multi_kernel) copies its set's Params up front for the
 // same reason the one-step kernels take them by value (+3 % over in place).
 // The explicit arguments start at offset 0 of the segment.  (Host pass and the test emulator: the argument itself.
 // -DJSS_PARAMS_ALL_IN_PLACE: A/B builds.)

@@ -1183,9 +1183,10 @@ __device__ __forceinline__ void wave_block(const Params &p, int block, int32_t *
 template <int JPL, int MODE, int TAB>
 __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel(Params p_arg) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
-    // by value where a launch is one step: measured faster than in place although it spills SGPRs; in place for the recorder,
-    // whose by-value form runs on scratch (jss_common.hpp: +6 % / +10 % on config 4's share / config 5 in trajectory mode)
-    JSS_PARAMS_OF(p, p_arg, MODE == kTraj);
+    // by value where a launch is one step: measured faster than in place although it spills SGPRs; in place for the launches
+    // that loop over steps with the state in registers (jss_common.hpp: trajectory mode +6.5 % / +10 % on config 4's share /
+    // config 5, the 64-iteration rollout +6 % / +3 %, jss_steps +2.5 %: there the up-front loads would stay live for the whole loop)
+    JSS_PARAMS_OF(p, p_arg, MODE == kTraj || MODE == kRollout || MODE == kSteps);
     wave_block<JPL, MODE, TAB>(p, (int)blockIdx.x, lds);
 }
 
