@@ -16,8 +16,8 @@ its own step s-1, so one sub-batch's drain overlaps another's fill; results are 
 Timing: W untimed warm-up steps, then windows of EXACTLY K steps, each bracketed by barrier +
 torch.cuda.synchronize() on both sides; per window the wall time is the MAX over ranks and the env steps the SUM
 over ranks (one RCCL all-reduce each, outside the timed region).  As many windows as it takes for the timed total to
-reach 50 ms (at least 5, at most 400): the driver's K = 20 makes a window 0.4 ms, and five of those are noise.
-value = median window; n / min / max are printed too.  roofline.frac is value x algorithmic bytes / peak -- the
+reach 0.5 s for the headline (0.1 s for the other configs; at least 5, at most 4 000 windows): the driver's K = 20 makes a
+window 0.3 ms, and a few of those are noise.  value = median window; n / min / p10 / max are printed too.  roofline.frac is value x algorithmic bytes / peak -- the
 wall-clock number anybody can recompute from the line; the HIP-event figure is kept as roofline.frac_gpu_time.
 
 Workload: BASELINE.json configs[1] shape (ta01, 15x15, one shared instance, random masked policy) at the
@@ -38,10 +38,11 @@ envs split over the N ranks by shard_bounds (strong scaling) -- measured after t
 Extra objects: roofline (HBM; frac = algorithmic bytes over the wall clock, frac_gpu_time over HIP events on the launch
 stream, single_launch = the one-launch-per-step form whose kernel duration rocprofv3 reports) and cpu_baseline = the
 Python / NumPy restatement of the reference's step() on ONE host core (kind "port": oracle/np_restatement.py, the stand-in
-for the reference's own speed, which cannot travel to this box), timed on this box in this run (rank 0, N = 1, ~10 s).
+for the reference's own speed, which cannot travel to this box), timed on this box in this run (rank 0, N = 1, ~5 s).
 --extras adds cpu_baseline_c_oracle (the C oracle, one env per thread) and cpu_baseline_twin (libjss_cpu.so).
 """
 import argparse
+import gc
 import hashlib
 import json
 import math
@@ -66,7 +67,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED_PEAK_GBS = 6290.0  # measured copy bandwidth, same guide (SURVEY.md 8(d) asks for both)
-MIN_WINDOWS, MAX_WINDOWS, MIN_TIMED_SECONDS = 5, 400, 0.05
+# windows per measurement: as many as it takes for the timed total to reach MIN_TIMED_SECONDS (the headline: half a second --
+# at the driver's K = 20 a window is 0.3 ms, so that is ~1 600 windows; the other configs 0.1 s each, the step_only legs 0.05 s)
+MIN_WINDOWS, MAX_WINDOWS = 5, 4000
+MIN_TIMED_SECONDS_HEADLINE, MIN_TIMED_SECONDS, MIN_TIMED_SECONDS_LIGHT = 0.55, 0.1, 0.05
+CPU_BASELINE_SECONDS = 5.0
 
 
 def csrc_hash():
@@ -114,7 +119,7 @@ def usable_threads():
 
 
 
-def cpu_baseline_restatement(inst_name, seed, target_seconds=10.0, instance=None):
+def cpu_baseline_restatement(inst_name, seed, target_seconds=CPU_BASELINE_SECONDS, instance=None):
     """The reference's own way of doing a step -- Python loops over NumPy arrays, one env, one core
     (oracle/np_restatement.py: attribute-for-attribute restatement of jss_env.py:121-653, pinned bit-exactly to the
     reference's golden traces; in the build container it runs at the live reference's speed) -- driven by the
@@ -206,8 +211,9 @@ CONFIG_KEYS = {    # detail-file key of a BASELINE config's side run -> its shor
     "config4_synthetic50x20_batch65536_one_gpu": "c4_syn50x20_b65536_one_gpu",
     "config4_sharded": "c4_syn50x20_b65536_sharded",
     "config5_mixed_padded_batch32768": "c5_mixed_b32768_padded",
-    "config5_mixed_padded_by_shape_batch32768": "c5_mixed_b32768_padded_by_shape",
+    "config5_mixed_padded_interleaved_batch32768": "c5_mixed_b32768_padded_interleaved",
     "config5_mixed_bucketed_batch32768": "c5_mixed_b32768_bucketed",
+    "synthetic15x15_per_env_tables": "syn15x15_b65536_per_env_tables",
 }
 
 
@@ -235,23 +241,32 @@ def compact_line(out, detail_files=()):
     line["config"]["launch"] = str(out.get("launch", ""))[:120]
     rf = out.get("roofline") or {}
     line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "frac_own_bytes", "frac_gpu_time", "traffic", "kernel",
-                                  "kernel_ms", "alg_bytes_per_env_step", "env_steps_per_launch", "wait_fraction",
+                                  "gpu_ms_per_step_events", "alg_bytes_per_env_step", "env_steps_per_launch", "wait_fraction",
                                   "wave_cycles_per_env_step"))
     single = out.get("single_launch_per_step")
     if isinstance(single, dict) and single.get("value"):
         # the plain form (ONE launch over the whole batch per step): the kernel duration rocprofv3 --kernel-trace reports
-        line["roofline"]["single_launch"] = _pick(single, ("value", "kernel_ms", "roofline_frac", "roofline_frac_gpu_time"))
+        line["roofline"]["single_launch"] = _pick(single, ("value", "gpu_ms_per_step_events", "roofline_frac", "roofline_frac_gpu_time"))
     cb = out.get("cpu_baseline")
     line["cpu_baseline"] = None if not isinstance(cb, dict) else {**_pick(cb, ("value", "unit", "cores", "kind")),
                                                                   "sample": str(cb.get("sample", ""))[:160]}
-    line["configs"], line["configs_env_steps_per_s"] = {}, {}
+    line["configs"], line["configs_env_steps_per_s"], line["configs_step_only"] = {}, {}, {}
+    so = out.get("step_only")
+    if isinstance(so, dict):
+        line["configs_step_only"]["headline"] = _sig(so.get("roofline_frac"), 4) if so.get("value") else None
     for key, shortname in CONFIG_KEYS.items():
         ent = out.get(key)
         if isinstance(ent, dict):
             line["configs"][shortname] = _sig(ent.get("roofline_frac"), 4) if ent.get("value") else None
             line["configs_env_steps_per_s"][shortname] = _sig(ent.get("value"), 4)
-    line["configs_note"] = "roofline.frac (wall clock, K steps per window) of each BASELINE config's fused one-launch-per-step form on one GPU"
-    line["windows"] = _pick(out.get("windows") or {}, ("n", "min", "max", "below_90pct_of_median"))
+            so = ent.get("step_only")
+            if isinstance(so, dict):
+                line["configs_step_only"][shortname] = _sig(so.get("roofline_frac"), 4) if so.get("value") else None
+    line["configs_note"] = ("roofline.frac (wall clock, K steps per window) of each config's fused one-launch-per-step form on one GPU; "
+                            "configs_step_only: the same for jss_step with the CALLER's actions, one launch per step = JssEnv.step(action)")
+    line["windows"] = _pick(out.get("windows") or {}, ("n", "min", "p10", "max", "below_90pct_of_median", "timed_seconds_total"))
+    if isinstance(out.get("ranks"), dict):
+        line["ranks"] = _pick(out["ranks"], ("value_min", "value_max", "numa_pinned"))
     if out.get("mean_makespan") is not None:
         line["mean_makespan"] = _sig(out["mean_makespan"])
     if out.get("process_group"):
@@ -261,7 +276,7 @@ def compact_line(out, detail_files=()):
     line["csrc_sha16"] = out.get("csrc_sha16")
     line["detail"] = list(detail_files)
     text = json.dumps(line, separators=(",", ":"))
-    for optional in ("configs_note", "windows", "configs_env_steps_per_s", "mean_makespan", "detail"):
+    for optional in ("configs_note", "configs_env_steps_per_s", "mean_makespan", "detail", "configs_step_only"):
         if len(text) <= COMPACT_MAX_BYTES:
             break
         line.pop(optional, None)
@@ -302,8 +317,12 @@ def parse_args():
                     help="mixed workload only: one compact sub-batch per shape class (BucketedJssEnv) instead of "
                          "padding every env to 100x20")
     ap.add_argument("--by-shape", action="store_true",
-                    help="mixed workload only: the padded batch with its envs ordered by shape class (BatchedJssEnv(order='by_shape')): "
-                         "same padded tensors, stepped by ONE grid of class-specialised bodies instead of the padded extents' kernel")
+                    help="mixed workload only: the padded batch with its envs ordered by shape class (BatchedJssEnv(order='by_shape'), "
+                         "which is also what the default constructor gives a ragged list): same padded tensors, stepped by ONE grid of "
+                         "class-specialised bodies instead of the padded extents' kernel")
+    ap.add_argument("--interleaved", action="store_true",
+                    help="mixed workload only: env i <- ta(1 + i %% 80) (BatchedJssEnv(order='interleaved'): every env on the padded "
+                         "extents' kernel, the default of rounds 1-5)")
     ap.add_argument("--bucketed-launch", default="grid", choices=["grid", "streams"],
                     help="--bucketed: ONE grid over all shape classes per step (jss_multi_rollout) or round 3's form, one launch "
                          "per class and step on a stream per class (A/B)")
@@ -343,7 +362,7 @@ def main():
     import torch
     import torch.distributed as dist
     from jssenv_amd import BatchedJssEnv, builtin_instance
-    from jssenv_amd.distributed import reduce_counters, select_device, shard_bounds
+    from jssenv_amd.distributed import local_world_size, pin_to_gpu_numa_node, reduce_counters, select_device, shard_bounds
     from jssenv_amd.instances import synthetic_packed
 
     rank = int(os.environ.get("RANK", "0"))
@@ -354,10 +373,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the GPU path has no CPU fallback")
     try:
-        local_rank = select_device(local_rank, world, torch.cuda.device_count(), share_device=args.share_device)
+        local_rank = select_device(local_rank, local_world_size(world), torch.cuda.device_count(), share_device=args.share_device)
     except (RuntimeError, ValueError) as exc:
         raise SystemExit(f"bench.py: {exc}")
     torch.cuda.set_device(local_rank)
+    # N ranks on one host, each polling its completion signals (HSA_ENABLE_INTERRUPT=0): every rank on CPUs of its own GPU's
+    # NUMA node, the ranks of a node on disjoint cores (distributed.pin_to_gpu_numa_node; a 1-rank run keeps the whole host for
+    # its CPU baselines).  JSS_BENCH_NO_PIN=1: A/B.
+    numa = {}
+    if world > 1 and not args.share_device and os.environ.get("JSS_BENCH_NO_PIN", "0") != "1":
+        numa = pin_to_gpu_numa_node(local_rank, int(os.environ.get("LOCAL_RANK", "0")), local_world_size(world))
     dev = torch.device("cuda", local_rank)
     backend = args.dist_backend or "nccl"   # "nccl" is RCCL on ROCm
     use_pg = world > 1 or args.force_process_group
@@ -401,7 +426,7 @@ def main():
         inst = builtin_instance(instance)
         return b_alg(inst.jobs, inst.machines), f"{instance} ({inst.jobs}x{inst.machines}) one instance shared by the batch", instance
 
-    def make_env(workload, batch, first_env, policy, instance="ta01", bucketed=False, spread=True, by_shape=False):
+    def make_env(workload, batch, first_env, policy, instance="ta01", bucketed=False, spread=True, order=None):
         if workload == "mixed" and bucketed:
             from jssenv_amd import BucketedJssEnv
             insts = [builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
@@ -419,7 +444,7 @@ def main():
         else:
             src = builtin_instance(instance)
         e = BatchedJssEnv(src, batch=batch, device=dev, seed=args.seed, env_id_base=first_env,
-                          order="by_shape" if (by_shape and workload == "mixed") else None)
+                          order=order if workload == "mixed" else None)      # (None: the constructor's default -- by shape for a ragged list)
         e.reset()
         if spread:
             # Spread the episode phases (a fresh batch is in lock step: every env at step 0) so the timed
@@ -519,29 +544,39 @@ def main():
         pick_mode.ranking = [(candidates[i], probe[i]) for i in order]      # (the headline re-measures a close runner-up)
         return candidates[order[0]]
 
-    def measure(env, policy, steps, mode, n_iter=1, windows=None, run=None, prep=None):
-        """Windows of `steps` steps each -- as many as it takes for the timed total to reach MIN_TIMED_SECONDS (between
+    def measure(env, policy, steps, mode, n_iter=1, windows=None, run=None, prep=None, min_seconds=MIN_TIMED_SECONDS):
+        """Windows of `steps` steps each -- as many as it takes for the timed total to reach `min_seconds` (between
         MIN_WINDOWS and MAX_WINDOWS; every rank takes the same number).  Returns the median window and all windows,
         already reduced over ranks.  `run(n)` overrides what a window executes (extras)."""
         graph = capture(env, policy, steps) if mode == "graph" else None
-        first = window(env, policy, steps, n_iter, mode, graph, run, prep)   # untimed: side streams / graph exist before the first window
+        window(env, policy, steps, n_iter, mode, graph, run, prep)           # untimed: side streams / graph exist before the first window
+        first = min(window(env, policy, steps, n_iter, mode, graph, run, prep)[0] for _ in range(3))   # untimed: sizes the count
         if windows is None:
-            t_win = agree_max([first[0]])[0]
-            windows = int(min(MAX_WINDOWS, max(MIN_WINDOWS, math.ceil(MIN_TIMED_SECONDS / max(t_win, 1e-6)))))
+            t_win = agree_max([first])[0]
+            windows = int(min(MAX_WINDOWS, max(MIN_WINDOWS, math.ceil(min_seconds / max(t_win, 1e-6)))))
         rows = []
+        # The collector stays out of the timed loop: a full collection of a process that has imported torch takes 20-40 ms --
+        # a hundred 0.3 ms windows -- and it fires whenever the allocation counters say so (round 6's first run: one window of
+        # 1 420 at 0.037 G env-steps/s next to a median of 4.26 G).  Nothing in the loop makes cycles; it runs once afterwards.
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
         for _ in range(windows):
             env.zero_counters()
             dt, _ = window(env, policy, steps, n_iter, mode, graph, run, prep)
             tot = reduce_counters(env.counter_totals().cpu() if on_host else env.counter_totals(), dt, force_collectives=use_pg)
             rows.append({"steps": tot["steps"], "seconds": tot["seconds"], "rate": tot["steps"] / tot["seconds"],
-                         "episodes": tot["episodes"], "makespan_sum": tot["makespan_sum"], "reward_num": tot["reward_num_sum"]})
+                         "episodes": tot["episodes"], "makespan_sum": tot["makespan_sum"], "reward_num": tot["reward_num_sum"],
+                         "rank_rate_min": tot["rank_rate_min"], "rank_rate_max": tot["rank_rate_max"]})
+        if gc_was_on:
+            gc.enable()
         # the GPU-time view (HIP events on the launch stream around the same K steps): a few extra windows of their own
         ms = sorted(window(env, policy, steps, n_iter, mode, graph, run, prep, events=True)[1] for _ in range(min(5, windows)))
-        kernel_ms = agree_max([ms[len(ms) // 2]])[0]
+        event_ms = agree_max([ms[len(ms) // 2]])[0]
         del graph
         rows.sort(key=lambda r: r["rate"])
         for r in rows:
-            r["kernel_ms"] = kernel_ms
+            r["gpu_ms_per_step_events"] = event_ms
         med = rows[len(rows) // 2]
         return med, rows
 
@@ -594,7 +629,7 @@ def main():
         (what the kernels achieve once launched; the difference is launch ramp-up, drain and the synchronisation)."""
         stepped = med["steps"] / world / steps
         achieved = med["rate"] / world * alg_per_step / 1e9
-        gpu_time = stepped * alg_per_step / (med["kernel_ms"] * 1e-3) / 1e9
+        gpu_time = stepped * alg_per_step / (med["gpu_ms_per_step_events"] * 1e-3) / 1e9
         traffic, src, sq = static_traffic(key, batch)
         step_s = med["seconds"] / steps
         # of the bytes the kernel really moves (counters; a pass in which every env steps): traffic / wall time per step
@@ -608,7 +643,10 @@ def main():
                 **sq,
                 "frac_gpu_time": gpu_time / HBM_PEAK_GBS, "achieved_gpu_time": gpu_time,
                 "measured_peak": HBM_MEASURED_PEAK_GBS, "traffic": traffic, "traffic_source": src,
-                "kernel": kernel_name(env), "kernel_ms": med["kernel_ms"],
+                "kernel": kernel_name(env),
+                # HIP-event time per step of windows of their own that keep the fork / join events -- GPU time of a STEP (all its
+                # launches, overlapped or not), not a kernel duration: that is rocprofv3's, profiles/<round>_*/kernel_stats.csv
+                "gpu_ms_per_step_events": med["gpu_ms_per_step_events"],
                 "alg_bytes_per_env_step": alg_per_step, "env_steps_per_launch": stepped}
 
     def traj_measure(env, policy, alg, KT=32):
@@ -640,13 +678,15 @@ def main():
             torch.cuda.synchronize()
             return {"value": None, "error": f"{type(exc).__name__}: {exc}"}
 
-    def step_only_measure(env, policy, alg, B):
+    def step_only_measure(env, policy, alg, B, light=False):
         """The boundary entry point itself: jss_step with the actions already resident in HBM, ONE launch per env step,
         next-step auto-reset folded into the action codes.  The actions are a recorded behaviour trajectory (jss_trajectory
         from a snapshot of the state, restored before every window), so every launch executes real, legal steps.  Eager
-        ctypes launches and a hipGraph replay of the same K launches; the better one is reported."""
+        ctypes launches and a hipGraph replay of the same K launches; the better one is reported.  (light: the default
+        run's leg -- windows of exactly K steps like every figure of the line, 50 ms of them per form.)"""
         try:
-            n2 = max(20, min(100, args.steps))
+            n2 = args.steps if light else max(20, min(100, args.steps))
+            secs = MIN_TIMED_SECONDS_LIGHT if light else MIN_TIMED_SECONDS
             env.zero_counters()                          # (the counters live in the arena: the snapshot holds zeros)
             snap = env._arena.clone(), env.solution.clone()
             acts = env.trajectory(policy, steps=n2, record=("action",))["action"]
@@ -658,7 +698,7 @@ def main():
             def replay_steps(n):
                 for k in range(n):
                     env.step(acts[k])
-            meds, rowss = measure(env, policy, n2, "eager", run=replay_steps, prep=restore)
+            meds, rowss = measure(env, policy, n2, "eager", run=replay_steps, prep=restore, min_seconds=secs)
             restore()
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -667,7 +707,7 @@ def main():
                 with torch.cuda.graph(gs, stream=side):
                     replay_steps(n2)
             torch.cuda.current_stream(dev).wait_stream(side)
-            medg, rowsg = measure(env, policy, n2, "eager", run=lambda n: gs.replay(), prep=restore)
+            medg, rowsg = measure(env, policy, n2, "eager", run=lambda n: gs.replay(), prep=restore, min_seconds=secs)
             del gs
             best, rws, how = (medg, rowsg, "hipGraph replay") if medg["rate"] > meds["rate"] else (meds, rowss, "eager ctypes launches")
             rfs = roofline(best, alg, n2, env, None, B)
@@ -788,12 +828,12 @@ def main():
         return out
 
     def side_run(workload, batch, policy, label_extra="", instance="ta01", bucketed=False, modes=("eager", "graph", "sub2", "sub3"),
-                 first_env=None, keep=False, with_trajectory=False, with_external=False, by_shape=False):
+                 first_env=None, keep=False, with_trajectory=False, with_external=False, order=None, with_step_only=False):
         """One extra workload on this GPU, same timing discipline as the headline."""
         alg, label, key = describe(workload, instance)
         env = make_env(workload, batch, first_env if first_env is not None else rank * batch, policy, instance=instance,
-                       bucketed=bucketed, by_shape=by_shape)
-        if by_shape:
+                       bucketed=bucketed, order=order)
+        if getattr(env, "_classes", None) is not None:
             key = "mixed_by_shape"
         for _ in range(args.warmup):
             env.rollout(policy, n_iter=1, autoreset=True)
@@ -819,6 +859,8 @@ def main():
             out["policy_then_step_pipelined"] = unfused_pipelined(env, policy, alg, batch)
             out["step_only"] = step_only_measure(env, policy, alg, batch)
             out["external_actions"] = external_action_forms(env, policy, alg, args.steps)
+        elif with_step_only and not bucketed and world == 1:
+            out["step_only"] = step_only_measure(env, policy, alg, batch, light=True)
         if keep:
             return out, env
         if hasattr(env, "close"):
@@ -833,20 +875,21 @@ def main():
         B, first_env = hi - lo, lo
     else:
         B, first_env = args.batch, rank * args.batch
-    env = make_env(args.workload, B, first_env, args.policy, instance=args.instance, bucketed=args.bucketed, by_shape=args.by_shape)
-    if args.by_shape and args.workload == "mixed":
+    env = make_env(args.workload, B, first_env, args.policy, instance=args.instance, bucketed=args.bucketed,
+                   order="by_shape" if args.by_shape else "interleaved" if args.interleaved else None)
+    if getattr(env, "_classes", None) is not None:
         key = "mixed_by_shape"
     for _ in range(args.warmup):
         env.rollout(args.policy, n_iter=1, autoreset=True)
     torch.cuda.synchronize()
-    mode = pick_mode(env, args.policy, ["eager", "graph", "sub2", "sub3"])
-    med, rows = measure(env, args.policy, args.steps, mode)
+    mode = pick_mode(env, args.policy, ["eager", "sub2", "sub3"] if getattr(env, "_classes", None) is not None else ["eager", "graph", "sub2", "sub3"])
+    med, rows = measure(env, args.policy, args.steps, mode, min_seconds=MIN_TIMED_SECONDS_HEADLINE)
     # The probe is five short windows per form: when the runner-up is within 15 % of the winner the two are too close to
     # call from that, so both get the full measurement and the better median is the headline (every rank takes the same
     # decision: the probe times and the medians are reduced over ranks).
     ranking = getattr(pick_mode, "ranking", [])
     if args.launch == "auto" and len(ranking) > 1 and ranking[1][1] <= 1.15 * ranking[0][1] and not hasattr(env, "buckets"):
-        med_b, rows_b = measure(env, args.policy, args.steps, ranking[1][0])
+        med_b, rows_b = measure(env, args.policy, args.steps, ranking[1][0], min_seconds=MIN_TIMED_SECONDS_HEADLINE)
         if agree_max([med_b["rate"] - med["rate"]])[0] > 0:
             mode, med, rows = ranking[1][0], med_b, rows_b
     # Host side of a window: what the C launch loop costs per launch (no synchronisation inside: the hardware queue holds a
@@ -865,8 +908,8 @@ def main():
             torch.cuda.synchronize()
         host_issue_us = agree_max([best / (args.steps * n_sub_i) * 1e6])[0]
     bucket_note = ", shape-bucketed (no padding)" if (args.bucketed and args.workload == "mixed") else \
-        (", padded 100x20, envs ordered by shape class" if (args.workload == "mixed" and args.by_shape) else
-         ", padded 100x20" if args.workload == "mixed" else "")
+        (", padded 100x20, envs ordered by shape class" if (args.workload == "mixed" and getattr(env, "_classes", None) is not None) else
+         ", padded 100x20, env i <- ta(1 + i % 80)" if args.workload == "mixed" else "")
     inst0 = builtin_instance(args.instance)
     out = {
         "metric": "env steps/sec (batched)", "value": med["rate"], "unit": "env steps/s", "n_gpus": world,
@@ -886,6 +929,9 @@ def main():
         "roofline": roofline(med, alg_per_step, args.steps, env,
                              ("mixed_bucketed" if env.launch == "grid" else None) if hasattr(env, "buckets") else key, B),
         "host_issue_us_per_launch": host_issue_us,
+        # per-rank view of the median window (a straggler GPU shows as value_min well under value / N)
+        "ranks": {"value_min": med["rank_rate_min"], "value_max": med["rank_rate_max"], "numa_pinned": numa.get("pinned"),
+                  "numa_node_rank0": numa.get("numa_node"), "cpus_rank0": numa.get("cpus")} if world > 1 else None,
         "episodes_finished": med["episodes"],
         "mean_makespan": med["makespan_sum"] / med["episodes"] if med["episodes"] else None,
         "mean_reward_per_step": (med["reward_num"] / inst0.max_time_op / med["steps"]) if (med["steps"] and args.workload == "shared") else None,
@@ -897,9 +943,11 @@ def main():
             m1 = pick_mode(env, args.policy, ["eager", "graph"]) if args.launch == "auto" else "eager"
             med1, rows1 = measure(env, args.policy, args.steps, m1)
             out["single_launch_per_step"] = {"value": med1["rate"], "min": rows1[0]["rate"], "max": rows1[-1]["rate"],
-                                             "kernel_ms": med1["kernel_ms"], "launch": launch_label(m1),
+                                             "gpu_ms_per_step_events": med1["gpu_ms_per_step_events"], "launch": launch_label(m1),
                                              "roofline_frac": roofline(med1, alg_per_step, args.steps, env, key, B)["frac"],
                                              "roofline_frac_gpu_time": roofline(med1, alg_per_step, args.steps, env, key, B)["frac_gpu_time"]}
+    if not args.no_extras and not args.extras and world == 1 and not hasattr(env, "buckets"):
+        out["step_only"] = step_only_measure(env, args.policy, alg_per_step, B, light=True)
     if args.extras and not hasattr(env, "buckets"):
         # fused multi-step rollout: 64 iterations per launch, state in registers, outputs once per launch
         n_l = max(4, args.steps // 16)
@@ -970,28 +1018,34 @@ def main():
         del env
         env = None
         x = bool(args.extras)                 # trajectory mode and the external-action forms of a config: --extras only
+        so = dict(with_step_only=not x)       # jss_step with the caller's actions next to every fused figure (light leg; --extras: the full one)
         extras = [
             ("config2_ta01_batch4096_random", dict(workload="shared", batch=4096, policy="random", modes=("eager", "graph"),
-                                                   with_trajectory=x, with_external=x)),
+                                                   with_trajectory=x, with_external=x, **so)),
             ("config3_ta41_spt_batch16384", dict(workload="shared", batch=16384, policy="SPT", instance="ta41", with_trajectory=x,
-                                                 with_external=x)),
+                                                 with_external=x, **so)),
             ("config4_synthetic50x20_batch8192", dict(workload="synthetic50x20", batch=8192, policy="random", with_trajectory=x,
-                                                      with_external=x)),
+                                                      with_external=x, **so)),
             ("config4_synthetic50x20_batch65536_one_gpu", dict(workload="synthetic50x20", batch=65536, policy="random",
                                                                label_extra=" -- all of config 4 on one GPU")),
-            ("config5_mixed_padded_batch32768", dict(workload="mixed", batch=32768, policy="random", label_extra=", padded 100x20",
-                                                     with_trajectory=x, with_external=x)),
-            ("config5_mixed_padded_by_shape_batch32768", dict(workload="mixed", batch=32768, policy="random", by_shape=True,
-                                                              modes=("eager", "sub2", "sub3"),
-                                                              label_extra=", padded 100x20, envs ordered by shape class: class-specialised bodies on the padded rows")),
+            # config 5 as a caller gets it: BatchedJssEnv([ta01 .. ta80], batch=32768) -- the constructor deals a ragged list out by
+            # shape class (order=None) -- and, next to it, the i % 80 order of rounds 1-5 (every env on the padded extents' kernel)
+            ("config5_mixed_padded_batch32768", dict(workload="mixed", batch=32768, policy="random", modes=("eager", "sub2", "sub3"),
+                                                     label_extra=", padded 100x20, default constructor (envs dealt out by shape class: "
+                                                                 "class-specialised bodies on the padded rows)",
+                                                     with_trajectory=x, with_external=x, **so)),
+            ("config5_mixed_padded_interleaved_batch32768", dict(workload="mixed", batch=32768, policy="random", order="interleaved",
+                                                                 label_extra=", padded 100x20, order='interleaved' (env i <- ta(1 + i % 80))")),
             ("config5_mixed_bucketed_batch32768", dict(workload="mixed", batch=32768, policy="random", bucketed=True,
                                                        label_extra=", shape-bucketed (no padding)")),
+            # north_star's "synthetic Taillard-shaped instances ... ta01-shape (15x15) at batch 65 536": one instance PER ENV (the
+            # headline shares ta01's table, staged in LDS, with 16-byte records; this one reads per-env tables, 24-byte records)
+            ("synthetic15x15_per_env_tables", dict(workload="synthetic15x15", batch=B, policy=args.policy, with_external=x, **so)),
         ]
         if x:
             extras += [
                 ("batch_x4", dict(workload="shared", batch=4 * B, policy=args.policy, instance=args.instance, modes=("eager", "sub2", "sub3"),
                                   label_extra=" -- 4x the batch (about 200 MB of state and outputs with compact records, plus the 236 MB solution tensor written one word per env step)")),
-                ("synthetic15x15_per_env_tables", dict(workload="synthetic15x15", batch=B, policy=args.policy)),
             ]
         for name, kw in extras:
             try:     # an extra that fails (memory on a busy box, ...) is reported, it does not cost the headline
@@ -1067,7 +1121,6 @@ def main():
     if env is not None and hasattr(env, "close"):
         env.close()
     del env
-    import gc
     gc.collect()
     torch.cuda.synchronize()
     if use_pg:

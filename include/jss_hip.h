@@ -242,9 +242,15 @@ extern "C" {
 
 /* JssDesc.kernel: JSS_KERNEL_AUTO packs 64/G envs per wavefront when every env of the batch fits a 16- or
  * 32-lane group (jmax, mmax <= 32) and uses one wavefront per env otherwise; JSS_KERNEL_WAVE forces one
- * wavefront per env (A/B runs, tests).  Per call, not per process.  The CPU twin ignores it. */
+ * wavefront per env (A/B runs, tests).  JSS_KERNEL_ONE_ENV_PER_WAVE (a bit, OR-ed in): the one-wavefront-per-env launches
+ * of the one-step calls (jss_step, jss_rollout(n_iter = 1), jss_rollout_steps, jss_multi_*) never let a wavefront serve two
+ * envs in turn -- what they do by default when a launch covers JSS_TWO_PER_WAVE_MIN_BATCH envs or more (one job per lane,
+ * per-env tables, full records; results identical either way: A/B runs, tests); JSS_KERNEL_TWO_ENVS_PER_WAVE: they do so
+ * whatever the size of the launch (tests on small batches).  Per call, not per process.  The CPU twin ignores the field. */
 #define JSS_KERNEL_AUTO 0
 #define JSS_KERNEL_WAVE 1
+#define JSS_KERNEL_ONE_ENV_PER_WAVE 2
+#define JSS_KERNEL_TWO_ENVS_PER_WAVE 4
 
 typedef struct JssDesc {
     int32_t batch;               /* B: envs in this shard                                   */
@@ -448,7 +454,7 @@ int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const J
  * flags = JSS_ROLLOUT_AUTORESET or 0), jss_multi_policy = jss_policy, jss_multi_rollout = n_steps x jss_rollout(n_iter = 1)
  * (n_steps launches per part, see below) -- results identical.  The fused grid covers sets with per-env instance tables
  * (n_tables > 1; full records, or medium records on the 16- / 32-lane shapes), 2 to 6 of them; any other combination is
- * issued as one plain launch per set on the same stream (same results).  `which` (jss_multi_reset) may be NULL, and so may
+ * issued as one plain launch per set (and part, below) in the same stream order (same results).  `which` (jss_multi_reset) may be NULL, and so may
  * its entries: every env of that set.  1 <= n_sets <= 16. */
 int jss_multi_reset(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
                     const uint8_t *const *which, void *stream);
@@ -458,7 +464,9 @@ int jss_multi_policy(int32_t n_sets, const JssDesc *const *descs, const JssState
                      uint32_t explore_q16, int32_t *const *actions, void *stream);
 /* n_sub, streams, JSS_ROLLOUT_FORK_JOIN as jss_rollout_steps: with n_sub > 1 every set is cut into n_sub contiguous parts
  * (at multiples of 64 envs; at most 4 are used) and part i of ALL sets is one grid per step on streams[i], so that one part's
- * drain overlaps another's fill; n_sub = 1 is one grid per step on streams[0]. */
+ * drain overlaps another's fill; n_sub = 1 is one grid per step on streams[0].  Sets without a body in the fused grid are cut
+ * into the same parts, part i of every set as plain launches on streams[i].  n_steps == 0 launches nothing and touches nothing
+ * (jss_rollout_steps, jss_rollout_steps_multi and jss_policy_step_steps likewise; both libraries). */
 int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssState *const *states, const JssOut *const *outs,
                       int kind, uint64_t seed, uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub,
                       void *const *streams);

@@ -52,7 +52,10 @@ POLICY_CR_F64 = POLICY["CR"] | (1 << 24)    # JSS_POLICY_CR_F64: the factor trav
 def policy_code(kind):
     """str | int -> the int the C ABI takes."""
     return POLICY[kind] if isinstance(kind, str) else int(kind)
-KERNEL = {"auto": 0, "wave": 1}
+# JssDesc.kernel: "wave" forces one wavefront per env; the "...-1env" forms add JSS_KERNEL_ONE_ENV_PER_WAVE (a wavefront of the
+# one-step launches never serves two envs in turn: A/B runs, tests)
+# ("...-2env": JSS_KERNEL_TWO_ENVS_PER_WAVE, they always do -- tests on small batches)
+KERNEL = {"auto": 0, "wave": 1, "auto-1env": 2, "wave-1env": 3, "auto-2env": 4, "wave-2env": 5}
 E_NULL, E_SHAPE, E_KIND, E_LDS, E_RESIDENT, E_SESSION = -1, -2, -3, -4, -5, -6
 MAX_SUB_BATCHES = 16
 

@@ -360,9 +360,16 @@ constexpr int kCrNone = 1 << 20;
 // JSS_POLICY_CR_F64: the reference's float64 expression itself (dispatching.py:351-363, :391-398) -- due date = length *
 // factor, ratio = (due date - now) / remaining -- every operation rounded on its own (no fused multiply-add), so that the
 // doubles, their order and their ties are the reference's.  Smallest ratio first, lowest job index on ties (strict `<`, :399).
+// (ROCm's __dmul_rn / __dsub_rn are plain `*` / `-`, and hipcc's default -ffp-contract=fast-honor-pragmas fuses them into one
+//  v_fma_f64 -- a single rounding, one ulp away from the reference whenever `now` is close to the due date: length 100,
+//  factor 1.2, now 120 gives 0.0 unfused and -4.4e-15 fused.  The pragma has to sit in THIS body: the operations are inlined
+//  from here, a pragma at the call site does not reach them.  parity_cases.case_cr_f64_unfused holds that state.)
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ double cr_ratio_f64(int length, double factor, int now, int remaining) {
-    return __ddiv_rn(__dsub_rn(__dmul_rn((double)length, factor), (double)now), (double)remaining);
+#pragma clang fp contract(off)
+    const double due = (double)length * factor;
+    const double left = due - (double)now;
+    return left / (double)remaining;
 }
 #else
 __device__ __forceinline__ double cr_ratio_f64(int length, double factor, int now, int remaining) {

@@ -702,7 +702,7 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
         d->n_tables < 1)
         return JSS_E_SHAPE;
     if (!d->table_of_env && d->n_tables != 1 && d->n_tables != d->batch) return JSS_E_SHAPE;
-    if (d->kernel != JSS_KERNEL_AUTO && d->kernel != JSS_KERNEL_WAVE) return JSS_E_KIND;
+    if (d->kernel & ~(JSS_KERNEL_WAVE | JSS_KERNEL_ONE_ENV_PER_WAVE | JSS_KERNEL_TWO_ENVS_PER_WAVE)) return JSS_E_KIND;
     if (d->record_ints != 0 && d->record_ints != JSS_NF && d->record_ints != JSS_NFC && d->record_ints != JSS_NFM) return JSS_E_SHAPE;
     if (d->record_ints == JSS_NFC && d->n_tables != 1) return JSS_E_SHAPE;
     if (d->record_ints == JSS_NFM && (d->mmax > 32 || d->n_tables == 1)) return JSS_E_SHAPE;
@@ -917,6 +917,10 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
                       uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub, void *const *streams) {
     if (n_steps < 0 || n_sub < 1 || n_sub > 16) return desc && state ? JSS_E_SHAPE : JSS_E_NULL;
     if (!streams) return JSS_E_NULL;
+    if (n_steps == 0) {                               // no step: nothing is touched (the HIP library launches nothing); arguments checked
+        const int rc = check_args(desc, state, out, true);
+        return rc ? rc : check_kind(desc, kind);
+    }
     return jss_rollout(desc, state, out, kind, seed, explore_q16, n_steps, flags, nullptr);
 }
 
@@ -942,7 +946,10 @@ int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const J
     if (!descs || !states || !outs || !streams) return JSS_E_NULL;
     if (n_sets < 1 || n_sets > 16 || n_steps < 0) return JSS_E_SHAPE;
     for (int i = 0; i < n_sets; ++i) {
-        const int rc = jss_rollout(descs[i], states[i], outs[i], kind, seed, explore_q16, n_steps, flags & JSS_ROLLOUT_AUTORESET, nullptr);
+        int rc = check_args(descs[i], states[i], outs[i], true);
+        if (!rc) rc = check_kind(descs[i], kind);
+        if (!rc && n_steps > 0)                       // (n_steps == 0: nothing is touched, like the HIP library, which launches nothing)
+            rc = jss_rollout(descs[i], states[i], outs[i], kind, seed, explore_q16, n_steps, flags & JSS_ROLLOUT_AUTORESET, nullptr);
         if (rc) return rc;
     }
     return 0;
@@ -990,7 +997,10 @@ int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssStat
     if (n_sets < 1 || n_sets > 16 || n_steps < 0 || n_sub < 1 || n_sub > 16) return JSS_E_SHAPE;
     void *stream = nullptr;
     for (int i = 0; i < n_sets; ++i) {       // n_steps x rollout(n_iter = 1) == rollout(n_iter = n_steps) on the state; `out` holds the last step either way
-        const int rc = jss_rollout(descs[i], states[i], outs[i], kind, seed, explore_q16, n_steps, flags & JSS_ROLLOUT_AUTORESET, stream);
+        int rc = check_args(descs[i], states[i], outs[i], true);
+        if (!rc) rc = check_kind(descs[i], kind);
+        if (!rc && n_steps > 0)                       // (n_steps == 0: nothing is touched, like the HIP library, which launches nothing)
+            rc = jss_rollout(descs[i], states[i], outs[i], kind, seed, explore_q16, n_steps, flags & JSS_ROLLOUT_AUTORESET, stream);
         if (rc) return rc;
     }
     return 0;

@@ -29,7 +29,7 @@ int check_args(const JssDesc *d, const JssState *s, const JssOut *o, bool need_o
         d->n_tables < 1)
         return JSS_E_SHAPE;
     if (!d->table_of_env && d->n_tables != 1 && d->n_tables != d->batch) return JSS_E_SHAPE;
-    if (d->kernel != JSS_KERNEL_AUTO && d->kernel != JSS_KERNEL_WAVE) return JSS_E_KIND;
+    if (d->kernel & ~(JSS_KERNEL_WAVE | JSS_KERNEL_ONE_ENV_PER_WAVE | JSS_KERNEL_TWO_ENVS_PER_WAVE)) return JSS_E_KIND;
     if (d->record_ints != 0 && d->record_ints != JSS_NF && d->record_ints != JSS_NFC && d->record_ints != JSS_NFM) return JSS_E_SHAPE;
     if (d->record_ints == JSS_NFC && d->n_tables != 1) return JSS_E_SHAPE;   // compact records need the ONE table in LDS
     // medium records: 21-bit ops (machines <= 32, whatever the number of jobs), per-env tables
@@ -108,7 +108,7 @@ unsigned long long *g_stamps = nullptr;
 int class_jobs(const JssDesc &d, bool by_class) { return by_class && d.jclass > 0 ? d.jclass : d.jmax; }
 int class_machines(const JssDesc &d, bool by_class) { return by_class && d.mclass > 0 ? d.mclass : d.mmax; }
 int packed_group(const JssDesc &d, bool by_class = false) {
-    if (d.kernel == JSS_KERNEL_WAVE) return 0;
+    if (d.kernel & JSS_KERNEL_WAVE) return 0;
     const int j = class_jobs(d, by_class), m = class_machines(d, by_class);
     if (j <= 16 && m <= 16) return 16;
     if (j <= 32 && m <= 32) return 32;
@@ -116,6 +116,24 @@ int packed_group(const JssDesc &d, bool by_class = false) {
 }
 
 using KernelFn = void (*)(Params);
+
+// Two envs per wavefront, one after the other (jss_wave_env.hpp, wave_block2): the one-step modes of the one-wavefront-per-env
+// flavour with one job per lane, per-env tables and full records.  Measured (profiles/r06_misc/two_per_wave_ab.txt,
+// wave_timeline_two_per_wave.txt): with half the wavefronts a launch of 8 192 envs is 15-18 % SLOWER (4 wavefronts per SIMD are
+// latency-bound: a wavefront's two steps take 26.7 k cycles where one took 16.3 k), 16 384 envs 9-10 % slower, and only from
+// about three rounds of resident wavefronts per launch on does the form come out ahead (65 536 envs in two or three
+// sub-batches: +6-7 %) -- there the second env's state arrives under the first env's step instead of at the head of a new
+// wavefront's life.  Hence the threshold; JssDesc.kernel's JSS_KERNEL_ONE / TWO_ENVS_PER_WAVE bits override it per call.
+#ifndef JSS_TWO_PER_WAVE_MIN_BATCH
+#define JSS_TWO_PER_WAVE_MIN_BATCH 20480
+#endif
+template <int MODE>
+bool two_per_wave(const JssDesc &d, int G, int class_j) {
+    if (MODE != kRollout1 && MODE != kStep) return false;
+    if (G || class_j > kWave || d.n_tables == 1 || d.record_ints == JSS_NFM) return false;
+    if (d.kernel & JSS_KERNEL_ONE_ENV_PER_WAVE) return false;
+    return (d.kernel & JSS_KERNEL_TWO_ENVS_PER_WAVE) || d.batch >= JSS_TWO_PER_WAVE_MIN_BATCH;
+}
 
 template <int MODE, int TAB>
 KernelFn pick_tab(int G, int jpl) {
@@ -130,10 +148,17 @@ KernelFn pick(int G, int jpl, bool shared, int record_ints) {
     return record_ints == JSS_NFC ? pick_tab<MODE, kTabLdsC>(G, jpl) : pick_tab<MODE, kTabLds>(G, jpl);
 }
 
+template <int MODE>
+KernelFn pick_two() {       // (instantiated for the one-step modes only)
+    if constexpr (MODE == kRollout1 || MODE == kStep) return jss_kernel_two<MODE, kTabGlobal>;
+    else return nullptr;
+}
+
 struct LaunchPlan {
     KernelFn fn;
     int envs_per_block;
     size_t shmem;
+    bool two;               // one-wavefront-per-env flavour, two envs per wavefront
 };
 
 constexpr size_t kMaxDynamicLds = 64 * 1024;   // available to a workgroup without raising the function attribute
@@ -145,6 +170,7 @@ int plan(Params &p, LaunchPlan &lp, bool by_class = false) {
     p.region_ints = p.d.jmax * p.d.mmax;
     p.table_lds_ints = shared ? ((p.region_ints + 3) & ~3) : 0;
     const int G = packed_group(p.d, by_class);
+    lp.two = false;
     if (G) {
         lp.envs_per_block = (kWave / G) * kWavesPerBlock;
         p.obs_wave_floats = ((kWave / G) * (p.d.jmax < G ? p.d.jmax : G) * 7 + 3) & ~3;      // (jmax > G: a class inside padded rows)
@@ -152,7 +178,8 @@ int plan(Params &p, LaunchPlan &lp, bool by_class = false) {
         p.norm_off_ints = p.mv_off_ints + kBlock;                       // one int per lane (six used per group), kTabGlobal
         lp.shmem = sizeof(int32_t) * ((size_t)p.norm_off_ints + (shared ? 0 : kBlock));
     } else {
-        lp.envs_per_block = kWavesPerBlock;
+        lp.two = !by_class && two_per_wave<MODE>(p.d, G, p.d.jmax);      // (the fused grid keeps one env per wavefront: its classes are parts of a batch)
+        lp.envs_per_block = kWavesPerBlock * (lp.two ? 2 : 1);
         p.obs_wave_floats = (p.d.jmax * 7 + 3 + 3) & ~3;               // + up to 3 floats of alignment shift (store_obs)
         if (p.obs_wave_floats < kWave) p.obs_wave_floats = kWave;      // unpack_env borrows it: one int per machine
         p.mv_off_ints = 0;
@@ -165,7 +192,7 @@ int plan(Params &p, LaunchPlan &lp, bool by_class = false) {
     lp.shmem += g_lds_pad;
 #endif
     if (lp.shmem > kMaxDynamicLds) return JSS_E_LDS;
-    lp.fn = by_class ? nullptr : pick<MODE>(G, p.d.jmax <= kWave ? 1 : 2, shared, p.d.record_ints);   // (the grid has its own kernel)
+    lp.fn = by_class ? nullptr : lp.two ? pick_two<MODE>() : pick<MODE>(G, p.d.jmax <= kWave ? 1 : 2, shared, p.d.record_ints);   // (the grid has its own kernel)
     return 0;
 }
 
@@ -415,18 +442,45 @@ template <int MODE>
 int launch_multi(Params *ps, int n, int n_steps, int n_sub, void *const *streams, bool fork_join) {
     bool fused = n >= 2 && n <= kMultiMaxSets;
     for (int i = 0; i < n && fused; ++i) fused = multi_flavour(ps[i].d) != kMfNone;
+    constexpr int kMaxParts = 4;
+    if (n_sub > kMaxParts) n_sub = kMaxParts;
     if (!fused) {
+        // No fused body for this combination (a shared-table set, medium records on the one-wavefront-per-env shapes, more
+        // than kMultiMaxSets sets): one plain launch per set, part and step -- parts and streams exactly as in the fused form
+        // (part i of every set on streams[i], JSS_ROLLOUT_FORK_JOIN honoured), so that a caller who asked for overlap gets it.
+        // (The reset / policy modes come here with n_sub == 1: sub_batch describes a part for the step-type modes only.)
+        struct Item { int set; Params p; };
+        static Item items[kMaxParts][16];                                 // (0.5 KB each: not on the stack of every caller)
+        static std::mutex items_mutex;
+        std::lock_guard<std::mutex> lock(items_mutex);
         LaunchPlan lps[16];
+        int count[kMaxParts] = {}, parts = 0;
         for (int i = 0; i < n; ++i) {
-            const int rc = plan<MODE>(ps[i], lps[i]);
+            const int rc = plan<MODE>(ps[i], lps[i]);                    // (the plan of a set serves its parts: fire() sizes the grid)
             if (rc) return rc;
         }
-        for (int s = 0; s < n_steps; ++s)
+        for (int part = 0; part < n_sub; ++part) {
+            int k = 0;
             for (int i = 0; i < n; ++i) {
-                const int rc = fire(ps[i], lps[i], streams[0]);
-                if (rc) return rc;
+                const Params &whole = ps[i];
+                if (n_sub == 1) { items[parts][k++] = Item{i, whole}; continue; }
+                const int chunk = (((whole.d.batch + n_sub - 1) / n_sub) + 63) & ~63;
+                const int start = part * chunk;
+                if (start >= whole.d.batch) continue;
+                items[parts][k++] = Item{i, sub_batch(whole, start, whole.d.batch - start < chunk ? whole.d.batch - start : chunk)};
             }
-        return 0;
+            if (k) count[parts++] = k;
+        }
+        if (parts == 0) return 0;
+        ForkJoinEvents *ev = nullptr;
+        int rc = 0;
+        fork_join = fork_join && parts > 1;
+        if (fork_join && ((rc = events_for(streams[0], &ev)) || (rc = fork_streams(*ev, streams, parts)))) return rc;
+        for (int s = 0; s < n_steps && !rc; ++s)
+            for (int part = 0; part < parts && !rc; ++part)
+                for (int k = 0; k < count[part] && !rc; ++k) rc = fire(items[part][k].p, lps[items[part][k].set], streams[part]);
+        const int jrc = fork_join ? join_streams(*ev, streams, parts) : 0;
+        return rc ? rc : jrc;
     }
     int order[kMultiMaxSets];
     for (int i = 0; i < n; ++i) order[i] = i;
@@ -434,8 +488,6 @@ int launch_multi(Params *ps, int n, int n_steps, int n_sub, void *const *streams
         for (int j = i; j > 0 && multi_flavour(ps[order[j]].d) < multi_flavour(ps[order[j - 1]].d); --j) {
             const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
         }
-    constexpr int kMaxParts = 4;
-    if (n_sub > kMaxParts) n_sub = kMaxParts;
     static MultiParams mp[kMaxParts];                                    // (2 KB each: not on the stack of every caller)
     static std::mutex mp_mutex;
     std::lock_guard<std::mutex> lock(mp_mutex);
@@ -450,13 +502,14 @@ int launch_multi(Params *ps, int n, int n_steps, int n_sub, void *const *streams
             const int start = part * chunk;
             if (start >= whole.d.batch) continue;
             LaunchPlan lp;
-            const int rc = plan<MODE>(whole, lp, true);                  // (fills the LDS layout fields of `whole`; class-aware)
-            if (rc) return rc;
             Params p = n_sub == 1 ? whole : sub_batch(whole, start, whole.d.batch - start < chunk ? whole.d.batch - start : chunk);
+            const int rc = plan<MODE>(p, lp, true);                      // (fills the LDS layout fields; class-aware; sized for THIS part)
+            if (rc) return rc;
             nb += (p.d.batch + lp.envs_per_block - 1) / lp.envs_per_block;
             m.p[k] = p;
             m.block_end[k] = nb;
             m.flavour[k] = multi_flavour(p.d);
+
             if (lp.shmem > shmem) shmem = lp.shmem;
             ++k;
         }
@@ -714,6 +767,7 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
     if ((rc = check_kind(desc, kind))) return rc;
     if (n_steps < 0 || n_sub < 1 || n_sub > 16) return JSS_E_SHAPE;
     if (!streams) return JSS_E_NULL;
+    if (n_steps == 0) return 0;                       // no step: nothing is launched, nothing is touched (both libraries)
     Params p = {};
     p.d = *desc; p.s = *state; p.o = *out; p.kind = kind; p.seed = seed; p.explore_q16 = explore_q16;
     p.n_iter = 1; p.flags = flags & ~JSS_ROLLOUT_FORK_JOIN;
@@ -728,6 +782,7 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
         if (start >= desc->batch) break;
         sub[n++] = sub_batch(p, start, desc->batch - start < chunk ? desc->batch - start : chunk);
     }
+    if (n > 1 && (rc = plan<kRollout1>(sub[0], lp))) return rc;         // the kernel form goes by the size of a LAUNCH (two_per_wave)
     const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n > 1;
     ForkJoinEvents *ev = nullptr;
     if (fork_join && ((rc = events_for(streams[0], &ev)) || (rc = fork_streams(*ev, streams, n)))) return rc;
@@ -745,6 +800,7 @@ int jss_policy_step_steps(const JssDesc *desc, const JssState *state, const JssO
     if ((rc = check_kind(desc, kind, true))) return rc;
     if (n_steps < 0 || n_sub < 1 || n_sub > 16) return JSS_E_SHAPE;
     if (!streams || !actions) return JSS_E_NULL;
+    if (n_steps == 0) return 0;
     Params pp = {}, ps = {};
     pp.d = *desc; pp.s = *state; pp.actions_out = actions; pp.kind = kind; pp.seed = seed; pp.explore_q16 = explore_q16;
     ps.d = *desc; ps.s = *state; ps.o = *out; ps.actions = actions; ps.flags = flags & JSS_ROLLOUT_AUTORESET;
@@ -763,6 +819,7 @@ int jss_policy_step_steps(const JssDesc *desc, const JssState *state, const JssO
         subs[n].actions = actions + start;
         ++n;
     }
+    if (n > 1 && (rc = plan<kStep>(subs[0], lps))) return rc;           // the kernel form goes by the size of a LAUNCH (two_per_wave)
     const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n > 1;
     ForkJoinEvents *ev = nullptr;
     if (fork_join && ((rc = events_for(streams[0], &ev)) || (rc = fork_streams(*ev, streams, n)))) return rc;
@@ -825,9 +882,11 @@ int jss_multi_rollout(int32_t n_sets, const JssDesc *const *descs, const JssStat
     if (rc) return rc;
     if (n_steps < 0 || n_sub < 1 || n_sub > 16) return JSS_E_SHAPE;
     if (!streams) return JSS_E_NULL;
+    for (int i = 0; i < n_sets; ++i)
+        if ((rc = check_kind(descs[i], kind))) return rc;
+    if (n_steps == 0) return 0;                       // no step: nothing is launched, nothing is touched (both libraries)
     Params ps[16];
     for (int i = 0; i < n_sets; ++i) {
-        if ((rc = check_kind(descs[i], kind))) return rc;
         ps[i] = {};
         ps[i].d = *descs[i]; ps[i].s = *states[i]; ps[i].o = *outs[i]; ps[i].kind = kind; ps[i].seed = seed;
         ps[i].explore_q16 = explore_q16; ps[i].n_iter = 1; ps[i].flags = flags & JSS_ROLLOUT_AUTORESET;
@@ -842,6 +901,7 @@ int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const J
     if (n_sets < 1 || n_sets > 16 || n_steps < 0) return JSS_E_SHAPE;
     Params ps[16];
     LaunchPlan lps[16];
+    const bool nothing = n_steps == 0;                // (arguments are still checked)
     for (int i = 0; i < n_sets; ++i) {
         int rc = check_args(descs[i], states[i], outs[i], true);
         if (rc) return rc;
@@ -852,6 +912,7 @@ int jss_rollout_steps_multi(int32_t n_sets, const JssDesc *const *descs, const J
         p.n_iter = 1; p.flags = flags & ~JSS_ROLLOUT_FORK_JOIN;
         if ((rc = plan<kRollout1>(p, lps[i]))) return rc;
     }
+    if (nothing) return 0;
     const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n_sets > 1;
     ForkJoinEvents *ev = nullptr;
     int rc = 0;

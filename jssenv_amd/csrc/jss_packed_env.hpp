@@ -736,6 +736,15 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
         // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
         if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
         if (fresh || hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) st_off(jb, jo + 16u, hi);
+        // A class of small instances inside wider padded rows (jmax > G: the fused grid's PADDED bodies): a reset leaves the rows
+        // behind the lane group as "no job" records too, like the reset of the padded extents' kernel, the session's write-back
+        // and the host twin do -- whichever path (re)initialised an env, its padded block holds the same bytes (a few KB per
+        // EPISODE; the steps never touch those rows).
+        if (fresh)
+            for (unsigned r = (unsigned)c.gl + G; r < jm; r += G) {
+                st_off(jb, (c.rel * jm + r) * 32u, make_int4(0, -1, 0, 0));
+                st_off(jb, (c.rel * jm + r) * 32u + 16u, make_int4(0, 0, 0, -1));
+            }
     }
 }
 

@@ -795,6 +795,13 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
                 st_off<int4>(jb, (unsigned)j * 32u, lo);
                 st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
             }
+            // a one-job-per-lane body inside rows wider than its 64 lanes (a class of the fused grid on padded tensors): the rows
+            // behind the lanes as "no job" records too, like the full-width reset writes them (same bytes whichever path resets)
+            if (s == JPL - 1)
+                for (int r = JPL * kWave + c.lane; r < jm; r += kWave) {
+                    st_off<int4>(jb, (unsigned)r * 32u, make_int4(0, -1, 0, 0));
+                    st_off<int4>(jb, (unsigned)r * 32u + 16u, make_int4(0, 0, 0, -1));
+                }
         } else if (j < c.J) {   // steps without a time advance touch few jobs
             const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
             if (lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w) st_off<int4>(jb, (unsigned)j * 32u, lo);
@@ -966,16 +973,48 @@ __device__ __forceinline__ bool step_call(Env<JPL> &e, Header &hd, Ctx &c, const
 }
 
 // ---------------------------------------------------------------------------------------
-// one env, one mode: everything behind "the header words are on their way"
+// one env, one mode: everything behind "the header words are on their way", in two halves -- wave_issue (the state loads of a
+// step-type call: nothing is waited for but, on ragged batches, the header word that says how many rows there are) and
+// wave_finish (everything else).  A wavefront that serves two envs (wave_block, EPW = 2) issues both envs' loads before it
+// finishes the first.
 // ---------------------------------------------------------------------------------------
-template <int JPL, int MODE, int TAB>
-__device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderWords &h, bool ragged, int a_in,
-                                          const int32_t *lds, float *scratch) {
+template <int JPL, int TAB>
+__device__ __forceinline__ RawEnv<JPL> wave_issue(const Params &p, int b, int lane, const HeaderWords &h, bool ragged) {
+    // the addresses depend on nothing but the env index -- unless the batch is ragged (jmin < jmax): then the rows behind
+    // J(env), known from the header, are never requested
+    return issue_loads<JPL, TAB>(b, lane, p, ragged ? __builtin_amdgcn_readfirstlane(h.J) : p.d.jmax);
+}
+
+// "These loads have landed": an empty asm that reads every register of `r`, so that the s_waitcnt for them is placed HERE.
+// vmcnt counts loads and stores alike on this architecture and retires in order: a wait for a load that is placed behind
+// stores of unknown number (the store loops of the observation) has to wait for every one of them -- vmcnt(0).  A wavefront
+// that serves two envs therefore claims its second env's records after the first env's compute and BEFORE the first env's
+// stores are issued: nothing but loads is outstanding then, and they have had the whole first step to arrive.
+template <int JPL>
+__device__ __forceinline__ void loads_landed(const RawEnv<JPL> &r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("; jss loads_landed tm %0" ::"v"(r.tm));
+#pragma unroll
+    for (int s = 0; s < JPL; ++s)
+        asm volatile("; jss loads_landed %0 %1 %2 %3 %4 %5 %6 %7" ::"v"(r.lo[s].x), "v"(r.lo[s].y), "v"(r.lo[s].z), "v"(r.lo[s].w), "v"(r.hi[s].x), "v"(r.hi[s].y), "v"(r.hi[s].z), "v"(r.hi[s].w));
+#else
+    (void)r;
+#endif
+}
+
+// `next`: the records of the env this wavefront serves after this one (wave_block2), claimed before this env's epilogue stores
+// (else NULL).  The claim sits at ONE point that every path to the next env runs through -- compute first, under `live`, then
+// the claim, then the stores, under `live` again: with an early return in front of it the waits of the two paths merge at the
+// join and the second env starts with an s_waitcnt for the first env's stores after all.
+// (NEXT = false, one env per wavefront: `live` false returns on the spot -- the form, and the code, these kernels always had)
+template <int JPL, int MODE, int TAB, bool NEXT = false>
+__device__ __forceinline__ void wave_finish(const Params &p, Ctx &c, const HeaderWords &h, RawEnv<JPL> raw, int a_in,
+                                            const int32_t *lds, float *scratch, const RawEnv<JPL> *next = nullptr) {
     const int b = c.b, lane = c.lane;
-    Header hd;
-    Env<JPL> e;
-    RawEnv<JPL> raw;
+    Header hd = {0, 0};
+    Env<JPL> e = {};
     bool fresh = false;                                                  // the env was (re)initialised by this call
+    bool live = true;                                                    // false: never reset -- nothing to step, nothing to store
     if (MODE == kReset) {
         // nothing of the old state is needed but the episode counter
         raw = blank_raw<JPL, TAB>();
@@ -989,28 +1028,30 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
             p.o.done[b] = 0;
         }
     } else {
-        // 1. state loads: their addresses depend on nothing but the env index -- unless the batch is ragged
-        //    (jmin < jmax): then the rows behind J(env), known from the header, are never requested
-        if (!ragged) raw = issue_loads<JPL, TAB>(b, lane, p, p.d.jmax);
         ctx_from_header(c, h);
-        if (ragged) raw = issue_loads<JPL, TAB>(b, lane, p, c.J);
-        if (c.J == 0) return;                                            // never reset: nothing to step
-        ctx_table<TAB>(c, p, lds);
-        hd.episode = __builtin_amdgcn_readfirstlane(h.episode);
-        hd.step = __builtin_amdgcn_readfirstlane(h.step);
-        if (MODE == kStep || MODE == kAdvance) {                         // no policy keys an RNG with them here: only the header
-            hd.episode = in_vgpr(hd.episode);                            // store at the very end reads them -- out of the scalar
-            hd.step = in_vgpr(hd.step);                                  // register file, which these kernels run out of
+        live = c.J != 0;
+        if (!NEXT && !live) return;
+        if (live) {
+            ctx_table<TAB>(c, p, lds);
+            hd.episode = __builtin_amdgcn_readfirstlane(h.episode);
+            hd.step = __builtin_amdgcn_readfirstlane(h.step);
+            if (MODE == kStep || MODE == kAdvance) {                     // no policy keys an RNG with them here: only the header
+                hd.episode = in_vgpr(hd.episode);                        // store at the very end reads them -- out of the scalar
+                hd.step = in_vgpr(hd.step);                              // register file, which these kernels run out of
+            }
+            JSS_STAMP(p, b, 1, c.J);
+            unpack_env<JPL, TAB>(e, c, raw, __builtin_amdgcn_readfirstlane(h.clock), __builtin_amdgcn_readfirstlane(h.status),
+                                 reinterpret_cast<int32_t *>(scratch));
+            JSS_STAMP(p, b, 2, e.left[0] + e.idle[0] + e.tm);
         }
-        JSS_STAMP(p, b, 1, c.J);
-        unpack_env<JPL, TAB>(e, c, raw, __builtin_amdgcn_readfirstlane(h.clock), __builtin_amdgcn_readfirstlane(h.status),
-                             reinterpret_cast<int32_t *>(scratch));
-        JSS_STAMP(p, b, 2, e.left[0] + e.idle[0] + e.tm);
     }
 
-    if (MODE == kStep) {                                                 // (JSS_ACTION_RESET never gets here: jss_kernel)
-        const StepResult r = step_compute<JPL, TAB, false, false>(e, hd, c, p, lds, a_in);
-        step_outputs<JPL, false>(e, c, p, r);
+    StepResult sr = {0, false, false, false};                            // kStep
+    int n_steps = 0, n_done = 0, sum_makespan = 0, sum_rn = 0, last_rn = 0, last_makespan = -1;   // the rollouts
+    if (!live) {
+        // nothing
+    } else if (MODE == kStep) {                                          // (JSS_ACTION_RESET never gets here: jss_kernel)
+        sr = step_compute<JPL, TAB, false, false>(e, hd, c, p, lds, a_in);
     } else if (MODE == kSteps) {
         // n_iter x jss_step with the actions given up front: the state stays in registers, every step optionally recorded
         for (int it = 0; it < p.n_iter; ++it) {
@@ -1039,8 +1080,6 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
     } else if (MODE == kRollout || MODE == kRollout1 || MODE == kTraj) {
         // n_iter x (policy + step), state stays in registers; kTraj also records every iteration (JssTraj)
         const uint64_t env_id = (uint64_t)(p.d.env_ids ? p.d.env_ids[b] : p.d.env_id_base + b);
-        int n_steps = 0, n_done = 0, sum_makespan = 0, sum_rn = 0;
-        int last_rn = 0, last_makespan = -1;
         const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;
         for (int it = 0; it < n_iter; ++it) {
             const size_t slot = (size_t)it * p.d.batch + b;              // kTraj: [it][b]
@@ -1083,6 +1122,13 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
                 if (p.t.done) p.t.done[slot] = done ? 1 : 0;
             }
         }
+    }
+    if (NEXT) loads_landed(*next);
+    if (!live) return;
+    // ---- the epilogue: the env's scalar outputs, its state, mask and observation ----
+    if (MODE == kStep) {
+        step_outputs<JPL, false>(e, c, p, sr);
+    } else if (MODE == kRollout || MODE == kRollout1 || MODE == kTraj) {
         if (lane == 0) {
             if (n_steps) p.o.reward[b] = reward_of(last_rn, c);
             p.o.done[b] = any_legal(e) ? 0 : 1;
@@ -1096,6 +1142,14 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
         store_obs(e, c, p.o.real_obs + (size_t)b * p.d.jmax * 7, scratch, fresh ? imin(p.d.jmax, JPL * kWave) : c.J);   // (a one-job-per-lane
     JSS_STAMP(p, b, 6, e.t);                                     //  body inside wider rows owns the first 64: the fused grid's classes)
+}
+
+template <int JPL, int MODE, int TAB>
+__device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderWords &h, bool ragged, int a_in,
+                                          const int32_t *lds, float *scratch) {
+    RawEnv<JPL> raw;
+    if (MODE != kReset) raw = wave_issue<JPL, TAB>(p, c.b, c.lane, h, ragged);   // (a reset reads nothing)
+    wave_finish<JPL, MODE, TAB>(p, c, h, raw, a_in, lds, scratch);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1190,6 +1244,79 @@ __global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel
     wave_block<JPL, MODE, TAB>(p, (int)blockIdx.x, lds);
 }
 
+// ---------------------------------------------------------------------------------------
+// Two envs per wavefront, one after the other (round 6).  A launch of the one-env-per-wavefront kernel over one round of
+// resident waves is load burst -> compute -> store burst, strictly one after the other, because every wave is in the same
+// phase at the same time (profiles/r05_misc/wave_timeline.txt: 4.4 k of a wave's 15.7 k cycles go by before its state has
+// arrived, 8 192 waves asking for 15 MB at once).  Here a wavefront owns envs 2w and 2w + 1: it asks for BOTH envs' headers and
+// state up front, steps the first while the second's state is on its way, claims the second's records before it issues the
+// first env's stores (loads_landed), and the first env's stores drain under the second env's compute.  Same instructions per
+// env, 9 more live VGPRs (the second env's raw records) and its 14 header words.  What it buys, measured
+// (profiles/r06_misc/two_per_wave_ab.txt, wave_timeline_two_per_wave.txt): NOT the one-round launch it was built for -- at
+// 8 192 envs half as many wavefronts (4 per SIMD) are latency-bound, a wavefront's two steps take 26.7 k cycles against 16.3 k
+// for one, the launch is 15-18 % slower -- but launches of several rounds (65 536 envs in sub-batches: +6-7 %), where the
+// second env's state arrives under the first env's step instead of at the head of a new wavefront's life.  The library uses it
+// from JSS_TWO_PER_WAVE_MIN_BATCH envs per launch on (jss_kernels.hip).  One job per lane, the one-step modes (kRollout1, kStep).
+// ---------------------------------------------------------------------------------------
+template <int MODE, int TAB>
+__device__ __forceinline__ void wave_one_of_two(const Params &p, int b, int lane, const HeaderWords &h, const RawEnv<1> &raw, int a_in,
+                                                const int32_t *lds, float *scratch, const RawEnv<1> *next) {
+    Ctx c;
+    c.b = b;
+    c.lane = lane;
+    if (MODE == kStep && a_in == JSS_ACTION_RESET) {                     // (see wave_block: the reset body, nothing of `raw` is used)
+        if (next) loads_landed(*next);                                   // (the reset body is all stores)
+        if (__builtin_amdgcn_readfirstlane(h.J) == 0) return;
+        const int tid = tab_in_lds(TAB) ? 0 : __builtin_amdgcn_readfirstlane(p.d.table_of_env ? p.d.table_of_env[b] : h.tid);
+        ctx_from_instance(c, p, tid);
+        wave_finish<1, kReset, TAB>(p, c, h, raw, a_in, lds, scratch);
+    } else {
+        if (next) wave_finish<1, MODE, TAB, true>(p, c, h, raw, a_in, lds, scratch, next);
+        else wave_finish<1, MODE, TAB>(p, c, h, raw, a_in, lds, scratch);
+    }
+}
+
+template <int MODE, int TAB>
+__device__ __forceinline__ void wave_block2(const Params &p, int block, int32_t *lds) {
+    static_assert(MODE == kRollout1 || MODE == kStep, "two envs per wavefront: the one-step modes");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *scratch = reinterpret_cast<float *>(lds + p.table_lds_ints) + wave * p.obs_wave_floats;
+    const int first = (block * kWavesPerBlock + wave) * 2;               // envs `first` and `first + 1`
+    const bool alive0 = first < p.d.batch, alive1 = first + 1 < p.d.batch;
+    const int b0 = alive0 ? first : p.d.batch - 1, b1 = alive1 ? first + 1 : p.d.batch - 1;   // (clamped: the loads stay in bounds)
+    JSS_STAMP(p, b0, 0, lane);
+    if (alive1) JSS_STAMP(p, b1, 0, lane);
+    const HeaderWords h0 = load_header(p, b0), h1 = load_header(p, b1);
+    int a0 = JSS_ACTION_SKIP, a1 = JSS_ACTION_SKIP;
+    if (MODE == kStep) {
+        a0 = __builtin_amdgcn_readfirstlane(p.actions[b0]);
+        a1 = __builtin_amdgcn_readfirstlane(p.actions[b1]);
+        if (p.flags & JSS_ROLLOUT_AUTORESET) {                           // jss_step_autoreset (wave_block)
+            if (__builtin_amdgcn_readfirstlane((int)p.o.done[b0]) != 0) a0 = JSS_ACTION_RESET;
+            if (__builtin_amdgcn_readfirstlane((int)p.o.done[b1]) != 0) a1 = JSS_ACTION_RESET;
+        }
+    }
+    if (tab_in_lds(TAB)) {
+        stage_shared_table(lds, p.d.ops, p.d.jmax * p.d.mmax, (int)threadIdx.x);
+        __syncthreads();
+    }
+    if (!alive0) return;
+    const bool ragged = p.d.jmin > 0 && p.d.jmin < p.d.jmax;
+    // both envs' state loads, unconditionally and in straight-line code (an env that is reset instead of stepped reads rows
+    // nobody looks at: one step in a few hundred) -- the wait in front of the first env's unpack then leaves exactly the
+    // second env's loads outstanding
+    const RawEnv<1> raw0 = wave_issue<1, TAB>(p, b0, lane, h0, ragged);
+    const RawEnv<1> raw1 = wave_issue<1, TAB>(p, b1, lane, h1, ragged);
+    wave_one_of_two<MODE, TAB>(p, b0, lane, h0, raw0, a0, lds, scratch, &raw1);
+    if (alive1) wave_one_of_two<MODE, TAB>(p, b1, lane, h1, raw1, a1, lds, scratch, nullptr);
+}
+
+template <int MODE, int TAB>
+__global__ __launch_bounds__(kBlock, JSS_WAVE_MIN_BLOCKS) void jss_kernel_two(Params p) {
+    HIP_DYNAMIC_SHARED(int32_t, lds)
+    wave_block2<MODE, TAB>(p, (int)blockIdx.x, lds);
+}
 
 // ---------------------------------------------------------------------------------------
 // The resident step-session kernel (include/jss_hip.h, jss_session_*), one wavefront per env.  Same protocol as

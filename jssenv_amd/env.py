@@ -321,18 +321,28 @@ class BatchedJssEnv:
     """B independent job-shop envs on one GPU.
 
     instances  one instance spec (name, path or Instance) shared by the whole batch, or a
-               sequence of them.  With a sequence, env i runs instance ``i % len(instances)``
-               unless ``table_of_env`` says otherwise.
+               sequence of them.  With a sequence of n instances and a batch of another size the envs are dealt onto the
+               instances so that every instance gets as many envs as ``i % n`` would give it; WHICH env gets which instance
+               is ``order``'s business and is always readable from ``table_of_env_host`` (``instance_of_env(i)``).
+               ``batch == n`` (or no batch): env i runs instances[i]; ``table_of_env`` overrides everything.
     batch      number of envs (defaults to len(instances)).
     kernel     "auto" (packed kernel when every env fits a 16/32-lane group) or "wave"
                (one wavefront per env); a per-env-object choice carried in JssDesc.
-    order      "by_shape": a ragged population in ONE set of padded tensors, stepped by class-specialised bodies.  The envs
-               are dealt onto the instances class by class (J, M <= 16, <= 32, J < 64, the rest: env i <- instance
-               sorted_by_class[i % n] -- every class a contiguous range of the batch) and reset / policy / step /
-               rollout(n_iter=1) / rollout_steps run as ONE grid over the classes (jss_multi_*, JssDesc.jclass: 4 or 2 envs
-               per wavefront for the small classes, one wavefront per env for the others) on the padded rows, instead of
-               the one kernel the padded extents would pick.  Same tensors, same layout, same results per env; an env
-               keeps its class for life (assign_instances: within the class).
+    order      how a batch deals its envs onto a LIST of instances (``batch != len(instances)``, no ``table_of_env``):
+               "by_shape"     a ragged population in ONE set of padded tensors, stepped by class-specialised bodies.  The envs
+                              are dealt onto the instances class by class (J, M <= 16, <= 32, J < 64, the rest: env i <-
+                              sorted_by_class[...] -- every class a contiguous range of the batch) and reset / policy / step /
+                              rollout(n_iter=1) / rollout_steps run as ONE grid over the classes (jss_multi_*, JssDesc.jclass:
+                              4 or 2 envs per wavefront for the small classes, one wavefront per env for the others) on the
+                              padded rows, instead of the one kernel the padded extents would pick.  Same tensors, same layout,
+                              same results per env; an env keeps its class for life (assign_instances: within the class).
+               "interleaved"  env i <- instances[i % n]: every env on the kernel of the PADDED shape (BASELINE config 5 as
+                              rounds 1-5 ran it by default: 0.49 of the roofline against 0.57 by shape).
+               None           (default) "by_shape" when the list holds more than one shape class, else "interleaved" -- the
+                              fast form is what a caller gets without asking; ``env.order`` says which one it got.  Chosen
+                              this way, the by-class deal costs nothing in generality: an ``assign_instances`` that moves an
+                              env to another class (an error under an explicit "by_shape") quietly hands the batch to the
+                              padded extents' kernel from then on (``steps_by_shape_class`` turns False).
     """
 
     def __init__(self, instances, batch: Optional[int] = None, device=None, env_id_base: int = 0,
@@ -359,17 +369,24 @@ class BatchedJssEnv:
         self.env_id_base = int(env_id_base)
         self.packed = pk
         self.jmax, self.mmax, self.n_tables = pk.jmax, pk.mmax, n
-        if order not in (None, "by_shape"):
-            raise ValueError("order must be None or 'by_shape'")
+        if order not in (None, "by_shape", "interleaved"):
+            raise ValueError("order must be None, 'by_shape' or 'interleaved'")
         self._class_of_table = None
+        # shape class of every instance (BucketedJssEnv's classes; a 64-job instance inside rows wider than 64 goes with
+        # the two-jobs-per-lane class: its NOPE flag lives at byte 64 of the mask row)
+        wide = 63 if pk.jmax > 64 else 64
+        cls = np.array([0 if (j <= 16 and m <= 16) else 1 if (j <= 32 and m <= 32) else 2 if j <= wide else 3
+                        for j, m in zip(pk.jobs.tolist(), pk.machines.tolist())])
+        self._order_given = order is not None
+        if order is None:
+            # the default: a list of instances of more than one shape class, dealt out by this constructor, is dealt out by
+            # class (a caller that passes no order gets the fast form); everything else keeps i % n
+            dealt_here = n > 1 and n != B and table_of_env is None
+            order = "by_shape" if (dealt_here and len(set(cls.tolist())) > 1) else "interleaved"
+        self.order = order
         if order == "by_shape":
             if n == 1 or table_of_env is not None:
                 raise ValueError("order='by_shape' deals the envs onto a LIST of instances itself (no table_of_env)")
-            # shape class of every instance (BucketedJssEnv's classes; a 64-job instance inside rows wider than 64 goes with
-            # the two-jobs-per-lane class: its NOPE flag lives at byte 64 of the mask row)
-            wide = 63 if pk.jmax > 64 else 64
-            cls = np.array([0 if (j <= 16 and m <= 16) else 1 if (j <= 32 and m <= 32) else 2 if j <= wide else 3
-                            for j, m in zip(pk.jobs.tolist(), pk.machines.tolist())])
             by_class = np.argsort(cls, kind="stable")                    # instances class by class, given order inside a class
             counts = np.bincount(np.arange(B) % n, minlength=n)[by_class]   # envs per instance as i % n would deal them
             table_of_env = np.repeat(by_class, counts)
@@ -403,7 +420,7 @@ class BatchedJssEnv:
         fits = n != 1 and pk.mmax <= 32                 # 21-bit ops: machines <= 32, any number of jobs, either kernel flavour
         if records == "medium" and not fits:
             raise ValueError("medium job records need a batch of different instances with machines <= 32")
-        self.medium = records == "medium" or (records is None and compact is None and fits and self.kernel == "auto"
+        self.medium = records == "medium" or (records is None and compact is None and fits and self.kernel.startswith("auto")
                                               and pk.jmax <= 16 and pk.mmax <= 16)
         self.record_ints = _abi.NFC if self.compact else _abi.NFM if self.medium else _abi.NF
         self.no_clocks = self.compact or self.medium           # time_until_available_machine is derived, not stored
@@ -465,9 +482,21 @@ class BatchedJssEnv:
         if self._class_of_table is not None:
             self._build_class_views()
 
+    @property
+    def steps_by_shape_class(self) -> bool:
+        """True while reset / policy / step / rollout(n_iter=1) / rollout_steps run the class-specialised bodies (order 'by_shape',
+        no assign_instances across classes since); False: the kernel of the padded extents."""
+        return self._classes is not None
+
+    def instance_of_env(self, i: int) -> int:
+        """Index (into the ``instances`` this batch was built with) of the instance env ``i`` runs -- ``table_of_env_host[i]``:
+        the one place that says how the constructor (``order``), ``table_of_env`` or ``assign_instances`` dealt the envs."""
+        return int(self.table_of_env_host[i])
+
     def _build_class_views(self):
         """order='by_shape': one JssDesc / JssState / JssOut per shape class, each describing a contiguous range of THIS
-        batch's padded tensors (every per-env pointer moved to the class's first env; the instance tables shared)."""
+        batch's padded tensors (every per-env pointer moved to the class's first env; the instance tables shared).  Rebuilt
+        whenever something they copy changes: ``set_env_ids`` (the RNG keys), ``assign_instances`` (a class's jmin / extents)."""
         be, B, J, M = self.backend, self.batch, self.jmax, self.mmax
         cls_env = self._class_of_table[self.table_of_env_host]
         assert (np.diff(cls_env) >= 0).all()
@@ -481,9 +510,10 @@ class BatchedJssEnv:
             assert b - a == idx.size
             jc, mc = int(self.jobs_per_env[a:b].max()), int(self.machines_per_env[a:b].max())
             off = lambda t, per_env: p(t) + a * per_env * t.dtype.itemsize if t is not None else None     # noqa: E731
-            d = _abi.JssDesc(b - a, J, M, self.n_tables, p(self._ops), p(self._rem), p(self._inst), off(self._table_of_env, 1), None,
+            d = _abi.JssDesc(b - a, J, M, self.n_tables, p(self._ops), p(self._rem), p(self._inst), off(self._table_of_env, 1),
+                             off(self._env_ids, 1),      # explicit global env ids (set_env_ids) key the RNG of a class like the batch's
                              self.env_id_base + a, _abi.KERNEL[self.kernel], int(getattr(be, "threads", 0)),
-                             int(self.jobs_per_env[a:b].min()), self.record_ints, 0.0, jc, mc)
+                             int(self.jobs_per_env[a:b].min()), self.record_ints, float(self._desc.cr_factor), jc, mc)
             st = _abi.JssState(off(self.env_header, _abi.NH), off(self.env_const, _abi.NC), off(self.job_state, J * self.record_ints),
                                None if self.no_clocks else off(self.machine_state, M), off(self.solution, J * M), off(self.counters, 4))
             o = _abi.JssOut(off(self.real_obs, J * 7), off(self.action_mask, J + 1), off(self.reward, 1), off(self.done, 1),
@@ -516,11 +546,18 @@ class BatchedJssEnv:
             raise ValueError("index out of range")
         if self._class_of_table is not None and not np.array_equal(self._class_of_table[self.table_of_env_host[env_indices]],
                                                                    self._class_of_table[table_indices]):
-            raise ValueError("order='by_shape': an env keeps its shape class for life -- give it an instance of the same class")
+            if self._order_given:
+                raise ValueError("order='by_shape': an env keeps its shape class for life -- give it an instance of the same class")
+            # The constructor chose the by-class deal on its own (order=None): the caller did not sign up for its one restriction.
+            # From here on every env is stepped by the kernel of the padded extents -- same tensors, same layout, same results
+            # (the reset below rewrites every row of the moved envs' padded blocks); the class ranges are given up.
+            self._classes, self._class_of_table = None, None
         self.table_of_env_host[env_indices] = table_indices
         self.jobs_per_env = self.packed.jobs[self.table_of_env_host]
         self.machines_per_env = self.packed.machines[self.table_of_env_host]
         self.backend.copy_into(self._table_of_env, self.table_of_env_host)
+        if self._classes is not None:
+            self._build_class_views()                        # a class's smallest J / extents may have changed
         which = np.zeros(self.batch, dtype=np.uint8)
         which[env_indices] = 1
         return self.reset(which=which)
@@ -534,6 +571,8 @@ class BatchedJssEnv:
         with self.backend.on_device():
             self._env_ids = self.backend.from_numpy(ids)
         self._desc.env_ids = self.backend.ptr(self._env_ids)
+        if self._classes is not None:
+            self._build_class_views()                        # the class views carry their own (offset) copy of the pointer
 
     # -- raw ABI handles (bench.py launches through these) -------------------------------
     @property
@@ -1266,6 +1305,12 @@ class JssEnv(gymnasium_base("Env")):
         self.sum_op = inst.sum_op                                          # :88
         self.last_time_step = float("inf")                                 # :53
         self.last_solution = None                                          # :52
+        import datetime
+        import random
+        self.start_timestamp = datetime.datetime.now().timestamp()         # :70 (render's time origin, :672)
+        self.colors = [tuple(random.random() for _ in range(3)) for _ in range(self.machines)]   # :99-101, used by render :686
+        self._alloc_log = []        # the job actions of this episode in call order (next_jobs: who queued an event first)
+        self._alloc_log_ok = True   # False once the episode was advanced by a device-side rollout (no per-call log)
         # on the GPU the env's arena (state + outputs, ~1 KB) lives in page-locked host memory the kernel works on in
         # place: step() = one launch + one stream synchronisation, nothing is copied (JSSENV_AMD_HOST_ARENA=0: device
         # memory and one device -> host copy per step, the round-3 form)
@@ -1343,6 +1388,32 @@ class JssEnv(gymnasium_base("Env")):
         return sorted({int(self.current_time_step + v) for v in tm if v > 0})
 
     @property
+    def next_jobs(self):
+        """The reference's list parallel to ``next_time_step`` (jss_env.py:56, :156, :453, :518): entry i is the job whose
+        allocation QUEUED event time ``next_time_step[i]`` -- the first job allocated to finish at that time; a later job
+        that finishes at the same time adds nothing (:450-453).  Derived: the running ops (start = solution[j][todo[j]],
+        end = start + duration > now) sorted by end time; among ops that end together the one allocated first -- the
+        earlier start, then the earlier ``step`` call of this episode (the facade logs its job actions; after a device-side
+        rollout there is no log and the lower job index stands in)."""
+        now = self.current_time_step
+        left, todo = self.time_until_finish_current_op_jobs, self.todo_time_step_job
+        running = [j for j in range(self.jobs) if left[j] > 0]
+        if not running:
+            return []
+        sol = self._solution()
+        rank = {}
+        if self._alloc_log_ok:
+            for pos, j in enumerate(self._alloc_log):
+                rank[j] = pos                                # the LAST allocation of job j is its running op
+        first = {}
+        for j in running:
+            end = int(now + left[j])
+            key = (int(sol[j][todo[j]]), rank.get(j, len(self._alloc_log) + j), j)
+            if end not in first or key < first[end][0]:
+                first[end] = (key, j)
+        return [first[t][1] for t in sorted(first)]
+
+    @property
     def illegal_actions(self):             # (M, J) matrix of the reference (:171, :427, :464-467)
         out = np.zeros((self.machines, self.jobs), dtype=bool)
         need, bl = self.needed_machine_jobs, self.action_illegal_no_op
@@ -1359,6 +1430,7 @@ class JssEnv(gymnasium_base("Env")):
         """jss_env.py:145-181 -- returns the observation dict only (no info tuple)."""
         self._b.reset()
         self._cache = None
+        self._alloc_log, self._alloc_log_ok = [], True
         return self._obs()
 
     def _raise_for(self, err, action=None):
@@ -1368,6 +1440,8 @@ class JssEnv(gymnasium_base("Env")):
             return
         self._b.clear_errors()
         self._cache = None
+        if err & _abi.ERR_ILLEGAL_ACTION and self._alloc_log and self._alloc_log[-1] == action:
+            self._alloc_log.pop()                  # the job was not allocated
         if err & _abi.ERR_BAD_ACTION:
             raise IndexError(f"action {action} out of range for {self.jobs} jobs")
         if err & _abi.ERR_NOPE_IDLE:
@@ -1378,6 +1452,8 @@ class JssEnv(gymnasium_base("Env")):
     def step(self, action):
         """jss_env.py:403-481."""
         action = int(action)
+        if 0 <= action < self.jobs:
+            self._alloc_log.append(action)         # (an action the mask refuses raises below and queues nothing: popped there)
         if getattr(self._b, "host_arena", False):  # GPU, arena in host memory: the action word is part of it
             return self._step_host_arena(action)
         elif self._act_pinned is not None:         # GPU: the action goes out through a pinned word, nothing is allocated
@@ -1459,6 +1535,7 @@ class JssEnv(gymnasium_base("Env")):
             b.seed = int(seed)
         b.reset()
         b.zero_counters()
+        self._alloc_log, self._alloc_log_ok = [], False      # the device picks the actions: no per-call log (next_jobs)
         chunk = self.jobs * self.machines + 16
         for _ in range(64):
             b.rollout(kind, n_iter=chunk, autoreset=False, explore=explore)

@@ -28,17 +28,24 @@ def gantt_rows(solution, instance, start_timestamp: float):
     return rows
 
 
+def _ensure_render_attrs(env):
+    """``start_timestamp`` (jss_env.py:70) and ``colors`` (:99-101) are public attributes of the reference's env, set by its
+    constructor; JssEnv sets them too -- any other object handed to the helpers here gets them on first use."""
+    if not hasattr(env, "start_timestamp"):
+        env.start_timestamp = datetime.datetime.now().timestamp()
+    if not hasattr(env, "colors"):
+        env.colors = [tuple(random.random() for _ in range(3)) for _ in range(env.machines)]
+
+
 def gantt(env):
     """Plotly figure of ``env.solution`` or None when nothing is scheduled yet."""
-    if not hasattr(env, "_render_t0"):
-        env._render_t0 = datetime.datetime.now().timestamp()
-        env._render_colors = [tuple(random.random() for _ in range(3)) for _ in range(env.machines)]
-    rows = gantt_rows(env.solution, env.instance, env._render_t0)
+    _ensure_render_attrs(env)
+    rows = gantt_rows(env.solution, env.instance, env.start_timestamp)
     if not rows:
         return None
     import pandas as pd
     import plotly.figure_factory as ff
-    fig = ff.create_gantt(pd.DataFrame(rows), index_col="Resource", colors=env._render_colors, show_colorbar=True,
+    fig = ff.create_gantt(pd.DataFrame(rows), index_col="Resource", colors=env.colors, show_colorbar=True,
                           group_tasks=True)
     fig.update_yaxes(autorange="reversed")   # tasks listed top-down
     return fig
@@ -53,11 +60,9 @@ def gantt(env):
 def _machine_colors(env):
     """One RGB triple (0-255) per machine: the colours render() hands to plotly (which rewrites that list in place as
     'rgb(r, g, b)' strings -- both spellings are read here)."""
-    if not hasattr(env, "_render_colors"):
-        env._render_t0 = datetime.datetime.now().timestamp()
-        env._render_colors = [tuple(random.random() for _ in range(3)) for _ in range(env.machines)]
+    _ensure_render_attrs(env)
     out = []
-    for c in env._render_colors:
+    for c in env.colors:
         if isinstance(c, str):
             out.append(tuple(int(float(x)) for x in c[c.index("(") + 1:c.index(")")].split(",")))
         else:

@@ -192,18 +192,24 @@ class StepSession:
         if self.closed:
             return
         be, env = self.be, self.env
+        wait_rc = 0
         if self.posted != self.waited:          # (not through wait(): a dead session must still be closable)
             with be.on_device():
-                be.lib.jss_session_wait(C.byref(env._desc), C.byref(self._sess), self.posted, be.stream())
-            self.waited = self.posted
+                wait_rc = be.lib.jss_session_wait(C.byref(env._desc), C.byref(self._sess), self.posted, be.stream())
+            if wait_rc == 0:
+                self.waited = self.posted       # (a wait that was never launched has waited for nothing)
         with be.on_device():
             rc = be.lib.jss_session_close(C.byref(env._desc), C.byref(self._sess), self.posted, be.stream())
-            _abi.check(be.lib, rc, "jss_session_close")
+            if check or rc == 0:
+                _abi.check(be.lib, rc, "jss_session_close")
             if self._stream is not None:
                 be.torch.cuda.current_stream(be.device).wait_stream(self._stream)
         self.closed = True
         env._session = None
         if check:
+            # the wait in front of the close: a launch error or JSS_E_SESSION is the caller's to know (the session is closed
+            # either way -- the close granule is posted behind whatever the wait managed to enqueue)
+            _abi.check(be.lib, wait_rc, "jss_session_wait")
             st = self.host_status()
             if st["session_timeouts"] or st["wait_timeouts"]:
                 raise RuntimeError(f"step session timed out on the device: {st}")

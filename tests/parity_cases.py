@@ -134,9 +134,11 @@ def case_random_golden(backend, inst, max_rows=None):
 # batched API: ragged batch, on-device policies, every env compared with its own oracle
 # -----------------------------------------------------------------------------------------
 def case_batch_lockstep(backend, inst_names, batch, n_steps, kind="random", seed=11, nope_every=0, check_every=1,
-                        explore=0.0, records=None):
+                        explore=0.0, records=None, order="interleaved"):
+    # (order: these generic cases hold the kernel of the PADDED extents to the oracle -- env i <- instance i % n; the by-class
+    #  deal a ragged list gets by default has its own cases: case_by_shape_padded, case_config5_mixed, FULL_SIZE_CONFIGS[7])
     insts = [I.builtin_instance(n) if isinstance(n, str) else n for n in inst_names]
-    env = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=1000, records=records, _backend=backend)
+    env = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=1000, records=records, order=order, _backend=backend)
     orcs = [OracleEnv(insts[t], strict=True) for t in env.table_of_env_host]
     env.reset()
     for o in orcs:
@@ -174,11 +176,11 @@ def case_batch_lockstep(backend, inst_names, batch, n_steps, kind="random", seed
     return env, orcs
 
 
-def case_rollout(backend, inst_names, batch, n_iter, kind="random", seed=5, chunks=(1,), autoreset=True):
+def case_rollout(backend, inst_names, batch, n_iter, kind="random", seed=5, chunks=(1,), autoreset=True, order="interleaved"):
     """jss_rollout (fused policy+step, auto-restart) against orc_rollout: same counter RNG, so
     final state, counters and makespans must agree exactly."""
     insts = [I.builtin_instance(n) for n in inst_names]
-    env = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=77, _backend=backend)
+    env = BatchedJssEnv(insts, batch=batch, seed=seed, env_id_base=77, order=order, _backend=backend)
     orcs = [OracleEnv(insts[t], strict=True) for t in env.table_of_env_host]
     env.reset()
     tot = [dict(steps=0, episodes=0, makespan_sum=0, reward_sum=0.0) for _ in orcs]
@@ -507,7 +509,10 @@ def case_bucketed_equals_padded(backend, n_envs=24, n_iter=260, seed=13):
     names = ["ta01", "ta11", "ta21", "ta31", "ta41", "ta51", "ta61", "ta71"]
     insts = [I.builtin_instance(n) for n in names]
     assert [shape_class(i.jobs, i.machines) for i in insts] == [0, 1, 1, 1, 1, 2, 2, 3]
-    padded = BatchedJssEnv(insts, batch=n_envs, seed=seed, env_id_base=500, _backend=backend)
+    # (the bucketed wrapper deals env i onto instance i % n: the padded batch it is compared with is asked for the same deal --
+    #  its default would be by shape class)
+    padded = BatchedJssEnv(insts, batch=n_envs, seed=seed, env_id_base=500, order="interleaved", _backend=backend)
+    assert padded.order == "interleaved" and padded._classes is None and (padded.table_of_env_host == np.arange(n_envs) % len(insts)).all()
     bucketed = BucketedJssEnv(insts, batch=n_envs, seed=seed, env_id_base=500, _backend=backend)
     padded.reset()
     bucketed.reset()
@@ -606,7 +611,7 @@ def case_vector_facade_by_shape(backend, steps=120):
 def case_instance_resampling(backend):
     """assign_instances(): envs switch instance (and shape) between episodes; untouched envs keep running."""
     insts = [I.builtin_instance(n) for n in ("ta01", "ta11", "ta02")]
-    env = BatchedJssEnv(insts, batch=6, seed=8, env_id_base=40, _backend=backend)     # env i <- instance i % 3
+    env = BatchedJssEnv(insts, batch=6, seed=8, env_id_base=40, order="interleaved", _backend=backend)     # env i <- instance i % 3
     orcs = [OracleEnv(insts[i % 3], strict=True) for i in range(6)]
     env.reset()
     for o in orcs:
@@ -658,6 +663,42 @@ def case_instance_resampling(backend):
     try:
         single.assign_instances([0], [0])
         raise AssertionError("a shared-instance batch has no env -> instance map to change")
+    except ValueError:
+        pass
+    # The DEFAULT constructor deals this ragged list out by shape class (ta01, ta02: 16-lane groups; ta11: 32-lane groups).  Its
+    # one restriction -- an env keeps its class -- is not the caller's problem: a move across classes hands the batch to the
+    # padded extents' kernel, results unchanged.  (An explicit order="by_shape" refuses the move.)
+    env = BatchedJssEnv(insts, batch=7, seed=8, env_id_base=40, _backend=backend)
+    assert env.order == "by_shape" and env.steps_by_shape_class
+    toe = env.table_of_env_host.copy()
+    assert sorted(np.bincount(toe, minlength=3)) == [2, 2, 3] and (np.diff(env._class_of_table[toe]) >= 0).all()
+    orcs = [OracleEnv(insts[t], strict=True) for t in toe]
+    env.reset()
+    for o in orcs:
+        o.reset()
+    step_all(20)
+    a, b = int(np.flatnonzero(toe == 1)[0]), int(np.flatnonzero(toe == 0)[0])     # a ta11 env and a ta01 env
+    env.assign_instances([b], [2])                 # ta01 -> ta02: same class, the class bodies stay
+    assert env.steps_by_shape_class
+    orcs[b] = OracleEnv(insts[2], strict=True)
+    orcs[b].reset()
+    orcs[b].episode = 2
+    step_all(12)
+    env.assign_instances([a, b], [0, 1])           # 20x15 -> 15x15 and 15x15 -> 20x15: across classes
+    assert not env.steps_by_shape_class and env.instance_of_env(a) == 0 and env.instance_of_env(b) == 1
+    orcs[a], orcs[b] = OracleEnv(insts[0], strict=True), OracleEnv(insts[1], strict=True)
+    for i, ep in ((a, 2), (b, 3)):
+        orcs[i].reset()
+        orcs[i].episode = ep
+    step_all(25)
+    env.rollout_steps("random", steps=3, n_sub=2)   # (the sub-batch form of the plain kernel on top)
+    for i, o in enumerate(orcs):
+        o.rollout("random", 8, 40 + i, 3, episode=o.episode, step_in_episode=o.step_in_episode)
+        assert_matches_oracle(env.host_state(i), o, f"default order, after a move across classes, env {i}")
+    strict = BatchedJssEnv(insts, batch=7, order="by_shape", _backend=backend)
+    try:
+        strict.assign_instances([int(np.flatnonzero(strict.table_of_env_host == 1)[0])], [0])
+        raise AssertionError("an explicit order='by_shape' keeps an env in its class")
     except ValueError:
         pass
 
@@ -898,19 +939,22 @@ def oracle_episode(inst, seed, env_id, episode=1):
     return orc, st
 
 
-def case_config5_mixed(backend, batch=32768, seed=21):
-    """env i <- ta(1 + i % 80), padded 100x20, ragged J/M; one random episode per env, then the benchmarked
-    auto-restart mode against the oracle's rollout."""
+def case_config5_mixed(backend, batch=32768, seed=21, order=None):
+    """ta01-ta80 dealt onto the batch (`order`: None = the constructor's default, by shape class; "interleaved" = env i <-
+    ta(1 + i % 80)), padded 100x20, ragged J/M; one random episode per env, then the benchmarked auto-restart mode against
+    the oracle's rollout."""
     insts = [I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)]
-    env = BatchedJssEnv(insts, batch=batch, seed=seed, _backend=backend)
+    env = BatchedJssEnv(insts, batch=batch, seed=seed, order=order, _backend=backend)
+    assert env.order == (order or "by_shape") and env.steps_by_shape_class == (env.order == "by_shape")
+    assert sorted(np.bincount(env.table_of_env_host, minlength=80)) == sorted(np.bincount(np.arange(batch) % 80, minlength=80))
     env.reset()
     env.rollout("random", n_iter=6000, autoreset=False)
     pk, t = env.packed, env.table_of_env_host
     dur, mach = (pk.ops & 0xFFFF)[t], (pk.ops >> 16)[t]
     sol, mk, cnt = one_episode_properties(env, dur, mach, pk.jobs[t], pk.machines[t], pk.sum_op[t], "config 5")
-    first = 80 * 5 if batch >= 80 * 6 else 0
-    for i in range(first, min(batch, first + 80)):                  # one env per instance
-        orc, st = oracle_episode(insts[i % 80], seed, i)
+    sample = np.unique(t[::-1], return_index=True)[1]                # one env per instance (the last one that runs it)
+    for i in (batch - 1 - sample).tolist():
+        orc, st = oracle_episode(insts[t[i]], seed, i)
         J, M = orc.jobs, orc.machines
         assert orc.current_time_step == mk[i] and (orc.solution == sol[i, :J, :M]).all() and st == cnt[i, 0], f"mixed env {i}"
         assert_matches_oracle(env.host_state(i), orc, f"mixed env {i}")
@@ -918,8 +962,8 @@ def case_config5_mixed(backend, batch=32768, seed=21):
     env.zero_counters()
     env.rollout("random", n_iter=700, autoreset=True)
     cnt = env.backend.numpy(env.counters)
-    for i in sorted({x for x in list(range(0, 80, 9)) + [79, 80 + 70, batch - 1] if x < batch}):
-        orc = OracleEnv(insts[i % 80], strict=True)
+    for i in sorted({x for x in list(range(0, 80, 9)) + [79, 80 + 70, batch // 2, batch - 1] if x < batch}):
+        orc = OracleEnv(insts[t[i]], strict=True)
         orc.reset()
         r = orc.rollout("random", seed, i, 700, episode=2, step_in_episode=0)
         assert_matches_oracle(env.host_state(i), orc, f"mixed env {i} (auto-restart)")
@@ -999,7 +1043,11 @@ def case_hip_equals_twin_full_size(hip_backend, configs=None):
         ("config 2: ta01 x 4096, random", dict(instances="ta01", batch=4096), "random", 300),
         ("config 3: ta41 x 16384, SPT", dict(instances="ta41", batch=16384), "SPT", 700),
         ("config 4: synthetic 50x20 x 8192, random", dict(instances=I.synthetic_packed(8192, 50, 20)), "random", 400),
-        ("config 5: mixed ta01-80 x 32768, random", dict(instances=[I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=32768), "random", 300),
+        # (order="interleaved": the kernel of the padded extents, whose resets write every padding row like the twin's do -- the
+        #  by-class bodies a ragged list gets by default leave the rows behind their lane group as the allocation made them, so
+        #  the tensors agree on every row of a job and not bit for bit; that path is held to the oracle, FULL_SIZE_CONFIGS[7])
+        ("config 5: mixed ta01-80 x 32768, random", dict(instances=[I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=32768,
+                                                         order="interleaved"), "random", 300),
         ("headline: ta01 x 65536, random", dict(instances="ta01", batch=65536), "random", 260),
     ]
     for what, kw, policy, n_iter in configs:
@@ -1025,13 +1073,18 @@ FULL_SIZE_CONFIGS = [   # (label, BatchedJssEnv kwargs factory, policy, iteratio
     ("config 2: ta01 x 4096, random", lambda: dict(instances="ta01", batch=4096), "random", 300, 0.0),
     ("config 3: ta41 x 16384, SPT", lambda: dict(instances="ta41", batch=16384), "SPT", 700, 0.0),
     ("config 4: synthetic 50x20 x 8192, random", lambda: dict(instances=I.synthetic_packed(8192, 50, 20)), "random", 400, 0.0),
+    # (env i <- ta(1 + i % 80): every env on the padded extents' kernel, <2,5,1>; the default constructor's deal is index 7)
     ("config 5: mixed ta01-80 x 32768, random",
-     lambda: dict(instances=[I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=32768), "random", 300, 0.0),
+     lambda: dict(instances=[I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=32768, order="interleaved"), "random", 300, 0.0),
     ("headline: ta01 x 65536, random", lambda: dict(instances="ta01", batch=65536), "random", 280, 0.0),
     # the other two batches bench.py times: per-env 15x15 tables at 65 536 envs (24-byte medium records, <16,5,3>) and ALL
     # of config 4 on one GPU (indices 5, 6: appended, the launch-form table of tests/test_hip_parity.py goes by index)
     ("syn15x15: synthetic 15x15 x 65536, random", lambda: dict(instances=I.synthetic_packed(65536, 15, 15)), "random", 260, 0.0),
     ("config 4 whole: synthetic 50x20 x 65536, random", lambda: dict(instances=I.synthetic_packed(65536, 50, 20)), "random", 150, 0.0),
+    # config 5 as the DEFAULT constructor builds it (round 6): a ragged list is dealt out by shape class and stepped by the
+    # class-specialised bodies of the fused grid on the padded rows -- what bench.py's c5_mixed_b32768_padded times
+    ("config 5 default: mixed ta01-80 x 32768 by shape class, random",
+     lambda: dict(instances=[I.builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=32768), "random", 300, 0.0),
 ]
 
 
@@ -1174,8 +1227,10 @@ def case_multi_entry_points(backend, steps=40):
                              dict(instances=["ta51", "ta61"], batch=3), dict(instances=["ta71", "ta52"], batch=4)],   # (last: ragged, 50 and 100 jobs: the grid's two-jobs-per-lane body has no narrow path)
               "fallback": [dict(instances="ta01", batch=6), dict(instances=["ta11", "ta12"], batch=4), dict(instances="ta51", batch=2)]}
     for what, kws in groups.items():
-        a = [BatchedJssEnv(seed=4, env_id_base=100 * i, _backend=be, **kw) for i, kw in enumerate(kws)]
-        b = [BatchedJssEnv(seed=4, env_id_base=100 * i, _backend=be, **kw) for i, kw in enumerate(kws)]
+        # (order="interleaved": each object is ONE set here, stepped by the kernel of its own padded extents -- the by-class deal
+        #  a ragged list gets by default would make the `b` objects fused grids themselves, and leaves other bytes in padding rows)
+        a = [BatchedJssEnv(seed=4, env_id_base=100 * i, order="interleaved", _backend=be, **kw) for i, kw in enumerate(kws)]
+        b = [BatchedJssEnv(seed=4, env_id_base=100 * i, order="interleaved", _backend=be, **kw) for i, kw in enumerate(kws)]
         n = len(a)
         sets = ((D * n)(*[C.pointer(e._desc) for e in a]), (S * n)(*[C.pointer(e._state) for e in a]), (O * n)(*[C.pointer(e._out) for e in a]))
         streams = (P * 2)(be.stream(), be.stream())
@@ -1592,8 +1647,8 @@ def case_cr_any_factor(backend, factors=(1.2, 1.3, 0.7, 1.0 / 3.0, 2.71828182845
     try:
         instances = [I.builtin_instance(n) for n in insts]
         for factor in factors:
-            env = BatchedJssEnv(instances, batch=batch, seed=seed, _backend=backend)
-            orcs = [OracleEnv(instances[i % len(instances)], strict=True) for i in range(batch)]
+            env = BatchedJssEnv(instances, batch=batch, seed=seed, _backend=backend)      # (a ragged list: dealt out by shape class)
+            orcs = [OracleEnv(instances[t], strict=True) for t in env.table_of_env_host]
             rules = [D.CriticalRatio(due_date_factor=factor) for _ in range(batch)]
             env.reset()
             for o in orcs:
@@ -1613,6 +1668,7 @@ def case_cr_any_factor(backend, factors=(1.2, 1.3, 0.7, 1.0 / 3.0, 2.71828182845
                     o.step(want)
                     acts.append(want)
                 env.step(np.asarray(acts, dtype=np.int32))
+        case_cr_f64_unfused(backend)
         # the code is for policy launches: the fused rollouts answer JSS_E_KIND, a factor that is not a positive float is refused
         be = env.backend
         d, s_, o_ = env._refs()
@@ -1634,6 +1690,35 @@ def case_cr_any_factor(backend, factors=(1.2, 1.3, 0.7, 1.0 / 3.0, 2.71828182845
             pass
     finally:
         np.random.random = real
+
+
+def case_cr_f64_unfused(backend):
+    """A state in which the reference's float64 ratio and a fused multiply-subtract of the same expression disagree
+    (dispatching.py:391-398 rounds `length * factor` before it subtracts `now`).  Jobs 0 and 1 are both 100 long; at
+    t = 120 both are legal, job 0 with 100 of work left, job 1 with 1.  fl(100 * 1.2) = 120.0, so both ratios are exactly
+    0.0 and the strict `<` keeps the lower index: job 0.  With one rounding 100 * 1.2 - 120 = -4.44e-15 and job 1
+    (-4.44e-15 / 1 < -4.44e-15 / 100) would win -- what the device code did while hipcc contracted the expression."""
+    from jssenv_amd import dispatching as D
+    machine = np.array([[2, 0, 1], [1, 0, 2], [2, 0, 1]], dtype=np.int32)
+    duration = np.array([[98, 1, 1], [98, 1, 1], [120, 1, 1]], dtype=np.int32)
+    inst = I.Instance("cr_unfused_3x3", machine, duration)
+    assert 100 * 1.2 - 120 == 0.0                         # the reference's (NumPy / Python float) evaluation
+    filler = random_instance(np.random.default_rng(1), 3, 3)   # a second table: the batch runs the per-env-table kernels too
+    for insts in ([inst], [inst, filler]):
+        env = BatchedJssEnv(insts, batch=len(insts) * 2, seed=1, _backend=backend)
+        orc = OracleEnv(inst, strict=True)
+        env.reset()
+        orc.reset()
+        for a in (2, 1, 1):                               # job 2 takes machine 2 until 120; job 1 runs 0-98 and 98-99
+            acts = np.full(env.batch, _abi.ACTION_SKIP, dtype=np.int32)
+            acts[::len(insts)] = a
+            env.step(acts)
+            orc.step(a)
+        assert orc.current_time_step == 120 and list(np.flatnonzero(orc.legal_actions)) == [0, 1, 2]
+        want = D.CriticalRatio(due_date_factor=1.2)(orc)
+        assert want == 0
+        dev = np.asarray(env.backend.numpy(env.policy("CR", cr_factor=1.2)))
+        assert (dev[::len(insts)] == want).all(), f"device picks {dev[::len(insts)]}, the reference's unfused float64 picks {want}"
 
 
 def case_cr_due_date_factor(backend, factors=(2.0, 0.5, 1.25), inst="ta01", batch=6, steps=260, seed=4):
@@ -1824,3 +1909,94 @@ def case_policy_step_steps(backend, batch=300, steps=9, seed=13, warm=230):
         for name in sa:
             assert np.array_equal(sa[name], sb[name]), f"policy_step_steps differs from the policy / step loop in {name}"
         assert a.stats()["steps"] > 0
+
+
+def case_integration_level2_stub(lib_path, on_gpu):
+    """INTEGRATION.md's Level-2 stub -- the ctypes binding a maintainer of the reference would paste into jss_env.py --
+    executed AS PRINTED: the code block is cut out of the document, the library name is given its path, the `...` that
+    stands for the reference's own parser (jss_env.py:72-95) is filled with one, and on a box without a GPU "cuda" reads
+    "cpu" and the stream is 0.  Nothing else is touched.  A FIFO episode on ta01 through the stub's reset() / step():
+    mask, observation, reward, done equal the oracle's at every step, 225 steps, makespan 1486 (golden G3)."""
+    import os
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## Level 2"):]
+    code = sec[sec.index("```python") + len("```python"):]
+    code = code[:code.index("```")]
+    assert 'C.CDLL("libjss_hip.so")' in code and code.count("...  ") == 1
+    code = code.replace('C.CDLL("libjss_hip.so")', f"C.CDLL({lib_path!r})")
+    code = code.replace(code[code.index("..."):code.index("\n", code.index("..."))], "_parse(self, env_config)")
+    if not on_gpu:
+        code = code.replace('"cuda"', '"cpu"').replace("torch.cuda.current_stream().cuda_stream", "0")
+    inst = I.builtin_instance("ta01")
+
+    def _parse(self, env_config):                         # what jss_env.py:72-95 leaves behind
+        self.jobs, self.machines = inst.jobs, inst.machines
+        self.instance_matrix = np.stack([inst.machine, inst.duration], axis=2).astype(np.int64)   # [j][k] = (machine, duration)
+        self.max_time_op = int(inst.duration.max())
+        self.jobs_length = inst.duration.sum(axis=1)
+        self.max_time_jobs = int(self.jobs_length.max())
+        self.sum_op = int(inst.duration.sum())
+
+    ns = {"gym": types.SimpleNamespace(Env=object), "_parse": _parse}
+    exec(compile(code, "INTEGRATION.md#level-2", "exec"), ns)
+    env = ns["JssEnv"]({"instance_path": "ta01"})
+    orc = OracleEnv(inst, strict=True)
+    obs, want = env.reset(), orc.reset()
+    steps, done = 0, False
+    while not done:
+        assert (obs["action_mask"] == orc.legal_actions).all(), steps
+        assert np.abs(obs["real_obs"].astype(np.float64) - orc.state).max() <= OBS_TOL, steps
+        legal = orc.legal_actions[:-1]
+        if legal.any():                                   # FIFO (dispatching.py:133-156): longest idle since its last op, first index wins
+            a = int(np.argmax(np.where(legal, orc.idle_time_jobs_last_op, -1)))
+        else:
+            a = orc.jobs
+        obs, r, done, trunc, info = env.step(a)
+        _, r0, d0 = orc.step(a)[:3]
+        assert reward_close(r, r0) and done == bool(d0) and trunc is False and info == {}, steps
+        steps += 1
+    assert steps == 225 and orc.current_time_step == 1486 and int(env._env[0, 0]) == 1486
+    assert (env._sol[0].cpu().numpy() == orc.solution).all()
+
+
+def case_two_envs_per_wavefront(backend_two, backend_one=None, steps=60, n_envs=7, seed=19):
+    """The one-step launches of the one-wavefront-per-env flavour with a wavefront serving TWO envs in turn (round 6:
+    jss_kernel_two; `backend_two`'s default kernel carries JSS_KERNEL_TWO_ENVS_PER_WAVE so that
+    small batches take the form too).  An ODD number of envs (the last wavefront owns one), ragged 30- / 50-job instances with
+    per-env tables: policy + jss_step in lock step with the oracle (forced NOPEs, next-step auto-resets = the kernel's reset
+    routing for one env of a pair), jss_rollout(n_iter = 1) and the sub-batch form against orc_rollout, a never-reset env in
+    the pair; then the same calls with one env per wavefront give the same bytes."""
+    assert _abi.KERNEL[backend_two.default_kernel] & 4
+    names = ["ta31", "ta51", "ta41", "ta62"]                      # 30x15, 50x15, 30x20, 50x20: one job per lane, ragged
+    case_batch_lockstep(backend_two, names, batch=n_envs, n_steps=steps, kind="random", nope_every=7, check_every=3)
+    case_rollout(backend_two, names, batch=n_envs, n_iter=0, chunks=(1,) * 6 + (40, 1, 1), kind="random")
+    case_rollout(backend_two, names[:2], batch=5, n_iter=0, chunks=(1,) * 5, kind="SPT", autoreset=False)
+    case_rollout_steps(backend_two, batch=2 * 64 + 3, steps=4, n_sub=2, seed=seed)
+    # a pair whose second env was never reset: left alone, its neighbour steps
+    insts = [I.builtin_instance(n) for n in names]
+    env = BatchedJssEnv(insts, batch=4, seed=seed, order="interleaved", _backend=backend_two)
+    env.reset(which=np.array([1, 0, 1, 1], dtype=np.uint8))
+    before = np.array(env.backend.numpy(env.job_state)[1], copy=True)
+    for _ in range(12):
+        env.step(env.policy("random"), autoreset=True)
+        env.rollout("random", n_iter=1)
+    assert np.array_equal(env.backend.numpy(env.job_state)[1], before) and env.backend.numpy(env.env_header)[1, _abi.H_EPISODE] == 0
+    assert env.backend.numpy(env.counters)[[0, 2, 3], 0].min() > 0 and env.backend.numpy(env.counters)[1, 0] == 0
+    if backend_one is not None:
+        # same calls, one env per wavefront: the same bytes -- over many short episodes (tiny instances), so that the restarts
+        # inside the fused rollout and jss_step_autoreset's routing of ONE env of a pair through the reset body both happen often
+        rng = np.random.default_rng(seed)
+        tiny = [random_instance(rng, int(rng.integers(3, 10)), int(rng.integers(2, 6))) for _ in range(5)]
+        outs = []
+        for be in (backend_two, backend_one):
+            e = BatchedJssEnv(tiny, batch=9, seed=seed, env_id_base=9, order="interleaved", _backend=be)
+            e.reset()
+            for k in range(90):
+                e.rollout("random", n_iter=1)
+                e.step(e.policy("random"), autoreset=True)
+            outs.append(_state_snapshot(e))
+            assert e.stats()["episodes"] >= 18
+        for name in outs[0]:
+            assert np.array_equal(outs[0][name], outs[1][name]), f"two envs per wavefront differs from one in {name}"

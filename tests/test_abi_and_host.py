@@ -157,3 +157,13 @@ def test_render_rows_from_solution():
     assert rows[0]["Resource"] == f"Machine {inst.machine[2, 0]}"
     assert (rows[1]["Finish"] - rows[1]["Start"]).total_seconds() == inst.duration[2, 1]
     assert gantt_rows(np.full((15, 15), -1), inst, 0.0) == []
+
+
+def test_integration_level2_stub_as_printed_on_the_twin():
+    """INTEGRATION.md's Level-2 ctypes stub, cut out of the document and executed against the host-core twin (same C ABI,
+    NumPy-backed torch CPU tensors, stream 0); the GPU suite runs the same text against libjss_hip.so."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_cases as P
+    from jssenv_amd.build import build_cpu_twin
+    P.case_integration_level2_stub(build_cpu_twin(), on_gpu=False)

@@ -78,6 +78,9 @@ def _two_ranks_equal_one_process(device, global_batch, iters, seed=7):
     c = whole["counters"].sum(axis=0)
     assert (tot["steps"], tot["episodes"], tot["makespan_sum"], tot["reward_num_sum"]) == tuple(float(x) for x in c)
     assert tot["steps"] > 0 and tot["steps_per_second"] == tot["steps"] / 2.0
+    # the slowest and the fastest rank of the window (each rank's own env steps over ITS wall time: 1 s and 2 s here)
+    own = [float(results[r][4]["counters"][:, 0].sum()) / (1.0 + r) for r in range(2)]
+    assert tot["rank_rate_min"] == min(own) and tot["rank_rate_max"] == max(own)
     return results[0][3]
 
 
@@ -119,6 +122,83 @@ def test_each_rank_selects_its_own_gpu():
         with pytest.raises(RuntimeError, match="8 ranks but only 4"):
             D.init_from_env("nccl")
         init_pg.assert_not_called()
+
+
+def test_multi_node_job_selects_by_local_world_size():
+    """2 nodes x 8 GPUs: WORLD_SIZE = 16, LOCAL_WORLD_SIZE = 8, 8 devices per node -- rank 13 is local rank 5 and drives GPU 5
+    (round 5 compared the device count with the global world size and refused such a job)."""
+    from unittest import mock
+    from jssenv_amd import distributed as D
+    env = dict(RANK="13", WORLD_SIZE="16", LOCAL_RANK="5", LOCAL_WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    with mock.patch.dict(os.environ, env), mock.patch("torch.cuda.device_count", return_value=8), \
+            mock.patch("torch.cuda.set_device") as set_device, mock.patch("torch.distributed.is_initialized", return_value=False), \
+            mock.patch("torch.distributed.init_process_group") as init_pg:
+        assert D.init_from_env("nccl") == (13, 16, 5)
+    set_device.assert_called_once_with(5)
+    (backend,), kw = init_pg.call_args
+    assert backend == "nccl" and kw["rank"] == 13 and kw["world_size"] == 16 and kw["device_id"] == torch.device("cuda", 5)
+    with mock.patch.dict(os.environ, dict(env, LOCAL_RANK="8")), mock.patch("torch.cuda.device_count", return_value=8), \
+            mock.patch("torch.distributed.is_initialized", return_value=False), mock.patch("torch.distributed.init_process_group"):
+        with pytest.raises(ValueError, match="outside a node of 8"):
+            D.init_from_env("nccl")
+
+
+def _fake_sysfs(root, gpu_nodes, cpulists, cpu_only_nodes=2):
+    """A sysfs tree with `cpu_only_nodes` CPU entries in the KFD topology followed by one GPU entry per element of `gpu_nodes`
+    (its NUMA node), render minors 128.., and `cpulists[n]` as NUMA node n's cpulist."""
+    topo = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+    for i in range(cpu_only_nodes):
+        os.makedirs(os.path.join(topo, str(i)))
+        with open(os.path.join(topo, str(i), "properties"), "w") as fh:
+            fh.write("cpu_cores_count 48\nsimd_count 0\ndrm_render_minor 0\n")
+    for g, node in enumerate(gpu_nodes):
+        d = os.path.join(topo, str(cpu_only_nodes + g))
+        os.makedirs(d)
+        with open(os.path.join(d, "properties"), "w") as fh:
+            fh.write(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + g}\n")
+        dev = os.path.join(root, "class", "drm", f"renderD{128 + g}", "device")
+        os.makedirs(dev)
+        with open(os.path.join(dev, "numa_node"), "w") as fh:
+            fh.write(f"{node}\n")
+    for n, cl in enumerate(cpulists):
+        d = os.path.join(root, "devices", "system", "node", f"node{n}")
+        os.makedirs(d)
+        with open(os.path.join(d, "cpulist"), "w") as fh:
+            fh.write(cl + "\n")
+
+
+def test_rank_pins_its_host_thread_to_its_gpus_numa_node(tmp_path):
+    """8 GPUs on 2 sockets (GPUs 0-3 on node 0, 4-7 on node 1), 8 ranks: every rank ends up on CPUs of ITS GPU's socket, the
+    four ranks of a socket on disjoint slices of it; a topology that cannot be read changes nothing (sysfs mocked, the
+    affinity calls mocked: this container has 8 CPUs)."""
+    from unittest import mock
+    from jssenv_amd import distributed as D
+    root = str(tmp_path)
+    _fake_sysfs(root, [0, 0, 0, 0, 1, 1, 1, 1], ["0-47,96-143", "48-95,144-191"])
+    assert [D.gpu_numa_node(g, root) for g in range(8)] == [0, 0, 0, 0, 1, 1, 1, 1] and D.gpu_numa_node(8, root) is None
+    assert D.numa_cpus(1, root) == set(range(48, 96)) | set(range(144, 192)) and D.numa_cpus(7, root) == set()
+    seen = {}
+    for r in range(8):
+        with mock.patch("os.sched_getaffinity", return_value=set(range(192))), mock.patch("os.sched_setaffinity") as setaff:
+            info = D.pin_to_gpu_numa_node(r, r, 8, sysfs=root)
+        (pid, cpus), _ = setaff.call_args
+        assert pid == 0 and info == {"numa_node": r // 4, "cpus": 24, "pinned": True}
+        assert set(cpus) <= D.numa_cpus(r // 4, root)
+        seen[r] = set(cpus)
+    assert all(not (seen[a] & seen[b]) for a in range(8) for b in range(a))          # nobody shares a core
+    # a cgroup that allows only 4 CPUs of the socket: the ranks share them (no slices of less than two CPUs)
+    with mock.patch("os.sched_getaffinity", return_value={0, 1, 2, 3, 50}), mock.patch("os.sched_setaffinity") as setaff:
+        info = D.pin_to_gpu_numa_node(2, 2, 8, sysfs=root)
+    assert setaff.call_args[0] == (0, [0, 1, 2, 3]) and info["cpus"] == 4
+    # unknown topology / a GPU without a NUMA node (-1) / no allowed CPU on the node: nothing is touched
+    with mock.patch("os.sched_setaffinity") as setaff:
+        assert D.pin_to_gpu_numa_node(0, 0, 1, sysfs=os.path.join(root, "nowhere"))["pinned"] is False
+        with open(os.path.join(root, "class", "drm", "renderD128", "device", "numa_node"), "w") as fh:
+            fh.write("-1\n")
+        assert D.pin_to_gpu_numa_node(0, 0, 8, sysfs=root) == {"numa_node": None, "cpus": None, "pinned": False}
+        with mock.patch("os.sched_getaffinity", return_value={200, 201}):
+            assert D.pin_to_gpu_numa_node(5, 5, 8, sysfs=root)["pinned"] is False
+        setaff.assert_not_called()
 
 
 def test_two_ranks_equal_one_process_cpu_twin():

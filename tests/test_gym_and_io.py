@@ -149,7 +149,7 @@ def test_render_gantt_end_to_end():
     sol = env.solution
     n_scheduled = int((sol >= 0).sum())
     assert n_scheduled > 0 and type(fig).__name__ == "Figure"
-    rows = gantt_rows(sol, env.instance, env._render_t0)
+    rows = gantt_rows(sol, env.instance, env.start_timestamp)
     assert len(rows) == n_scheduled
     # plotly's create_gantt draws one filled scatter trace per machine: 5 points per bar, the bars of a trace
     # separated by sharing the closing point (5 n - 1 points for n bars)
@@ -223,3 +223,70 @@ def test_render_rows_equal_the_reference():
                          "Resource": f"Machine {ref.instance_matrix[job][k][0]}"})
     assert mine == want and fig is not None
     assert len(env.render().data) == len(fig.data)
+
+
+def _facade_attribute_walk(ref, env, rng, episodes=2, with_advance=False):
+    """Random masked episodes (forced NOPEs included), the facade in lock step with `ref` (anything with the reference's
+    attributes): next_jobs / next_time_step equal after every call."""
+    for _ in range(episodes):
+        ref.reset()
+        env.reset()
+        assert env.next_jobs == [] and list(ref.next_jobs) == []
+        done, n = False, 0
+        while not done:
+            legal = np.flatnonzero(ref.legal_actions)
+            a = int(rng.choice(legal))
+            if n % 11 == 5 and len(ref.next_time_step) > 0 and ref.legal_actions[:-1].sum() > 0:
+                a = ref.jobs                                   # a NOPE whatever the mask says (queues nothing, pops events)
+            _, _, done, _, _ = ref.step(a)
+            env.step(a)
+            n += 1
+            assert env.next_time_step == [int(t) for t in ref.next_time_step], n
+            assert env.next_jobs == [int(j) for j in ref.next_jobs], (n, env.next_jobs, list(ref.next_jobs))
+            if with_advance and n % 17 == 3 and len(ref.next_time_step) > 0:
+                assert env.increase_time_step() == ref.increase_time_step()
+                assert env.next_jobs == [int(j) for j in ref.next_jobs]
+                done = ref.nb_legal_actions == 0 if hasattr(ref, "nb_legal_actions") else done
+                if done:
+                    break
+
+
+@pytest.mark.parametrize("name", ["ta01", "ta31", "dmu16"])
+def test_facade_next_jobs_colors_start_timestamp(name):
+    """The three public attributes of the reference's env that no test of its reads (jss_env.py:56 / :70 / :99): next_jobs
+    -- the job that queued each pending event -- against the NumPy restatement (pinned to the reference's golden traces,
+    and it keeps the list the reference's way, :453 / :518) on random episodes; colors and start_timestamp as render() uses them."""
+    import time
+    from jssenv_amd import builtin_instance, make
+    from oracle.np_restatement import NumpyJssEnv
+    t0 = time.time()
+    env = make("jss-v1", env_config={"instance_path": name}, device="cpu")
+    assert t0 - 1 <= env.start_timestamp <= time.time() + 1
+    assert len(env.colors) == env.machines and all(len(c) == 3 and all(0.0 <= x <= 1.0 for x in c) for c in env.colors)
+    _facade_attribute_walk(NumpyJssEnv(builtin_instance(name)), env, np.random.default_rng(5), with_advance=True)
+    # a caller may set them like on the reference's env: render() takes its time origin and colours from there
+    env.start_timestamp, env.colors = 1000.0, [(0.1, 0.2, 0.3)] * env.machines
+    from jssenv_amd.render import gantt_rows
+    import datetime
+    rows = gantt_rows(env.solution, env.instance, env.start_timestamp)
+    assert rows and min(r["Start"] for r in rows) == datetime.datetime.fromtimestamp(1000.0)
+    # after a device-side episode (the rule runs on the device: no per-call log) the list is still well formed
+    from jssenv_amd.dispatching import get_rule
+    get_rule("SPT").run_episode(env, device_rng=True, seed=1)
+    assert env.next_jobs == [] and env.next_time_step == []
+
+
+@pytest.mark.refcheck
+def test_facade_next_jobs_equal_the_reference():
+    """Build container only: the same walk against the live reference's own lists."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import refload
+    if not refload.reference_available():
+        pytest.skip("reference tree absent")
+    from jssenv_amd import make
+    Ref, _ = refload.load_reference()
+    for name in ("ta01", "ta41"):
+        ref = Ref({"instance_path": refload.reference_instance_path(name)})
+        env = make("jss-v1", env_config={"instance_path": name}, device="cpu")
+        _facade_attribute_walk(ref, env, np.random.default_rng(9), episodes=2)
+        assert hasattr(ref, "colors") and hasattr(ref, "start_timestamp") and len(env.colors) == len(ref.colors)

@@ -407,3 +407,26 @@ def test_medium_records_at_the_limits(hip):
 def test_policy_step_steps_equals_the_loop(hip):
     P.case_policy_step_steps(hip, batch=5000, steps=30)
     P.case_policy_step_steps(hip, batch=65536, steps=12, warm=60)       # the benchmarked batch (bench.py policy_then_step_pipelined)
+
+
+def test_integration_level2_stub_as_printed():
+    """INTEGRATION.md's Level-2 ctypes stub, cut out of the document and executed against libjss_hip.so on the GPU."""
+    from jssenv_amd import _abi
+    P.case_integration_level2_stub(_abi.library_path(), on_gpu=True)
+
+
+def test_two_envs_per_wavefront_small_batches():
+    """jss_kernel_two on request (JSS_KERNEL_TWO_ENVS_PER_WAVE) on small, odd, ragged batches;
+    at the benchmarked sizes the form is the default and FULL_SIZE_CONFIGS[2, 6, 7] hold every env of it to the oracle."""
+    from jssenv_amd.env import HipBackend
+    two, one = HipBackend("cuda:0"), HipBackend("cuda:0")
+    two.default_kernel, one.default_kernel = "wave-2env", "wave-1env"
+    P.case_two_envs_per_wavefront(two, one, steps=200, n_envs=131)
+
+
+@pytest.mark.parametrize("cfg", [2, 6, 7])
+def test_one_env_per_wavefront_form_at_full_size(hip_auto, cfg):
+    """The form the one-wavefront-per-env launches had before round 6 (and still have below 6 144 envs per launch), at the
+    benchmarked sizes, every env against the oracle -- the A/B partner of the default."""
+    label, kw, kind, iters, explore = P.FULL_SIZE_CONFIGS[cfg]
+    P.case_every_env_vs_oracle(hip_auto, label + " [one env per wavefront]", dict(kw(), kernel="auto-1env"), kind, iters, explore=explore, form="free")
