@@ -81,7 +81,7 @@
 extern "C" {
 #endif
 
-#define JSS_ABI_VERSION 9
+#define JSS_ABI_VERSION 10
 
 #define JSS_MAX_JOBS 128
 #define JSS_MAX_MACHINES 64
@@ -309,6 +309,10 @@ typedef struct JssTraj {
                              reset instead of stepped (JSS_ROLLOUT_AUTORESET); JSS_ACTION_SKIP = found done, left frozen */
     float *reward;        /* [K][B]  reward of that step (0 in RESET / SKIP slots)   */
     uint8_t *done;        /* [K][B]  done after that step                            */
+    int64_t stride;       /* envs between slot k and slot k + 1 of one env: 0 = desc->batch.  A call on a RANGE of a larger
+                             batch (a shape class of a batch dealt out by class, JssDesc.jclass: every per-env pointer moved to
+                             the range's first env, these five and jss_steps' actions included) passes the WHOLE batch's size,
+                             so that the range's records land in its columns of the whole batch's [K][B] buffers (ABI v10) */
 } JssTraj;
 
 int jss_abi_version(void);

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 STATE_LAYOUT = 7     # version of the state tensors' layout (checkpoints): unchanged since ABI v7
 MAX_JOBS, MAX_MACHINES = 128, 64
 F_TODO, F_CUR, F_LEFT, F_PERF, F_IDLE, F_IDLE_LAST, F_F4, F_NEXT, NF = 0, 1, 2, 3, 4, 5, 6, 7, 8
@@ -84,7 +84,8 @@ class JssOut(C.Structure):
 
 
 class JssTraj(C.Structure):
-    _fields_ = [("real_obs", _p), ("action_mask", _p), ("action", _p), ("reward", _p), ("done", _p)]
+    _fields_ = [("real_obs", _p), ("action_mask", _p), ("action", _p), ("reward", _p), ("done", _p),
+                ("stride", C.c_int64)]       # envs between two steps' slots (0 = the call's batch): a range of a larger batch
 
 
 class JssSession(C.Structure):

@@ -158,6 +158,9 @@ struct Params {
 #define JSS_ABLATE_ADVANCE 16
 #endif
 
+// envs between slot k and slot k + 1 of the step-major [K][B] buffers (JssTraj.stride: a call on a range of a larger batch)
+__device__ __forceinline__ size_t traj_stride(const Params &p) { return p.t.stride ? (size_t)p.t.stride : (size_t)p.d.batch; }
+
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 

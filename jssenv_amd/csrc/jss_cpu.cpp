@@ -598,7 +598,7 @@ void run_env(const Call &c, int mode, int b) {
     case kSteps: {                                                        // n_iter x kStep, actions [n_iter][B], every step optionally recorded
         const int jm = c.d.jmax;
         for (int it = 0; it < c.n_iter; ++it) {
-            const size_t slot = (size_t)it * c.d.batch + b;
+            const size_t slot = (size_t)it * (c.t.stride ? (size_t)c.t.stride : (size_t)c.d.batch) + b;
             bool called;
             int rn;
             step_call(e, c, b, c.actions[slot], called, rn);
@@ -628,7 +628,7 @@ void run_env(const Call &c, int mode, int b) {
         int n_steps = 0, n_done = 0, last_rn = 0, last_makespan = -1;
         long long sum_makespan = 0, sum_rn = 0;
         for (int it = 0; it < c.n_iter; ++it) {
-            const size_t slot = (size_t)it * c.d.batch + b;
+            const size_t slot = (size_t)it * (c.t.stride ? (size_t)c.t.stride : (size_t)c.d.batch) + b;
             if (mode == kTraj)                                            // what the policy sees in this slot
                 write_obs_mask(e, jm, c.t.real_obs ? c.t.real_obs + slot * jm * 7 : nullptr,
                                c.t.action_mask ? c.t.action_mask + slot * (jm + 1) : nullptr, false);

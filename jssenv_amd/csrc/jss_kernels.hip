@@ -117,6 +117,14 @@ int packed_group(const JssDesc &d, bool by_class = false) {
 
 using KernelFn = void (*)(Params);
 
+// Jobs per lane of the one-wavefront-per-env flavour for a plain (single-set) launch: by the padded extent -- unless the call
+// names a shape class inside wider rows (JssDesc.jclass: every env of the call has J <= jclass) that fits one job per lane.
+// (64 jobs inside rows wider than 64 stay with two jobs per lane: the NOPE flag of such an env is byte 64 of its mask row.)
+int wave_jpl(const JssDesc &d) {
+    if (d.jmax <= kWave) return 1;
+    return (d.jclass > 0 && d.jclass < kWave) ? 1 : 2;
+}
+
 // Two envs per wavefront, one after the other (jss_wave_env.hpp, wave_block2): the one-step modes of the one-wavefront-per-env
 // flavour with one job per lane, per-env tables and full records.  Measured (profiles/r06_misc/two_per_wave_ab.txt,
 // wave_timeline_two_per_wave.txt): with half the wavefronts a launch of 8 192 envs is 15-18 % SLOWER (4 wavefronts per SIMD are
@@ -192,7 +200,7 @@ int plan(Params &p, LaunchPlan &lp, bool by_class = false) {
     lp.shmem += g_lds_pad;
 #endif
     if (lp.shmem > kMaxDynamicLds) return JSS_E_LDS;
-    lp.fn = by_class ? nullptr : lp.two ? pick_two<MODE>() : pick<MODE>(G, p.d.jmax <= kWave ? 1 : 2, shared, p.d.record_ints);   // (the grid has its own kernel)
+    lp.fn = by_class ? nullptr : lp.two ? pick_two<MODE>() : pick<MODE>(G, wave_jpl(p.d), shared, p.d.record_ints);   // (the grid has its own kernel)
     return 0;
 }
 

@@ -531,7 +531,28 @@ template <int G>
 struct PRaw {  // loads issued before the op table is staged; unpacked after the barrier
     int4 h, lo, hi;
     int tm;
+#ifdef JSS_COUNTERS_PLAIN
+    int cw;    // word gl (< 8) of my env's four 64-bit counters: see p_bump_counters
+#endif
 };
+
+#ifdef JSS_COUNTERS_PLAIN
+// A/B build: the env's counter row -- four int64 = eight words -- is loaded with the state, one word
+// per group lane, and the words that change are stored with it, instead of 2-4 result-less atomics per env step.  Nobody else
+// touches an env's counters while a launch that owns the env runs.  Word 2k / 2k + 1 = low / high half of counter k; the
+// carry (and the sign extension of a negative reward numerator) crosses from the even lane to the odd one by one DPP move.
+template <int G, int TAB>
+__device__ __forceinline__ void p_bump_counters(const PCtx<G, TAB> &c, const Params &p, int cw, int steps, int episodes, int makespan_sum, int reward_num) {
+    const int k = c.gl >> 1;
+    const int add = k == 0 ? steps : k == 1 ? episodes : k == 2 ? makespan_sum : reward_num;
+    const unsigned lo_new = (unsigned)cw + (unsigned)add;
+    const int hi_delta = (add >> 31) + (lo_new < (unsigned)cw ? 1 : 0);        // (meaningful on even lanes)
+    const int from_lo = JSS_DPP(hi_delta, 0xB1);                               // lane ^ 1
+    const int now = (c.gl & 1) ? cw + from_lo : (int)lo_new;
+    if (c.alive && c.gl < 8 && now != cw)
+        st_off<int>(reinterpret_cast<int32_t *>(p.s.counters) + (size_t)c.first_env * 8, (c.rel * 8u + (unsigned)c.gl) * 4u, now);
+}
+#endif
 
 template <int G, int TAB>
 __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G, TAB> &c, const Params &p) {
@@ -558,6 +579,9 @@ __device__ __forceinline__ PRaw<G> p_issue_loads(const PCtx<G, TAB> &c, const Pa
     }
     // compact batches keep no machine clocks in memory: a machine is busy for as long as the job on it (p_unpack)
     r.tm = tab_no_clocks(TAB) ? 0 : ld_off<int>(p.s.machine + fe * mm, (c.rel * mm + mc) * 4u);
+#ifdef JSS_COUNTERS_PLAIN
+    r.cw = (p.s.counters && c.gl < 8) ? ld_off<int>(reinterpret_cast<const int32_t *>(p.s.counters) + fe * 8, (c.rel * 8u + (unsigned)c.gl) * 4u) : 0;
+#endif
     return r;
 }
 
@@ -691,7 +715,10 @@ __device__ __forceinline__ PRaw<G> p_pack(const PEnv<G> &e, const PCtx<G, TAB> &
 // State back to HBM.  fresh = my env was (re)initialised by this call: every row of its padded block is written (rows
 // behind J(env) as "no job") together with the instance constants in its header; otherwise rows < J(env), and of
 // those only the halves that changed.
-template <int G, int TAB>
+// DIFF = false (the modes that loop over steps with the state in registers: one store per K steps): every row of a job is
+// written without comparing it with what was loaded, so that `raw` -- 9 VGPRs -- is dead from the unpack on instead of live
+// through the whole loop.
+template <int G, int TAB, bool DIFF = true>
 __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, const PHeader &hd,
                                         const PRaw<G> &raw, bool fresh) {
     if (!c.alive) return;
@@ -711,22 +738,22 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
     }
     if (tab_no_clocks(TAB)) {
         // no machine clocks in memory (p_unpack)
-    } else if (fresh ? (unsigned)c.gl < mm : (c.mvalid && e.tm != raw.tm))      // idle machines stay 0
+    } else if (fresh ? (unsigned)c.gl < mm : (c.mvalid && (!DIFF || e.tm != raw.tm)))      // idle machines stay 0
         st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
     if (tab_medium(TAB)) {
         if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {   // the thirds of the record that changed
             int32_t *jb = p.s.job + fe * jm * JSS_NFM;
             const unsigned jo = (c.rel * jm + c.gl) * (JSS_NFM * 4u);
             const int4 lo = now.lo, hi = now.hi;
-            if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y) st_off(jb, jo, make_int2(lo.x, lo.y));
-            if (fresh || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo + 8u, make_int2(lo.z, lo.w));
-            if (fresh || hi.x != raw.hi.x || hi.y != raw.hi.y) st_off(jb, jo + 16u, make_int2(hi.x, hi.y));
+            if (!DIFF || fresh || lo.x != raw.lo.x || lo.y != raw.lo.y) st_off(jb, jo, make_int2(lo.x, lo.y));
+            if (!DIFF || fresh || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo + 8u, make_int2(lo.z, lo.w));
+            if (!DIFF || fresh || hi.x != raw.hi.x || hi.y != raw.hi.y) st_off(jb, jo + 16u, make_int2(hi.x, hi.y));
         }
     } else if (tab_compact(TAB)) {
         if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
             const int4 lo = now.lo;
             // an unchanged record is not rewritten (steps without a time advance touch few jobs)
-            if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w)
+            if (!DIFF || fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w)
                 st_off(p.s.job + fe * jm * JSS_NFC, (c.rel * jm + c.gl) * (JSS_NFC * 4u), lo);
         }
     } else if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
@@ -734,8 +761,8 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
         const unsigned jo = (c.rel * jm + c.gl) * 32u;
         const int4 lo = now.lo, hi = now.hi;
         // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
-        if (fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
-        if (fresh || hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) st_off(jb, jo + 16u, hi);
+        if (!DIFF || fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
+        if (!DIFF || fresh || hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) st_off(jb, jo + 16u, hi);
         // A class of small instances inside wider padded rows (jmax > G: the fused grid's PADDED bodies): a reset leaves the rows
         // behind the lane group as "no job" records too, like the reset of the padded extents' kernel, the session's write-back
         // and the host twin do -- whichever path (re)initialised an env, its padded block holds the same bytes (a few KB per
@@ -881,7 +908,7 @@ __device__ __forceinline__ bool p_step_call(PEnv<G> &e, PHeader &hd, PCtx<G, TAB
 
 template <int G, int MODE, int TAB>
 __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c, const Params &p, int a_in, bool selected,
-                                       int32_t *mvtab, float *scratch, bool wave_whole) {
+                                       int32_t *mvtab, float *scratch, bool wave_whole, int cw = 0) {
     const size_t fe = (size_t)c.first_env;
     bool fresh = false;
     if (MODE == kReset) {
@@ -903,7 +930,7 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
     } else if (MODE == kSteps) {
         // n_iter x jss_step with the actions given up front: the state stays in registers, every step optionally recorded
         for (int it = 0; it < p.n_iter; ++it) {
-            const size_t slot0 = (size_t)it * p.d.batch + fe;            // [it][first env of the wave]
+            const size_t slot0 = (size_t)it * traj_stride(p) + fe;       // [it][first env of the wave]
             const int a = ld_off<int>(p.actions + slot0, c.rel * 4u);
             int rn;
             bool called;
@@ -935,7 +962,7 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
         const bool autoreset = (p.flags & JSS_ROLLOUT_AUTORESET) != 0;
         const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;
         for (int it = 0; it < n_iter; ++it) {
-            const size_t slot0 = (size_t)it * p.d.batch + fe;            // kTraj: slot [it][first env of the wave]
+            const size_t slot0 = (size_t)it * traj_stride(p) + fe;       // kTraj: slot [it][first env of the wave]
             if (MODE == kTraj) {                                         // what the policy sees in this slot
                 if (p.t.real_obs) p_store_obs<G, TAB>(e, c, p, p.t.real_obs + slot0 * p.d.jmax * 7, scratch, wave_whole);
                 if (p.t.action_mask) p_store_mask<G, TAB>(e, c, p, p.t.action_mask + slot0 * (p.d.jmax + 1));
@@ -973,11 +1000,16 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
             }
         }
         const bool done = !grp_any<G>(e.legal, c.gbase);
+#ifdef JSS_COUNTERS_PLAIN
+        if (p.s.counters) p_bump_counters(c, p, cw, n_steps, n_done, sum_makespan, sum_rn);
+#endif
         if (c.alive && c.gl == 0) {
             if (n_steps) st_off<float>(p.o.reward + fe, c.rel * 4u, div_by((float)last_rn, (float)c.max_time_op, p_norm(c).r_op));
             st_off<uint8_t>(p.o.done + fe, c.rel, done ? 1 : 0);
             if (last_makespan >= 0) st_off<int>(p.o.makespan + fe, c.rel * 4u, last_makespan);
+#ifndef JSS_COUNTERS_PLAIN
             if (p.s.counters) add_counters(p.s.counters + (fe + c.rel) * 4, n_steps, n_done, sum_makespan, sum_rn);
+#endif
         }
     }
     return fresh;
@@ -1093,9 +1125,13 @@ __device__ __forceinline__ void packed_block(const Params &p, int block, int32_t
     // an env that was never reset (episode counter 0: every reset bumps it) is left alone by the step-type calls, like
     // the one-wavefront-per-env kernel and the host twin do (J == 0 in its constants record): no stores, no counters
     if (MODE != kReset && hd.episode == 0) c.alive = false;
+#ifdef JSS_COUNTERS_PLAIN
+    const bool fresh = p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab, scratch, wave_whole, raw.cw);
+#else
     const bool fresh = p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab, scratch, wave_whole);
+#endif
     if (MODE == kPolicy) return;
-    p_store(e, c, p, hd, raw, fresh);
+    p_store<G, TAB, !(MODE == kRollout || MODE == kTraj || MODE == kSteps)>(e, c, p, hd, raw, fresh);
     p_store_mask<G, TAB, false, PADDED>(e, c, p, p.o.action_mask + fe * (p.d.jmax + 1));
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
         p_store_obs<G, TAB, false, PADDED>(e, c, p, p.o.real_obs + fe * p.d.jmax * 7, scratch, wave_whole);
@@ -1191,7 +1227,7 @@ __device__ __forceinline__ PRaw<G> p_unpark(const int4 *park, int slot, int lane
 }
 
 template <int G, int TAB>
-__global__ __launch_bounds__(kBlock, 6) void jss_packed_session_kernel(Params p_arg) {
+__global__ __launch_bounds__(kBlock, tab_global(TAB) ? 5 : 6) void jss_packed_session_kernel(Params p_arg) {   // (per-env tables: 90 VGPRs, no scratch at 5)
     HIP_DYNAMIC_SHARED(int32_t, lds)
     JSS_PARAMS_OF(p, p_arg, false);
     constexpr int E = kWave / G;

@@ -747,7 +747,10 @@ __device__ __forceinline__ RawEnv<JPL> pack_env(const Env<JPL> &e, const Ctx &c)
 
 // State back to HBM.  all_rows = the env was (re)initialised: every row of the padded block is written (rows behind
 // J(env) as "no job"); otherwise rows < J(env), and of those only the halves that changed.
-template <int JPL, int TAB>
+// DIFF = false (the modes that loop over steps with the state in registers: one store per K steps): every row of a job is
+// written without comparing it with what was loaded -- `raw` is dead from the unpack on instead of live through the whole
+// loop (9 VGPRs per job slot: what kept the two-jobs-per-lane recorder in scratch memory).
+template <int JPL, int TAB, bool DIFF = true>
 __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p, const Header &hd,
                                           const RawEnv<JPL> &raw, bool all_rows) {
     const int jm = p.d.jmax;
@@ -766,7 +769,7 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
         // no machine clocks in memory (unpack_env)
     } else if (all_rows) {
         if (c.lane < p.d.mmax) st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
-    } else if (c.lane < c.M && e.tm != raw.tm) {                         // idle machines stay 0
+    } else if (c.lane < c.M && (!DIFF || e.tm != raw.tm)) {              // idle machines stay 0
         st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
     }
     const RawEnv<JPL> now = pack_env<JPL, TAB>(e, c);
@@ -778,16 +781,16 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
             const unsigned jo = (unsigned)j * (JSS_NFM * 4u);
             const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
             if (all_rows ? j < jm : j < c.J) {
-                if (all_rows || lo.x != lo0.x || lo.y != lo0.y) st_off<int2>(jb, jo, make_int2(lo.x, lo.y));
-                if (all_rows || lo.z != lo0.z || lo.w != lo0.w) st_off<int2>(jb, jo + 8u, make_int2(lo.z, lo.w));
-                if (all_rows || hi.x != hi0.x || hi.y != hi0.y) st_off<int2>(jb, jo + 16u, make_int2(hi.x, hi.y));
+                if (!DIFF || all_rows || lo.x != lo0.x || lo.y != lo0.y) st_off<int2>(jb, jo, make_int2(lo.x, lo.y));
+                if (!DIFF || all_rows || lo.z != lo0.z || lo.w != lo0.w) st_off<int2>(jb, jo + 8u, make_int2(lo.z, lo.w));
+                if (!DIFF || all_rows || hi.x != hi0.x || hi.y != hi0.y) st_off<int2>(jb, jo + 16u, make_int2(hi.x, hi.y));
             }
             continue;
         }
         if (tab_compact(TAB)) {
             const unsigned jo = (unsigned)j * (JSS_NFC * 4u);
             const int4 lo0 = raw.lo[s];
-            if (all_rows ? j < jm : (j < c.J && (lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w))) st_off<int4>(jb, jo, lo);
+            if (all_rows ? j < jm : (j < c.J && (!DIFF || lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w))) st_off<int4>(jb, jo, lo);
             continue;
         }
         if (all_rows) {
@@ -804,8 +807,8 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
                 }
         } else if (j < c.J) {   // steps without a time advance touch few jobs
             const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
-            if (lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w) st_off<int4>(jb, (unsigned)j * 32u, lo);
-            if (hi.x != hi0.x || hi.y != hi0.y || hi.z != hi0.z || hi.w != hi0.w) st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
+            if (!DIFF || lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w) st_off<int4>(jb, (unsigned)j * 32u, lo);
+            if (!DIFF || hi.x != hi0.x || hi.y != hi0.y || hi.z != hi0.z || hi.w != hi0.w) st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
         }
     }
 }
@@ -1055,7 +1058,7 @@ __device__ __forceinline__ void wave_finish(const Params &p, Ctx &c, const Heade
     } else if (MODE == kSteps) {
         // n_iter x jss_step with the actions given up front: the state stays in registers, every step optionally recorded
         for (int it = 0; it < p.n_iter; ++it) {
-            const size_t slot = (size_t)it * p.d.batch + b;              // [it][b]
+            const size_t slot = (size_t)it * traj_stride(p) + b;         // [it][b]
             const int a = __builtin_amdgcn_readfirstlane(p.actions[slot]);
             int rn;
             bool called;
@@ -1082,7 +1085,7 @@ __device__ __forceinline__ void wave_finish(const Params &p, Ctx &c, const Heade
         const uint64_t env_id = (uint64_t)(p.d.env_ids ? p.d.env_ids[b] : p.d.env_id_base + b);
         const int n_iter = MODE == kRollout1 ? 1 : p.n_iter;
         for (int it = 0; it < n_iter; ++it) {
-            const size_t slot = (size_t)it * p.d.batch + b;              // kTraj: [it][b]
+            const size_t slot = (size_t)it * traj_stride(p) + b;         // kTraj: [it][b]
             if (MODE == kTraj) {                                         // what the policy sees in this slot
                 if (p.t.real_obs) store_obs(e, c, p.t.real_obs + slot * p.d.jmax * 7, scratch, c.J);
                 if (p.t.action_mask) store_mask(e, c, p.t.action_mask + slot * (p.d.jmax + 1), p.d.jmax);
@@ -1136,7 +1139,11 @@ __device__ __forceinline__ void wave_finish(const Params &p, Ctx &c, const Heade
             if (p.s.counters) add_counters(p.s.counters + (size_t)b * 4, n_steps, n_done, sum_makespan, sum_rn);
         }
     }
-    store_env<JPL, TAB>(e, c, p, hd, raw, fresh);
+    // (the one-job-per-lane recorder keeps comparing: without `raw` it needs 61 VGPRs instead of 78, runs 8 wavefronts per
+    //  SIMD instead of 6 and is 5 % SLOWER on 8 192 envs -- one round of wavefronts in lock step instead of two that overlap;
+    //  profiles/r06_misc/looping_stores_ab.txt)
+    constexpr bool kDiffStores = !(MODE == kRollout || MODE == kSteps || (MODE == kTraj && JPL == 2));
+    store_env<JPL, TAB, kDiffStores>(e, c, p, hd, raw, fresh);
     store_mask(e, c, p.o.action_mask + (size_t)b * (p.d.jmax + 1), p.d.jmax);
     JSS_STAMP(p, b, 5, e.t);
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
@@ -1171,15 +1178,18 @@ __device__ __forceinline__ void wave_main(const Params &p, Ctx &c, const HeaderW
 #define JSS_TRAJ1_MIN_BLOCKS 6
 #endif
 #ifndef JSS_TRAJ2_MIN_BLOCKS
-#define JSS_TRAJ2_MIN_BLOCKS 6
+#define JSS_TRAJ2_MIN_BLOCKS 5
 #endif
-// waves per SIMD each instantiation is compiled for: the largest occupancy it reaches without scratch memory
-constexpr int wave_min_blocks(int jpl, int mode) {
+// waves per SIMD each instantiation is compiled for: the largest occupancy it reaches without scratch memory (round 6: NO
+// instantiation uses scratch -- tests/test_abi_and_host.py reads the code object's notes; the kernels that loop over steps
+// got there by storing the state without comparing it with what was loaded, store_env<.., DIFF = false>, the two-jobs-per-lane
+// recorder in addition by one occupancy step, 6 -> 5, the two-jobs-per-lane one-step rollout on 24-byte records 7 -> 6)
+constexpr int wave_min_blocks(int jpl, int mode, int tab) {
     return mode == kTraj ? (jpl == 2 ? JSS_TRAJ2_MIN_BLOCKS : JSS_TRAJ1_MIN_BLOCKS)
          : mode == kRollout ? (jpl == 2 ? 5 : 7)
          : mode == kStep ? (jpl == 2 ? 5 : 8)
          : mode == kSteps ? (jpl == 2 ? 4 : 6)
-         : mode == kRollout1 ? (jpl == 2 ? JSS_WAVE2_MIN_BLOCKS : JSS_WAVE_MIN_BLOCKS)
+         : mode == kRollout1 ? (jpl == 2 ? (tab_medium(tab) ? 6 : JSS_WAVE2_MIN_BLOCKS) : JSS_WAVE_MIN_BLOCKS)
          : (jpl == 2 ? 7 : 8);
 }
 // One workgroup's share of a launch (`block`: see packed_block).  NARROW: a two-jobs-per-lane instantiation also holds the
@@ -1235,7 +1245,7 @@ __device__ __forceinline__ void wave_block(const Params &p, int block, int32_t *
 }
 
 template <int JPL, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE)) void jss_kernel(Params p_arg) {
+__global__ __launch_bounds__(kBlock, wave_min_blocks(JPL, MODE, TAB)) void jss_kernel(Params p_arg) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
     // by value where a launch is one step: measured faster than in place although it spills SGPRs; in place for the launches
     // that loop over steps with the state in registers (jss_common.hpp: trajectory mode +6.5 % / +10 % on config 4's share /

@@ -521,6 +521,22 @@ class BatchedJssEnv:
             descs.append(d), states.append(st), outs.append(o), spans.append((a, b, k))
         n = len(descs)
         D, S, O = C.POINTER(_abi.JssDesc), C.POINTER(_abi.JssState), C.POINTER(_abi.JssOut)
+        # The single-set calls that loop over steps (rollout(n_iter > 1), trajectory, steps) run ONE launch over all the classes
+        # that fit one job per lane (they differ in nothing but the lane group the fused grid gives them) and one over the
+        # two-jobs-per-lane class: `ranges` = their (desc, state, out, first env) -- the first one's jclass says "below 64 jobs".
+        narrow = [i for i, (_, _, k) in enumerate(spans) if k < 3]
+        ranges = []
+        if len(narrow) > 1:
+            a, b = spans[narrow[0]][0], spans[narrow[-1]][1]
+            d0 = descs[narrow[0]]
+            dm = _abi.JssDesc(b - a, J, M, self.n_tables, d0.ops, d0.rem, d0.inst, d0.table_of_env, d0.env_ids, d0.env_id_base, d0.kernel,
+                              d0.threads, int(self.jobs_per_env[a:b].min()), self.record_ints, float(self._desc.cr_factor),
+                              int(self.jobs_per_env[a:b].max()), int(self.machines_per_env[a:b].max()))
+            ranges.append((dm, states[narrow[0]], outs[narrow[0]], a))
+            ranges += [(descs[i], states[i], outs[i], spans[i][0]) for i in range(n) if i not in narrow]
+        else:
+            ranges = [(descs[i], states[i], outs[i], spans[i][0]) for i in range(n)]
+        self._class_ranges = ranges
         self._classes = {"n": n, "spans": spans, "keep": (descs, states, outs),
                          "sets": ((D * n)(*[C.pointer(x) for x in descs]), (S * n)(*[C.pointer(x) for x in states]),
                                   (O * n)(*[C.pointer(x) for x in outs]))}
@@ -711,10 +727,10 @@ class BatchedJssEnv:
                 rc = be.lib.jss_multi_rollout(self._classes["n"], *self._classes["sets"], k, self.seed if seed is None else int(seed),
                                               int(round(explore * 65536)), 1, flags, 1, streams)
                 _abi.check(be.lib, rc, "jss_multi_rollout")
-            else:
-                _abi.check(be.lib, be.lib.jss_rollout(d, s, o, k, self.seed if seed is None else int(seed),
-                                                      int(round(explore * 65536)), int(n_iter), flags, be.stream()),
-                           "jss_rollout")
+                return self._obs(), self.reward, self.done, False, {}
+        sd, q16 = self.seed if seed is None else int(seed), int(round(explore * 65536))
+        # (by shape class: one launch per range -- below 64 jobs / the rest -- with the kernel of its shape)
+        self._over_ranges(lambda dk, sk, ok, _a, stream: be.lib.jss_rollout(dk, sk, ok, k, sd, q16, int(n_iter), flags, stream), "jss_rollout")
         return self._obs(), self.reward, self.done, False, {}
 
     def rollout_steps(self, kind: Union[str, int] = "random", steps: int = 1, n_sub: int = 2, seed: Optional[int] = None,
@@ -841,13 +857,53 @@ class BatchedJssEnv:
                 out[name] = t if t is not None and tuple(t.shape) == shape else be.zeros(shape, dtype)
         k = _abi.policy_code(kind)
         flags = _abi.ROLLOUT_AUTORESET if autoreset else 0
-        traj = _abi.JssTraj(*[be.ptr(out.get(n)) for n in ("real_obs", "action_mask", "action", "reward", "done")])
-        d, s, o = self._refs()
-        with be.on_device():
-            _abi.check(be.lib, be.lib.jss_trajectory(d, s, o, C.byref(traj), k, self.seed if seed is None else int(seed),
-                                                     int(round(explore * 65536)), K, flags, be.stream()),
-                       "jss_trajectory")
+        sd, q16 = self.seed if seed is None else int(seed), int(round(explore * 65536))
+        # (by shape class: one launch per range of the batch -- below 64 jobs / the rest -- each with the kernel of ITS shape,
+        #  recording into its columns of the whole batch's [K][B] buffers)
+        keep = []
+
+        def call(d, s, o, a, stream):
+            keep.append(self._traj_at(out, a))
+            return be.lib.jss_trajectory(d, s, o, C.byref(keep[-1]), k, sd, q16, K, flags, stream)
+        self._over_ranges(call, "jss_trajectory")
         return out
+
+    def _ranges(self):
+        """[(desc, state, out, first env)] a single-set call that loops over steps covers the batch with: the batch itself,
+        or -- dealt out by shape class -- the range of the classes below 64 jobs and the range of the rest, each with a JssDesc
+        of its own (jclass: the library picks the kernel of that shape: one job per lane / two)."""
+        if self._classes is None:
+            d, s, o = self._refs()
+            return [(d, s, o, 0)]
+        self._refs()                                  # (refuses while a session is open)
+        return [(C.byref(d), C.byref(s), C.byref(o), a) for d, s, o, a in self._class_ranges]
+
+    def _over_ranges(self, call, what):
+        """call(desc, state, out, first_env, stream) for every range of `_ranges()`: one range on the current stream; several
+        on the current stream + side streams forked from / joined back into it (a launch that loops over K steps lasts K step
+        latencies however few envs it holds -- two of them one after the other would take twice that)."""
+        be = self.backend
+        rs = self._ranges()
+        with be.on_device():
+            if len(rs) == 1 or not hasattr(be, "stream_array"):
+                for d, s, o, a in rs:
+                    _abi.check(be.lib, call(d, s, o, a, be.stream()), what)
+                return
+
+            def issue(streams):
+                for i, (d, s, o, a) in enumerate(rs):
+                    rc = call(d, s, o, a, streams[i])
+                    if rc:
+                        return rc
+                return 0
+            _abi.check(be.lib, be.with_streams(len(rs), issue, self._stream_events), what)
+
+    def _traj_at(self, bufs, a):
+        """JssTraj over the step-major [K][B] buffers `bufs` for the range of the batch that starts at env `a`."""
+        be, J = self.backend, self.jmax
+        per_env = {"real_obs": J * 7 * 4, "action_mask": J + 1, "action": 4, "reward": 4, "done": 1}
+        ptr = lambda n: (be.ptr(bufs[n]) + a * per_env[n]) if bufs.get(n) is not None else None      # noqa: E731
+        return _abi.JssTraj(ptr("real_obs"), ptr("action_mask"), ptr("action"), ptr("reward"), ptr("done"), self.batch)
 
     def steps(self, actions, record=(), buffers: Optional[dict] = None):
         """K consecutive ``step()`` calls per env in ONE launch (``jss_steps``): ``actions`` is a (K, B) int32 array of
@@ -874,10 +930,12 @@ class BatchedJssEnv:
                 shp, dtype = shapes[name]
                 t = None if buffers is None else buffers.get(name)
                 out[name] = t if t is not None and tuple(t.shape) == shp else be.zeros(shp, dtype)
-            traj = _abi.JssTraj(be.ptr(out.get("real_obs")), be.ptr(out.get("action_mask")), None, be.ptr(out.get("reward")),
-                                be.ptr(out.get("done")))
-            d, s, o = self._refs()
-            _abi.check(be.lib, be.lib.jss_steps(d, s, o, C.byref(traj), be.ptr(a), K, be.stream()), "jss_steps")
+        keep = []
+
+        def call(d, s, o, first, stream):         # (by shape class: one launch per range, see trajectory)
+            keep.append(self._traj_at({n: out.get(n) for n in ("real_obs", "action_mask", "reward", "done")}, first))
+            return be.lib.jss_steps(d, s, o, C.byref(keep[-1]), be.ptr(a) + first * 4, K, stream)
+        self._over_ranges(call, "jss_steps")
         self._steps_keep = a                  # alive until the launch has read it
         return out
 

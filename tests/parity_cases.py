@@ -838,13 +838,15 @@ def case_compact_limits(backend, shapes=((3, 64), (4, 32), (16, 16), (33, 8)), s
 
 
 def case_trajectory(backend, instances="ta01", batch=9, steps=40, kind="random", seed=17, explore=0.0, autoreset=True,
-                    warm=0, table_of_env=None):
+                    warm=0, table_of_env=None, order=None):
     """jss_trajectory (K steps per launch, every transition recorded) against K x (jss_policy, jss_step with next-step
     auto-reset) on a twin env: slot by slot the observation and mask the policy saw, the action it took (-2 where
     the env was found done and reset), reward and done; afterwards every state tensor and counter bit-identical to
     both that env and one advanced by jss_rollout(n_iter = K), the call jss_trajectory is defined as.
     (The step-by-step path itself is held to the oracle by case_batch_lockstep.)"""
-    kw = dict(batch=batch, seed=seed, env_id_base=5, _backend=backend, table_of_env=table_of_env)
+    # (a ragged list is dealt out by shape class by default: trajectory / rollout(n_iter > 1) then run one launch per class
+    #  range with the kernel of the class's shape, policy / step the fused grid; order="interleaved": the padded extents' kernel)
+    kw = dict(batch=batch, seed=seed, env_id_base=5, _backend=backend, table_of_env=table_of_env, order=order)
     a = BatchedJssEnv(instances, **kw)
     b = BatchedJssEnv(instances, **kw)
     a.reset()

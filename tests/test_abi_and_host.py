@@ -42,8 +42,10 @@ def test_header_constants_match_python_mirror():
     assert (defs["JSS_TODO_MASK"], defs["JSS_FLAG_LEGAL"], defs["JSS_FLAG_BLOCKED"], defs["JSS_NEXT2_SHIFT"]) == \
         (_abi.TODO_MASK, _abi.FLAG_LEGAL, _abi.FLAG_BLOCKED, _abi.NEXT2_SHIFT)
     assert defs["JSS_NI"] == _abi.NI == I.INST_RECORD_INTS and defs["JSS_I_RCP_MACHINES"] == _abi.I_RCP_MACHINES
-    for name, kid in _abi.KERNEL.items():
-        assert defs["JSS_KERNEL_" + name.upper()] == kid
+    for name, kid in _abi.KERNEL.items():          # "auto" / "wave", optionally "-1env" / "-2env" = the two form bits OR-ed in
+        base, _, form = name.partition("-")
+        bit = {"": 0, "1env": defs["JSS_KERNEL_ONE_ENV_PER_WAVE"], "2env": defs["JSS_KERNEL_TWO_ENVS_PER_WAVE"]}[form]
+        assert defs["JSS_KERNEL_" + base.upper()] | bit == kid
     assert (defs["JSS_E_NULL"], defs["JSS_E_SHAPE"], defs["JSS_E_KIND"], defs["JSS_E_LDS"]) == (_abi.E_NULL, _abi.E_SHAPE, _abi.E_KIND, _abi.E_LDS)
     assert defs["JSS_ABI_VERSION"] == _abi.ABI_VERSION
     assert defs["JSS_MAX_JOBS"] == _abi.MAX_JOBS == I.MAX_JOBS and defs["JSS_MAX_MACHINES"] == I.MAX_MACHINES
@@ -63,7 +65,7 @@ def test_header_constants_match_python_mirror():
     assert ctypes.sizeof(_abi.JssDesc) == 16 + 5 * 8 + 8 + 16 + 8 + 8 and ctypes.sizeof(_abi.JssState) == 48      # (+ double cr_factor, + jclass, mclass)
     assert _abi.POLICY_CR_F64 == defs["JSS_POLICY_CR"] | (1 << 24) and "#define JSS_POLICY_CR_F64 (JSS_POLICY_CR | (1 << 24))" in hdr
     assert ctypes.sizeof(_abi.JssState) == 48 and ctypes.sizeof(_abi.JssOut) == 40
-    assert ctypes.sizeof(_abi.JssTraj) == 40
+    assert ctypes.sizeof(_abi.JssTraj) == 48
 
 
 def test_argument_errors_without_gpu(hip_lib):
@@ -167,3 +169,19 @@ def test_integration_level2_stub_as_printed_on_the_twin():
     import parity_cases as P
     from jssenv_amd.build import build_cpu_twin
     P.case_integration_level2_stub(build_cpu_twin(), on_gpu=False)
+
+
+def test_no_kernel_uses_scratch_memory():
+    """Every kernel of the shipped library keeps its working set in registers: the code object's notes say 0 bytes of private
+    segment and 0 spilled VGPRs for each of them (SGPRs parked in spare VGPR lanes are not memory).  Round 5 shipped ten
+    kernels with 8-92 bytes of scratch -- in loops that keep the env state in registers that is memory traffic per iteration."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import LLVM, kernel_resources
+    if not os.path.isfile(os.path.join(LLVM, "llvm-readelf")):
+        pytest.skip("no llvm-readelf on this host")
+    from jssenv_amd.build import build_extension
+    rows = kernel_resources(build_extension())
+    assert len(rows) > 100
+    bad = [(n, vs, scratch) for n, _, _, vs, _, scratch in rows if vs or scratch]
+    assert not bad, f"kernels with scratch memory / spilled VGPRs: {bad}"

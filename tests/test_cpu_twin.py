@@ -116,6 +116,7 @@ def test_every_env_against_the_batch_oracle(cpu):
 def test_trajectory(cpu):
     P.case_trajectory(cpu, "ta01", batch=9, steps=60, kind="random", warm=200)
     P.case_trajectory(cpu, ["ta01", "ta31", "ta71"], batch=7, steps=40, kind="SPT", explore=0.2)
+    P.case_trajectory(cpu, ["ta01", "ta31", "ta71"], batch=7, steps=30, kind="SPT", explore=0.2, order="interleaved")
     P.case_trajectory(cpu, "ta01", batch=4, steps=12, kind="FIFO", warm=220, autoreset=False)
 
 
@@ -257,6 +258,7 @@ def test_launch_form_driver_and_render_rows(cpu):
 def test_steps_and_step_session(cpu):
     P.case_steps(cpu, dict(instances="ta01", batch=70), K=60, warm=200)
     P.case_steps(cpu, dict(instances=["ta01", "ta31", "ta71"], batch=11), K=40, kind="SPT", warm=5)
+    P.case_steps(cpu, dict(instances=["ta01", "ta31", "ta71"], batch=11, order="interleaved"), K=30, kind="SPT", warm=5)
     P.case_session(cpu, dict(instances="ta01", batch=50), K=36)
     P.case_session(cpu, dict(instances=["ta02", "ta51"], batch=7), K=20, kind="FIFO")
 

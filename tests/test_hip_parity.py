@@ -54,7 +54,8 @@ def test_rollout_ragged(hip):
 def test_trajectory_equals_policy_plus_step(hip):
     """jss_trajectory: K steps per launch, every transition recorded, == K x (jss_policy, jss_step)."""
     P.case_trajectory(hip, "ta01", batch=130, steps=300, kind="random", warm=150)       # shared table, crosses episode ends
-    P.case_trajectory(hip, ["ta01", "ta31", "ta51", "ta71"], batch=11, steps=120, kind="SPT", explore=0.2)   # ragged
+    P.case_trajectory(hip, ["ta01", "ta31", "ta51", "ta71"], batch=11, steps=120, kind="SPT", explore=0.2)   # ragged: by shape class
+    P.case_trajectory(hip, ["ta01", "ta31", "ta51", "ta71"], batch=11, steps=90, kind="random", order="interleaved")   # ragged, padded extents' kernel
     P.case_trajectory(hip, ["ta02", "ta03", "ta04"], batch=9, steps=260, kind="random")  # env -> instance map, global tables
     P.case_trajectory(hip, "ta41", batch=6, steps=40, kind="FIFO", warm=590, autoreset=False)
 
@@ -325,7 +326,8 @@ def test_two_envs_two_threads_two_streams():
 def test_steps_equal_repeated_step(hip):
     """jss_steps: K x jss_step per launch with the actions given up front, every step recorded."""
     P.case_steps(hip, dict(instances="ta01", batch=700), K=80, warm=180)                            # crosses episode ends
-    P.case_steps(hip, dict(instances=["ta01", "ta31", "ta51", "ta71"], batch=21), K=50, kind="SPT", warm=5)
+    P.case_steps(hip, dict(instances=["ta01", "ta31", "ta51", "ta71"], batch=21), K=50, kind="SPT", warm=5)       # one launch per shape class
+    P.case_steps(hip, dict(instances=["ta01", "ta31", "ta51", "ta71"], batch=21, order="interleaved"), K=50, kind="SPT", warm=5)
     P.case_steps(hip, dict(instances=["ta02", "ta03", "ta04"], batch=130), K=40)                    # env -> instance map
 
 

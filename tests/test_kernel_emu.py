@@ -133,7 +133,8 @@ def test_nope_fuzz_tiny_instances(emu):
 
 def test_trajectory_equals_policy_plus_step(emu):
     P.case_trajectory(emu, "ta01", batch=9, steps=40, kind="random", warm=200)          # crosses episode ends
-    P.case_trajectory(emu, ["ta01", "ta31", "ta71"], batch=5, steps=25, kind="SPT", explore=0.2)   # ragged, two jobs per lane
+    P.case_trajectory(emu, ["ta01", "ta31", "ta71"], batch=5, steps=25, kind="SPT", explore=0.2)   # ragged: one launch per shape class
+    P.case_trajectory(emu, ["ta01", "ta31", "ta71"], batch=5, steps=14, kind="SPT", explore=0.2, order="interleaved")   # two jobs per lane + narrow body
 
 
 def test_trajectory_frozen_without_autoreset(emu):
@@ -154,7 +155,8 @@ def test_compact_records_at_the_limits(emu):
 
 def test_steps_equal_repeated_step(emu):
     P.case_steps(emu, dict(instances="ta01", batch=9), K=30, warm=200)                           # crosses episode ends
-    P.case_steps(emu, dict(instances=["ta01", "ta31", "ta71"], batch=5), K=16, kind="SPT", warm=5)   # ragged, two jobs per lane
+    P.case_steps(emu, dict(instances=["ta01", "ta31", "ta71"], batch=5), K=16, kind="SPT", warm=5)   # ragged: one launch per shape class
+    P.case_steps(emu, dict(instances=["ta01", "ta31", "ta71"], batch=5, order="interleaved"), K=10, kind="SPT", warm=5)   # two jobs per lane
 
 
 def test_step_session_resident_kernel(emu):

@@ -7,6 +7,8 @@ JSSENV_AMD_LIB points somewhere else.
     variants/pg8.so         -DJSS_PACKED_GLOBAL_MIN_BLOCKS=8: packed per-env-table step kernels at 8 waves/SIMD (2 VGPRs in scratch)
     variants/w2occ8.so      -DJSS_WAVE2_MIN_BLOCKS=8: the two-jobs-per-lane one-step rollout at 8 waves/SIMD
     variants/nodeepwalk.so  -DJSS_EXP_NO_DEEP_WALK: the look-ahead walk without op-table reads (WRONG results; a ceiling)
+    variants/plaincounters.so  -DJSS_COUNTERS_PLAIN: packed fused rollouts load / store their env's counter row with the state
+                               instead of bumping it with atomics (round 6 A/B); nocounters.so: no counters at all (a ceiling)
 
 One-off experiments whose findings are recorded in profiles/README.md (streaming hints on other streams, rewriting
 every record, the walk without op table reads) were compile-time variants of the same sources at the commits named
@@ -20,7 +22,8 @@ sys.path.insert(0, ROOT)
 from jssenv_amd.build import build_extension  # noqa: E402
 
 VARIANTS = {"profiling": ["-DJSS_PROFILING"], "occ7": ["-DJSS_WAVE_MIN_BLOCKS=7"], "pg8": ["-DJSS_PACKED_GLOBAL_MIN_BLOCKS=8"],
-            "nodeepwalk": ["-DJSS_EXP_NO_DEEP_WALK"], "w2occ8": ["-DJSS_WAVE2_MIN_BLOCKS=8"]}
+            "nodeepwalk": ["-DJSS_EXP_NO_DEEP_WALK"], "w2occ8": ["-DJSS_WAVE2_MIN_BLOCKS=8"],
+            "plaincounters": ["-DJSS_COUNTERS_PLAIN"], "nocounters": ["-DJSS_EXP_NO_COUNTERS"]}
 
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "variants"), exist_ok=True)

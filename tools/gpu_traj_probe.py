@@ -1,4 +1,6 @@
-"""GPU box: env-steps/s of jss_trajectory (K steps per launch, everything recorded) on the benchmark workloads."""
+"""GPU box: env-steps/s of jss_trajectory (K steps per launch, everything recorded) and of jss_steps (the same K steps replayed
+from the recorded actions, everything recorded) on the benchmark workloads -- the A/B harness of the kernels that loop over
+steps with the state in registers (JSSENV_AMD_LIB=variants/<x>.so python tools/gpu_traj_probe.py)."""
 import os
 import sys
 import time
@@ -31,5 +33,22 @@ for what, B in (("ta01", 65536), ("ta01", 4096), ("synthetic50x20", 8192), ("mix
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         best = max(best, env.stats()["steps"] / dt)
-    print(f"traj K={K} {what} B={B}: {best / 1e9:.3f} G env-steps/s  lib={os.path.basename(os.environ.get('JSSENV_AMD_LIB', 'shipped'))}", flush=True)
-    del env, bufs
+    lib = os.path.basename(os.environ.get('JSSENV_AMD_LIB', 'shipped'))
+    print(f"traj  K={K} {what} B={B}: {best / 1e9:.3f} G env-steps/s  lib={lib}", flush=True)
+    # jss_steps: the recorded actions of one trajectory launch, replayed from the state they were recorded in
+    snap = env._arena.clone(), env.solution.clone()
+    acts = env.trajectory("random", steps=K, record=("action",))["action"]
+    n_steps = int((acts >= 0).sum().item())
+    rec = ("real_obs", "action_mask", "reward", "done")
+    sb = None
+    best = 0.0
+    for rep in range(5):
+        env._arena.copy_(snap[0])
+        env.solution.copy_(snap[1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sb = env.steps(acts, record=rec, buffers=sb)
+        torch.cuda.synchronize()
+        best = max(best, n_steps / (time.perf_counter() - t0))
+    print(f"steps K={K} {what} B={B}: {best / 1e9:.3f} G env-steps/s  lib={lib}", flush=True)
+    del env, bufs, sb
