@@ -199,4 +199,4 @@ def test_policy_step_steps_equals_the_loop(emu):
 def test_two_envs_per_wavefront():
     """jss_kernel_two under the emulator (small batches take the form on request)."""
     from emu_backend import EmuBackend
-    P.case_two_envs_per_wavefront(EmuBackend(default_kernel="wave-2env"), EmuBackend(default_kernel="wave-1env"), steps=36, n_envs=5)
+    P.case_two_envs_per_wavefront(EmuBackend(default_kernel="wave-2env"), EmuBackend(default_kernel="wave-1env"), steps=24, n_envs=5)
