@@ -10,7 +10,9 @@ fallback -- the host-core twin ``libjss_cpu.so`` with the same C ABI.
 from .instances import (Instance, PackedBatch, available_instances, builtin_instance, load_batch,  # noqa: F401
                         load_instance_file, pack_batch, parse_instance_text, save_batch, synthetic_batch,
                         synthetic_packed, taillard_instance)
-from .env import BatchedJssEnv, CpuBackend, HipBackend, JssEnv, make, make_backend  # noqa: F401
+from .backends import CpuBackend, HipBackend, make_backend  # noqa: F401
+from .env import BatchedJssEnv  # noqa: F401
+from .facade import JssEnv, make  # noqa: F401
 from .bucketed import BucketedJssEnv  # noqa: F401
 from .vector import JssVectorEnv  # noqa: F401
 
@@ -21,7 +23,7 @@ def _register_with_gymnasium():
     """``gym.make('jss-v1', env_config=...)`` as in JSSEnv/__init__.py:6-9, when gymnasium exists."""
     try:
         from gymnasium.envs.registration import register
-        register(id="jss-v1", entry_point="jssenv_amd.env:JssEnv")
+        register(id="jss-v1", entry_point="jssenv_amd.facade:JssEnv")
     except Exception:
         pass
 

@@ -1,22 +1,9 @@
 """Host side of the batched MI355X job-shop environment.
 
-``BatchedJssEnv`` owns the per-env state as PyTorch-ROCm tensors laid out over a
-batch axis (include/jss_hip.h describes the layout) and advances it with the
-HIP kernels of ``libjss_hip.so`` through the C ABI.  ``JssEnv`` is the
-single-env view with the reference's exact surface
-(JSSEnv/envs/jss_env.py: ``reset() -> obs``, ``step(a) -> (obs, reward, done,
-False, {})``, ``get_legal_actions()``, ``increase_time_step()`` and the public
-attributes its tests and dispatching rules read).
-
-Two backends implement the same C ABI:
-
-* ``HipBackend`` (default): torch.cuda tensors + ``libjss_hip.so``.  Constructing it
-  without a GPU or without the built extension raises -- there is NO silent fallback.
-* ``CpuBackend`` (``device="cpu"``, explicit only): NumPy arrays + ``libjss_cpu.so``,
-  the from-scratch C++/OpenMP twin with identical symbols (BASELINE config 1, "runs
-  without a GPU"; also bench.py's ``cpu_baseline`` kind "twin").
-
-torch is used for device memory and streams only.
+``BatchedJssEnv`` owns the per-env state as PyTorch-ROCm tensors laid out over a batch axis (include/jss_hip.h describes the
+layout) and advances it with the HIP kernels of ``libjss_hip.so`` through the C ABI.  Memory and library handles come from a
+backend (``jssenv_amd.backends``: ``HipBackend`` by default -- no silent CPU path -- or, on request, ``CpuBackend``, the
+host-core twin); the single-env view with the reference's surface is ``jssenv_amd.facade.JssEnv``.
 """
 from __future__ import annotations
 
@@ -27,294 +14,8 @@ from typing import Optional, Sequence, Union
 import numpy as np
 
 from . import _abi
+from .backends import _NULL_CTX, CpuBackend, HipBackend, _carve_numpy, make_backend  # noqa: F401  (re-exported: the historical home)
 from .instances import Instance, PackedBatch, pack_batch, resolve_instance
-
-
-class HipBackend:
-    """Device memory = torch.cuda tensors; kernels = libjss_hip.so on torch's current stream."""
-
-    name = "hip"
-    default_kernel = "auto"
-
-    def __init__(self, device=None):
-        import torch
-        if not torch.cuda.is_available():
-            raise RuntimeError("jssenv_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no silent "
-                               "CPU fallback -- pass device='cpu' to run on the host-core twin (libjss_cpu.so) on purpose")
-        path = _abi.library_path()
-        if not os.path.isfile(path):
-            raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
-        self.torch = torch
-        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-        if self.device.type != "cuda":
-            raise ValueError(f"HipBackend needs a cuda device, got {self.device}")
-        if self.device.index is None:
-            self.device = torch.device("cuda", torch.cuda.current_device())
-        self.lib = _abi.bind(C.CDLL(path))
-        if not self.lib.jss_backend().startswith(b"hip"):
-            raise RuntimeError(f"{path} is not the HIP library ({self.lib.jss_backend()!r})")
-        self._scalars = {}
-        self._stream_arrays = {}
-        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-
-    # -- memory ----------------------------------------------------------------------------
-    def zeros(self, shape, dtype):
-        return self.torch.zeros(shape, dtype=getattr(self.torch, dtype), device=self.device)
-
-    def from_numpy(self, a):
-        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-
-    def zeros_pinned(self, shape, dtype):
-        """Zero-filled page-locked HOST memory the device reads and writes in place (hipHostMalloc: coherent, uncached on
-        the GPU): a tensor on the CPU whose data_ptr() the kernels take like any other -- the B = 1 facade's arena."""
-        return self.torch.zeros(shape, dtype=getattr(self.torch, dtype), pin_memory=True)
-
-    def ptr(self, x):
-        return 0 if x is None else x.data_ptr()
-
-    def numpy(self, x):
-        if isinstance(x, np.ndarray):              # (host-derived attributes are NumPy already)
-            return x
-        if x.device.type == "cpu":                 # a view of a host arena: the kernels write it in place -- wait, then copy
-            self.sync()
-            return x.detach().numpy().copy()
-        return x.detach().cpu().numpy()
-
-    def as_device(self, x, dtype):
-        t = self.torch.as_tensor(x, device=self.device)
-        return t.to(getattr(self.torch, dtype)).contiguous()
-
-    def stage(self, buf, x):
-        """`x` (device tensor of any integer dtype, NumPy array, list) as a contiguous device tensor of buf's dtype:
-        `x` itself when it already is one, otherwise copied into the preallocated `buf` -- nothing is allocated on the
-        device (an int64 tensor, what argmax returns, is converted by the copy kernel)."""
-        t = self.torch
-        if isinstance(x, t.Tensor):
-            if tuple(x.shape) != tuple(buf.shape):      # checked first: the kernels read buf.numel() elements
-                raise ValueError(f"expected shape {tuple(buf.shape)}, got {tuple(x.shape)}")
-            if x.device == buf.device and x.dtype == buf.dtype and x.is_contiguous():
-                return x
-            buf.copy_(x)
-            return buf
-        a = np.ascontiguousarray(np.asarray(x), dtype=np.dtype(str(buf.dtype).split(".")[-1]))
-        if a.shape != tuple(buf.shape):
-            raise ValueError(f"expected shape {tuple(buf.shape)}, got {a.shape}")
-        buf.copy_(t.from_numpy(a))
-        return buf
-
-    def copy_into(self, dst, src):
-        if isinstance(src, np.ndarray):
-            src = self.torch.from_numpy(np.ascontiguousarray(src))
-        dst.copy_(src)
-
-    def carve(self, arena, off, shape, dtype):
-        """View of `arena` (flat uint8 tensor) at byte offset `off` as `shape` / `dtype`."""
-        dt = getattr(self.torch, dtype)
-        n = int(np.prod(shape)) * dt.itemsize
-        return arena[off:off + n].view(dt).view(shape)
-
-    def snapshot(self, arena, host=None):
-        """One device -> host copy of a whole arena into a pinned staging buffer (reused); returns the NumPy view."""
-        t = self.torch
-        if host is None or host.numel() != arena.numel():
-            host = t.empty(arena.numel(), dtype=t.uint8, pin_memory=True)
-        host.copy_(arena, non_blocking=True)
-        t.cuda.current_stream(self.device).synchronize()
-        return host, host.numpy()
-
-    def select_into(self, out, flags, a, b):
-        """out[...] = where(flags != 0, a (scalar), b): one elementwise kernel, nothing allocated (`flags` is a uint8
-        tensor holding 0 / 1, reinterpreted as bool)."""
-        self.torch.where(flags.view(self.torch.bool), self.scalar(a, out.dtype), b, out=out)
-
-    def scalar(self, value, dtype):
-        """Cached 0-dim device tensor (created outside any stream capture: BatchedJssEnv makes the ones it needs
-        when it is constructed)."""
-        key = (int(value), str(dtype))
-        if key not in self._scalars:
-            dt = getattr(self.torch, dtype) if isinstance(dtype, str) else dtype
-            self._scalars[key] = self.torch.tensor(int(value), dtype=dt, device=self.device)
-            self._scalars[(int(value), str(dt))] = self._scalars[key]
-        return self._scalars[key]
-
-    # -- execution -------------------------------------------------------------------------
-    def stream(self):
-        """Raw handle of torch's current stream on this backend's device (the private accessor where torch has it: 0.3 us
-        against 3 us for building a torch.cuda.Stream object and asking for its .cuda_stream -- per launch)."""
-        raw = self._raw_stream
-        if raw is not None:
-            return raw(self.device.index)
-        return self.torch.cuda.current_stream(self.device).cuda_stream
-
-    def sync(self):
-        self.torch.cuda.current_stream(self.device).synchronize()
-
-    def on_device(self):
-        """Context making this backend's device current (kernel launches go to its streams)."""
-        t = self.torch
-        if t.cuda.current_device() == self.device.index:
-            return _NULL_CTX
-        return t.cuda.device(self.device)
-
-    def with_streams(self, n, fn, events=None):
-        """Call fn(streams) where streams is a (void* * n) array: the current stream plus n-1 side streams that
-        are forked from it before the call and joined back into it afterwards (stream-ordered for the caller,
-        capturable in a hipGraph).  The side streams are created once per process and device and shared by every
-        env: HIP deals streams onto a handful of hardware queues in creation order, and a side stream that lands
-        on the caller's queue serialises the sub-batches it was created to overlap (seen in a long-running bench
-        process: 2 sub-batches slower than one launch until the streams were pinned like this).  The fork / join
-        EVENTS belong to the caller (`events`: a dict the env object keeps), so two envs driven from two host
-        threads order their side work against their own streams; the side streams themselves are still shared,
-        i.e. such envs' sub-batch work is serialised on them -- one host thread per device is the intended use."""
-        t = self.torch
-        main = t.cuda.current_stream(self.device)
-        pool = self.side_pool(n - 1)
-        side = pool["streams"][:n - 1]
-        ev = events if events is not None else pool.setdefault("events", {})
-        if "fork" not in ev:
-            ev["fork"], ev["join"] = t.cuda.Event(), []
-        while len(ev["join"]) < n - 1:
-            ev["join"].append(t.cuda.Event())
-        if side:
-            ev["fork"].record(main)
-            for st in side:
-                st.wait_event(ev["fork"])
-        arr = (C.c_void_p * n)(main.cuda_stream, *[st.cuda_stream for st in side])
-        rc = fn(arr)
-        for i, st in enumerate(side):
-            ev["join"][i].record(st)
-            main.wait_event(ev["join"][i])
-        return rc
-
-    def stream_array(self, n):
-        """(void* * n): the current stream + n - 1 of the process-wide side streams, for JSS_ROLLOUT_FORK_JOIN calls."""
-        main = self.stream()
-        key = (n, main)
-        arr = self._stream_arrays.get(key)
-        if arr is None:
-            side = self.side_pool(n - 1)["streams"][:n - 1]
-            arr = self._stream_arrays[key] = (C.c_void_p * n)(main, *[st.cuda_stream for st in side])
-        return arr
-
-    def side_pool(self, n):
-        """The process-wide side streams of this device (at least n of them)."""
-        t = self.torch
-        pool = _SIDE_STREAMS.setdefault(self.device.index, {"streams": []})
-        while len(pool["streams"]) < n:
-            pool["streams"].append(t.cuda.Stream(device=self.device))
-        return pool
-
-    def close(self):
-        pass
-
-
-_SIDE_STREAMS = {}    # device index -> side streams / events of HipBackend.with_streams (process-wide)
-
-
-class _NullCtx:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
-
-
-_NULL_CTX = _NullCtx()
-
-
-class CpuBackend:
-    """Host memory = NumPy arrays; stepping = libjss_cpu.so (C++17 + OpenMP over envs, same C ABI, written from the
-    kernels' queue-free state).  Explicit choice only (``device='cpu'``); never a fallback of the HIP path."""
-
-    name = "cpu"
-    default_kernel = "auto"
-    device = "cpu"
-
-    def __init__(self, threads: int = 0):
-        from .build import build_cpu_twin
-        try:
-            path = build_cpu_twin()               # no-op when the in-tree library is newer than its sources
-        except Exception as exc:                  # no compiler on this host: a prebuilt library of this ABI still serves
-            path = _abi.library_path("libjss_cpu.so")
-            if not os.path.isfile(path):
-                raise RuntimeError(f"device='cpu' needs {path}: build it with `g++ -O3 -std=c++17 -fopenmp -fPIC -shared "
-                                   f"-Iinclude jssenv_amd/csrc/jss_cpu.cpp -o {path}` (automatic build failed: {exc})") from exc
-        self.lib = _abi.bind(C.CDLL(path))
-        if not self.lib.jss_backend().startswith(b"cpu"):
-            raise RuntimeError(f"{path} is not the CPU twin ({self.lib.jss_backend()!r})")
-        self.threads = int(threads)
-        self._keep = None
-
-    def zeros(self, shape, dtype):
-        return np.zeros(shape, dtype=getattr(np, dtype))
-
-    def from_numpy(self, a):
-        return np.ascontiguousarray(a).copy()
-
-    def ptr(self, x):
-        if x is None:
-            return 0
-        assert x.flags["C_CONTIGUOUS"]
-        return x.ctypes.data
-
-    def numpy(self, x):
-        return np.array(x, copy=True)
-
-    def as_device(self, x, dtype):
-        a = np.ascontiguousarray(np.asarray(x).astype(getattr(np, dtype), copy=False))
-        self._keep = a
-        return a
-
-    def stage(self, buf, x):
-        a = np.asarray(x)
-        if a.shape != buf.shape:
-            raise ValueError(f"expected shape {buf.shape}, got {a.shape}")
-        if a.dtype == buf.dtype and a.flags["C_CONTIGUOUS"]:
-            self._keep = a
-            return a
-        buf[...] = a
-        return buf
-
-    def copy_into(self, dst, src):
-        dst[...] = src
-
-    def carve(self, arena, off, shape, dtype):
-        return _carve_numpy(arena, off, shape, dtype)
-
-    def snapshot(self, arena, host=None):
-        return arena, arena                 # host memory already: the "copy" is the arena itself
-
-    def select_into(self, out, flags, a, b):
-        np.copyto(out, b)
-        out[flags != 0] = a
-
-    def stream(self):
-        return 0
-
-    def sync(self):
-        pass
-
-    def on_device(self):
-        return _NULL_CTX
-
-    def with_streams(self, n, fn, events=None):
-        return fn((C.c_void_p * n)())
-
-    def close(self):
-        pass
-
-
-def _carve_numpy(arena, off, shape, dtype):
-    dt = np.dtype(dtype)
-    n = int(np.prod(shape)) * dt.itemsize
-    return arena[off:off + n].view(dt).reshape(shape)
-
-
-def make_backend(device=None):
-    """``None`` / ``'cuda[:i]'`` -> HipBackend (raises without a GPU); ``'cpu'`` -> CpuBackend."""
-    if device is not None and str(device).startswith("cpu"):
-        return CpuBackend()
-    return HipBackend(device)
 
 
 class BatchedJssEnv:
@@ -1275,386 +976,10 @@ class _LazyRows:
         return self._fetch()[i]
 
 
-class _Snap:
-    """Env 0 of a host snapshot, decoded lazily: ``step()`` needs the observation, mask, reward, done and the error
-    bits; everything else (the per-job arrays the reference exposes as attributes) is unpacked when it is read."""
-
-    def __init__(self, t, J, M, decode):
-        self.t, self.J, self.M, self.c, self.decode = t, J, M, {}, decode
-
-    def __contains__(self, k):
-        return k in self.c
-
-    def __setitem__(self, k, v):
-        self.c[k] = v
-
-    def __getitem__(self, k):
-        c = self.c
-        if k in c:
-            return c[k]
-        t, J, M = self.t, self.J, self.M
-        if k in ("clock", "err", "noop_flag", "episode", "step_in_episode"):
-            hdr = t["env_header"][0]
-            st = int(hdr[_abi.H_STATUS])
-            c.update(clock=int(hdr[_abi.H_CLOCK]), err=st & 0xFF, noop_flag=bool(st & _abi.STATUS_NOOP),
-                     episode=int(hdr[_abi.H_EPISODE]), step_in_episode=int(hdr[_abi.H_STEP]))
-        elif k in ("job_state", "next_op", "next2_op", "blocked"):
-            js, nxt, nxt2 = self.decode(t["job_state"][0], 0)
-            c.update(job_state=js, next_op=nxt, next2_op=nxt2, blocked=(js[7] & 2) != 0)
-        elif k == "tm":
-            c[k] = (t["machine_state"][0, :M].astype(np.int64) if "machine_state" in t else
-                    BatchedJssEnv.clocks_from_jobs(self["job_state"], M))
-        elif k == "mask":
-            c[k] = t["action_mask"][0, :J + 1] != 0
-        elif k == "obs":
-            c[k] = t["real_obs"][0, :J].copy()
-        elif k == "reward":
-            c[k] = float(t["reward"][0])
-        elif k == "done":
-            c[k] = bool(t["done"][0])
-        elif k == "makespan":
-            c[k] = int(t["makespan"][0])
-        elif k == "counters":
-            c[k] = t["counters"][0].copy()
-        elif k == "mask_padding":
-            c[k] = t["action_mask"][0, J + 1:].copy()
-        elif k == "obs_padding":
-            c[k] = t["real_obs"][0, J:].copy()
-        else:
-            raise KeyError(k)
-        return c[k]
-
-
-def gymnasium_base(which: str = "Env"):
-    """``gymnasium.Env`` (or ``gymnasium.vector.VectorEnv``) when gymnasium is importable and really has that class,
-    ``object`` otherwise: the reference's env IS a ``gym.Env`` (jss_env.py:14) and gymnasium's wrappers assert
-    ``isinstance(env, gymnasium.Env)``; without gymnasium the package works all the same."""
-    try:
-        import gymnasium
-        base = getattr(gymnasium, "Env", None) if which == "Env" else getattr(getattr(gymnasium, "vector", None), "VectorEnv", None)
-        return base if isinstance(base, type) else object
-    except Exception:
-        return object
-
-
-class JssEnv(gymnasium_base("Env")):
-    """Drop-in for ``JSSEnv.envs.jss_env.JssEnv``: one env (B = 1) on the GPU (a ``gymnasium.Env`` when gymnasium exists).
-
-    Same constructor argument (``env_config={'instance_path': ...}``, default ta80 as at
-    jss_env.py:35-38), same methods and return shapes, same public attributes (NumPy, pulled
-    from the device on access).  Differences, all outside what the reference defines:
-    a job action outside the mask raises ``ValueError`` (the reference corrupts its counters
-    silently); the observation is float32.  ``device='cpu'`` runs the same env on the
-    host-core twin (no GPU needed).
-    """
-
-    metadata = {"render_modes": ["human"]}
-
-    def __init__(self, env_config=None, device=None, _backend=None):
-        if env_config is None:
-            env_config = {"instance_path": "ta80"}                         # jss_env.py:35-38
-        inst = resolve_instance(env_config["instance_path"])
-        self.instance = inst
-        self.jobs, self.machines = inst.jobs, inst.machines                # :77
-        self.instance_matrix = inst.instance_matrix                        # :78,:85
-        self.jobs_length = inst.jobs_length                                # :87
-        self.max_time_op = inst.max_time_op                                # :86
-        self.max_time_jobs = inst.max_time_jobs                            # :89
-        self.sum_op = inst.sum_op                                          # :88
-        self.last_time_step = float("inf")                                 # :53
-        self.last_solution = None                                          # :52
-        import datetime
-        import random
-        self.start_timestamp = datetime.datetime.now().timestamp()         # :70 (render's time origin, :672)
-        self.colors = [tuple(random.random() for _ in range(3)) for _ in range(self.machines)]   # :99-101, used by render :686
-        self._alloc_log = []        # the job actions of this episode in call order (next_jobs: who queued an event first)
-        self._alloc_log_ok = True   # False once the episode was advanced by a device-side rollout (no per-call log)
-        # on the GPU the env's arena (state + outputs, ~1 KB) lives in page-locked host memory the kernel works on in
-        # place: step() = one launch + one stream synchronisation, nothing is copied (JSSENV_AMD_HOST_ARENA=0: device
-        # memory and one device -> host copy per step, the round-3 form)
-        self._b = BatchedJssEnv([inst], batch=1, device=device, _backend=_backend,
-                                host_arena=os.environ.get("JSSENV_AMD_HOST_ARENA", "1") != "0")
-        self._cache = None
-        self._act = np.zeros(1, dtype=np.int32)
-        # remaining work of job j from op k on (MWR / LWR / CR on the host): suffix sums of the durations
-        self._remaining = np.cumsum(inst.duration[:, ::-1], axis=1)[:, ::-1].astype(np.int64)
-        self._act_pinned, self._zero_copy, self._fast = None, False, None
-        be = self._b.backend
-        if getattr(be, "name", "") == "hip":
-            self._act_pinned = be.torch.zeros(1, dtype=be.torch.int32).pin_memory()
-            # JSSENV_AMD_ZEROCOPY=1: jss_step reads the action straight from the pinned host word (one H2D copy less per step)
-            self._zero_copy = os.environ.get("JSSENV_AMD_ZEROCOPY", "0") == "1"
-        try:  # spaces only when gymnasium is importable (jss_env.py:97, :112-119)
-            import gymnasium as gym
-            self.action_space = gym.spaces.Discrete(self.jobs + 1)
-            self.observation_space = gym.spaces.Dict({
-                "action_mask": gym.spaces.Box(0, 1, shape=(self.jobs + 1,)),
-                "real_obs": gym.spaces.Box(low=0.0, high=1.0, shape=(self.jobs, 7), dtype=float),
-            })
-        except ImportError:  # gymnasium is optional
-            self.action_space = self.observation_space = None
-
-    # -- host mirror of the device state ---------------------------------------------------
-    def _h(self):
-        if self._cache is None:                    # one device -> host copy per step (the env's arena), decoded lazily
-            self._cache = _Snap(self._b.host_tensors(), self.jobs, self.machines, self._b.decode_jobs)
-        return self._cache
-
-    def _solution(self):
-        h = self._h()
-        if "solution" not in h:                    # the start-time table comes over only when somebody reads it
-            b = self._b
-            h["solution"] = b.backend.numpy(b.solution[0])[:self.jobs, :self.machines].astype(np.int64)
-        return h["solution"]
-
-    def _obs(self):
-        h = self._h()
-        return {"real_obs": h["obs"], "action_mask": h["mask"]}
-
-    current_time_step = property(lambda s: s._h()["clock"])
-    todo_time_step_job = property(lambda s: s._h()["job_state"][_abi.F_TODO])
-    needed_machine_jobs = property(lambda s: s._h()["job_state"][_abi.F_CUR] >> 16)
-    time_until_finish_current_op_jobs = property(lambda s: s._h()["job_state"][_abi.F_LEFT])
-    total_perform_op_time_jobs = property(lambda s: s._h()["job_state"][_abi.F_PERF])
-    total_idle_time_jobs = property(lambda s: s._h()["job_state"][_abi.F_IDLE])
-    idle_time_jobs_last_op = property(lambda s: s._h()["job_state"][_abi.F_IDLE_LAST])
-    time_until_available_machine = property(lambda s: s._h()["tm"])
-    solution = property(lambda s: s._solution())
-    legal_actions = property(lambda s: s._h()["mask"])
-    action_illegal_no_op = property(lambda s: s._h()["blocked"])
-    state = property(lambda s: s._h()["obs"])
-    err = property(lambda s: s._h()["err"])
-
-    @property
-    def nb_legal_actions(self):            # stored counter in the reference; a popcount here
-        return int(self.legal_actions[:-1].sum())
-
-    @property
-    def machine_legal(self):               # reference :173-179, :463, :632-634
-        out = np.zeros(self.machines, dtype=bool)
-        need = self.needed_machine_jobs
-        out[need[self.legal_actions[:-1]]] = True
-        return out
-
-    @property
-    def nb_machine_legal(self):
-        return int(self.machine_legal.sum())
-
-    @property
-    def next_time_step(self):              # the reference's sorted event list (:449-453, :517)
-        tm = self.time_until_available_machine
-        return sorted({int(self.current_time_step + v) for v in tm if v > 0})
-
-    @property
-    def next_jobs(self):
-        """The reference's list parallel to ``next_time_step`` (jss_env.py:56, :156, :453, :518): entry i is the job whose
-        allocation QUEUED event time ``next_time_step[i]`` -- the first job allocated to finish at that time; a later job
-        that finishes at the same time adds nothing (:450-453).  Derived: the running ops (start = solution[j][todo[j]],
-        end = start + duration > now) sorted by end time; among ops that end together the one allocated first -- the
-        earlier start, then the earlier ``step`` call of this episode (the facade logs its job actions; after a device-side
-        rollout there is no log and the lower job index stands in)."""
-        now = self.current_time_step
-        left, todo = self.time_until_finish_current_op_jobs, self.todo_time_step_job
-        running = [j for j in range(self.jobs) if left[j] > 0]
-        if not running:
-            return []
-        sol = self._solution()
-        rank = {}
-        if self._alloc_log_ok:
-            for pos, j in enumerate(self._alloc_log):
-                rank[j] = pos                                # the LAST allocation of job j is its running op
-        first = {}
-        for j in running:
-            end = int(now + left[j])
-            key = (int(sol[j][todo[j]]), rank.get(j, len(self._alloc_log) + j), j)
-            if end not in first or key < first[end][0]:
-                first[end] = (key, j)
-        return [first[t][1] for t in sorted(first)]
-
-    @property
-    def illegal_actions(self):             # (M, J) matrix of the reference (:171, :427, :464-467)
-        out = np.zeros((self.machines, self.jobs), dtype=bool)
-        need, bl = self.needed_machine_jobs, self.action_illegal_no_op
-        for j in range(self.jobs):
-            if bl[j] and need[j] >= 0:
-                out[need[j], j] = True
-        return out
-
-    # -- reference API -----------------------------------------------------------------------
-    def get_legal_actions(self):           # jss_env.py:136-143
-        return self.legal_actions
-
-    def reset(self, *, seed=None, options=None):
-        """jss_env.py:145-181 -- returns the observation dict only (no info tuple)."""
-        self._b.reset()
-        self._cache = None
-        self._alloc_log, self._alloc_log_ok = [], True
-        return self._obs()
-
-    def _raise_for(self, err, action=None):
-        """Turn the kernel's per-env error bits into the reference's exceptions.  The bits are sticky on the
-        device, so they are cleared here: every offending call raises, not only the first of an episode."""
-        if not err:
-            return
-        self._b.clear_errors()
-        self._cache = None
-        if err & _abi.ERR_ILLEGAL_ACTION and self._alloc_log and self._alloc_log[-1] == action:
-            self._alloc_log.pop()                  # the job was not allocated
-        if err & _abi.ERR_BAD_ACTION:
-            raise IndexError(f"action {action} out of range for {self.jobs} jobs")
-        if err & _abi.ERR_NOPE_IDLE:
-            raise IndexError("pop from empty list")  # what the reference raises at jss_env.py:517
-        if err & _abi.ERR_ILLEGAL_ACTION:
-            raise ValueError(f"job {action} is not a legal action")
-
-    def step(self, action):
-        """jss_env.py:403-481."""
-        action = int(action)
-        if 0 <= action < self.jobs:
-            self._alloc_log.append(action)         # (an action the mask refuses raises below and queues nothing: popped there)
-        if getattr(self._b, "host_arena", False):  # GPU, arena in host memory: the action word is part of it
-            return self._step_host_arena(action)
-        elif self._act_pinned is not None:         # GPU: the action goes out through a pinned word, nothing is allocated
-            self._act_pinned[0] = action
-            b = self._b
-            if self._zero_copy:                    # the kernel reads the pinned word itself
-                b.step_raw(self._act_pinned.data_ptr())
-            else:
-                b._act_in.copy_(self._act_pinned, non_blocking=True)
-                b.step_raw(b._act_in.data_ptr())
-        else:
-            self._act[0] = action
-            self._b.step(self._act)
-        self._cache = None
-        h = self._h()
-        self._raise_for(h["err"], action)
-        if h["done"]:                                                       # :649-652
-            self.last_time_step = h["clock"]
-            self.last_solution = self._solution()
-        return self._obs(), h["reward"], h["done"], False, {}
-
-    def _step_host_arena(self, action):
-        """step() when the env's arena is page-locked host memory: the action is written into it, ONE launch works on it
-        in place, one stream synchronisation (through the library: it also surfaces a kernel fault), and the results are
-        read where they lie.  Everything that does not change between calls is bound once."""
-        fp = self._fast
-        if fp is None:
-            b, be = self._b, self._b.backend
-            if not b._is_reset:
-                raise RuntimeError("call reset() before step()")
-            lib, (d, s, o) = be.lib, b._refs()
-            views = b.host_tensors()
-            # torch's current stream of the env's device as a raw handle: the private accessor costs 0.3 us, building a
-            # torch.cuda.Stream object to ask for its .cuda_stream 3 us (tools/gpu_facade_floor.py)
-            raw = getattr(be.torch._C, "_cuda_getCurrentRawStream", None)
-            index = be.device.index
-            stream_of = (lambda: raw(index)) if raw is not None else (lambda: be.torch.cuda.current_stream(be.device).cuda_stream)
-            fp = self._fast = (b._act_in.numpy(), lib.jss_step, lib.jss_sync_check, d, s, o, b._act_in.data_ptr(),
-                               stream_of, views, lib, b)
-        act, jss_step, sync_check, d, s, o, a_ptr, stream_of, views, lib, b = fp
-        act[0] = action
-        stream = stream_of()
-        rc = jss_step(d, s, a_ptr, o, stream)
-        if rc == 0:
-            rc = sync_check(stream)
-        if rc:
-            _abi.check(lib, rc, "jss_step")
-        h = self._cache = _Snap(views, self.jobs, self.machines, b.decode_jobs)
-        err = h["err"]
-        if err:
-            self._raise_for(err, action)
-        done = h["done"]
-        if done:                                                            # :649-652
-            self.last_time_step = h["clock"]
-            self.last_solution = self._solution()
-        return {"real_obs": h["obs"], "action_mask": h["mask"]}, h["reward"], done, False, {}
-
-    def increase_time_step(self):
-        """jss_env.py:495-637 -- public in the reference and called directly by its tests."""
-        hole = int(self._b.backend.numpy(self._b.increase_time_step())[0])
-        self._cache = None
-        self._raise_for(self._h()["err"])
-        return hole
-
-    def render(self, mode: str = "human"):
-        """Gantt chart of ``solution`` (jss_env.py:655-693); needs pandas + plotly on the host."""
-        from .render import gantt
-        return gantt(self)
-
-    def close(self):
-        """gymnasium.Env.close(): waits for the env's outstanding device work."""
-        self._b.synchronize()
-
-    def _run_rule(self, kind, explore: float = 0.0, seed=None):
-        """One whole episode of a dispatching rule, rule + step fused on the device (dispatching.py:55-75 with the
-        exploration drawn from the counter RNG).  Returns (total reward, makespan) like ``run_episode``."""
-        b = self._b
-        if seed is not None:
-            b.seed = int(seed)
-        b.reset()
-        b.zero_counters()
-        self._alloc_log, self._alloc_log_ok = [], False      # the device picks the actions: no per-call log (next_jobs)
-        chunk = self.jobs * self.machines + 16
-        for _ in range(64):
-            b.rollout(kind, n_iter=chunk, autoreset=False, explore=explore)
-            self._cache = None
-            h = self._h()
-            if h["done"]:
-                break
-        else:
-            raise RuntimeError("episode did not finish")
-        self._raise_for(h["err"])
-        self.last_time_step = h["clock"]
-        self.last_solution = self._solution()
-        return float(h["counters"][3]) / self.max_time_op, h["clock"]
-
-    def _rule_best(self, kind, legal_actions, due_date_factor: float = 1.5):
-        """arg-best of a dispatching rule over the legal jobs from the host snapshot of this step (dispatching.py's
-        strict comparisons: the lowest job index wins ties); -1 when no job is legal.  Same selectors as the device's
-        jss_policy (tests hold the two to each other)."""
-        legal = np.asarray(legal_actions[:self.jobs], dtype=bool)
-        if not legal.any():
-            return -1
-        h = self._h()
-        if "job_state" not in h and kind in ("FIFO", "MOR", "LOR"):
-            # these rank on ONE word of the job records: read it where it lies instead of decoding every record
-            raw = h.t["job_state"][0][:self.jobs]
-            if kind == "FIFO":
-                key = raw[:, _abi.FC_IDLE_LAST if self._b.compact else _abi.F_IDLE_LAST].astype(np.float64)
-            else:
-                todo = raw[:, 0] & (_abi.FC_TODO_MASK if self._b.compact else _abi.TODO_MASK)
-                key = ((self.machines - todo) * (1 if kind == "MOR" else -1)).astype(np.float64)
-            key[~legal] = -np.inf
-            return int(np.argmax(key))
-        js = h["job_state"]
-        todo = js[_abi.F_TODO]
-        if kind == "FIFO":
-            key = js[_abi.F_IDLE_LAST]
-        elif kind == "SPT":
-            key = -(js[_abi.F_CUR] & 0xFFFF)
-        elif kind in ("MOR", "LOR"):
-            key = (self.machines - todo) * (1 if kind == "MOR" else -1)
-        else:
-            rem = self._remaining[np.arange(self.jobs), np.minimum(todo, self.machines - 1)]
-            if kind == "MWR":
-                key = rem
-            elif kind == "LWR":
-                key = -rem
-            elif kind == "CR":     # smallest (1.5 * job length - now) / remaining work, as the reference's floats (:391-398)
-                with np.errstate(divide="ignore"):
-                    key = -np.where(rem > 0, (self._remaining[:, 0] * due_date_factor - self._h()["clock"]) / np.maximum(rem, 1), np.inf)
-            else:
-                raise KeyError(kind)
-        key = np.where(legal, key, -np.inf)
-        return int(np.argmax(key))           # first maximum = lowest index among ties
-
-    # on-device action selectors for the dispatching module
-    def _policy(self, kind, cr_factor=None):
-        return int(self._b.backend.numpy(self._b.policy(kind, cr_factor=cr_factor))[0])
-
-
-def make(env_id: str = "jss-v1", env_config=None, **kwargs):
-    """``gym.make('jss-v1', env_config=...)`` without gymnasium (JSSEnv/__init__.py:6-9)."""
-    if env_id != "jss-v1":
-        raise ValueError(f"unknown env id {env_id!r}; this package registers 'jss-v1'")
-    return JssEnv(env_config=env_config, **kwargs)
+def __getattr__(name):
+    """``jssenv_amd.env.JssEnv`` / ``make`` / ``gymnasium_base`` (their home until round 6, and the gymnasium entry point
+    "jssenv_amd.env:JssEnv"): resolved lazily, facade.py imports this module."""
+    if name in ("JssEnv", "make", "gymnasium_base"):
+        from . import facade
+        return getattr(facade, name)
+    raise AttributeError(name)

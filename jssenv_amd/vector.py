@@ -19,7 +19,8 @@ from __future__ import annotations
 
 from typing import Optional
 
-from .env import BatchedJssEnv, gymnasium_base
+from .env import BatchedJssEnv
+from .facade import gymnasium_base
 
 
 class JssVectorEnv(gymnasium_base("VectorEnv")):

@@ -42,7 +42,7 @@ _GYM_SCRIPT = textwrap.dedent('''
     sys.path.insert(0, %r)
     import gymnasium
     import jssenv_amd
-    assert table == {"jss-v1": "jssenv_amd.env:JssEnv"}, table
+    assert table == {"jss-v1": "jssenv_amd.facade:JssEnv"}, table
     env = gymnasium.make("jss-v1", env_config={"instance_path": "ta01"}, device="cpu")
     assert type(env) is jssenv_amd.JssEnv
     assert isinstance(env, gymnasium.Env)          # the reference: class JssEnv(gym.Env), jss_env.py:14

@@ -36,7 +36,7 @@ _SCRIPT = textwrap.dedent('''
     sys.modules.update({"gymnasium": gym, "gymnasium.spaces": spaces, "gymnasium.envs": envs,
                         "gymnasium.envs.registration": registration})
     import jssenv_amd, jssenv_amd.dispatching
-    assert table == {"jss-v1": "jssenv_amd.env:JssEnv"}, table
+    assert table == {"jss-v1": "jssenv_amd.facade:JssEnv"}, table
     # the reference's package name resolves to this package
     sys.modules["JSSEnv"] = jssenv_amd
     sys.modules["JSSEnv.dispatching"] = jssenv_amd.dispatching
