@@ -799,6 +799,15 @@ def main():
             out["steps_per_launch_last_obs_only"]["launch"] = (f"jss_steps: {K} x jss_step per launch, reward / done per step, observation and "
                                                                f"mask of the last step only")
             restore()
+            try:
+                probe = env.session(depth=K)
+                probe.close(check=False)
+            except RuntimeError as exc:            # JSS_E_RESIDENT: the batch does not fit the chip as one round of resident workgroups
+                out["session_posted_ahead"] = out["session_lockstep"] = {"value": None, "note": f"no session for this batch: {exc}"[:200]}
+                restore()
+                del snap, acts
+                return out
+            restore()
             with env.session(depth=K) as sess:
                 out["session_posted_ahead"] = timed(lambda w: (sess.post(acts[w * K:(w + 1) * K]), sess.wait()))
             st = sess.host_status()
