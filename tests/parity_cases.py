@@ -1246,6 +1246,17 @@ def case_multi_entry_points(backend, steps=40):
         for _ in range(5):
             assert be.lib.jss_multi_policy(n, sets[0], sets[1], _abi.POLICY["random"], 4, 0, acts, be.stream()) == 0
             assert be.lib.jss_multi_step(n, sets[0], sets[1], acts, sets[2], _abi.ROLLOUT_AUTORESET, be.stream()) == 0
+        # parts on streams (every set cut in two, part i of all sets on streams[i], the library forks / joins): the fused grid
+        # and -- round 6 -- the one-launch-per-set fallback alike; n_steps == 0 launches nothing and touches nothing
+        two = be.stream_array(2) if hasattr(be, "stream_array") else (P * 2)()
+        fj = _abi.ROLLOUT_FORK_JOIN if hasattr(be, "stream_array") else 0
+        before = [_state_snapshot(e) for e in a]
+        assert be.lib.jss_multi_rollout(n, *sets, _abi.POLICY["random"], 4, 0, 0, _abi.ROLLOUT_AUTORESET | fj, 2, two) == 0
+        for e, snap in zip(a, before):
+            e.synchronize()
+            now = _state_snapshot(e)
+            assert all(np.array_equal(now[k], snap[k]) for k in snap), f"jss_multi_rollout(n_steps = 0) ({what}) touched the state"
+        assert be.lib.jss_multi_rollout(n, *sets, _abi.POLICY["random"], 4, 0, 3, _abi.ROLLOUT_AUTORESET | fj, 2, two) == 0
         # partial reset: only the sets whose mask says so, only the envs whose byte is set
         which = [be.as_device(np.arange(e.batch) % 2, "uint8") if i != 1 else None for i, e in enumerate(a)]
         keep = list(which)                                                   # (alive until the call has read them)
@@ -1254,6 +1265,8 @@ def case_multi_entry_points(backend, steps=40):
             e.rollout("SPT", n_iter=steps, seed=4, explore=6554 / 65536)
             for _ in range(5):
                 e.step(e.policy("random", seed=4), autoreset=True)
+            e.rollout_steps("random", steps=0, seed=4)
+            e.rollout_steps("random", steps=3, n_sub=1, seed=4)
             e.reset(which=None if i == 1 else np.arange(e.batch) % 2)
         for x, y in zip(a, b):
             x.synchronize()
