@@ -2015,3 +2015,69 @@ def case_two_envs_per_wavefront(backend_two, backend_one=None, steps=60, n_envs=
             assert e.stats()["episodes"] >= 18
         for name in outs[0]:
             assert np.array_equal(outs[0][name], outs[1][name]), f"two envs per wavefront differs from one in {name}"
+
+
+def case_fuzz_mixed_calls(backend_factory, rounds=12, seed=2026, max_batch=260, max_iters=140, shapes=None, kernels=None):
+    """Random populations through a random MIX of the calls that all advance the same process -- `iters` x (policy + step)
+    with auto-restart from a fresh reset: rollout(n), n x rollout(1), rollout_steps (sub-batches / parts on streams),
+    trajectory(n), steps replayed from a recorded trajectory is NOT one of them (its actions come from outside), n x
+    (policy -> step with next-step auto-reset) -- then EVERY env against the oracle's rollout.  Random shapes (1..128 jobs,
+    2..64 machines, durations up to 65 535, machine orders that repeat machines), random batch sizes (odd ones: the last
+    wavefront of a two-envs-per-wavefront launch owns one env), every dispatching rule with and without NOPE exploration, all
+    deals (the default by shape class, interleaved, explicit by_shape), every kernel form.  `backend_factory(kernel)` -> backend."""
+    rng = np.random.default_rng(seed)
+    kernels = kernels or ["auto", "wave", "auto-2env", "wave-2env", "auto-1env"]
+    kinds = ["random", "FIFO", "SPT", "MWR", "LWR", "MOR", "LOR", "CR"]
+    backends = {}
+    for r in range(rounds):
+        n_inst = int(rng.integers(1, 7))
+        insts = []
+        for _ in range(n_inst):
+            if shapes is not None:
+                J, M = shapes[int(rng.integers(len(shapes)))]
+            else:
+                J = int(rng.choice([rng.integers(1, 17), rng.integers(1, 33), rng.integers(17, 65), rng.integers(60, 129)]))
+                M = int(rng.choice([rng.integers(2, 17), rng.integers(2, 33), rng.integers(2, 65)]))
+            insts.append(random_instance(rng, J, M, max_dur=int(rng.choice([9, 99, 65535])), permutation=bool(rng.integers(2))))
+        batch = int(rng.integers(1, max_batch)) | int(rng.integers(2))
+        kernel = kernels[int(rng.integers(len(kernels)))]
+        be = backends.setdefault(kernel, backend_factory(kernel))
+        ragged = len({(0 if (i.jobs <= 16 and i.machines <= 16) else 1 if (i.jobs <= 32 and i.machines <= 32) else 2) for i in insts}) > 1
+        order = [None, "interleaved"][int(rng.integers(2))] if (n_inst == 1 or batch == n_inst) else \
+            [None, "interleaved", "by_shape"][int(rng.integers(3))]
+        kind = kinds[int(rng.integers(len(kinds)))]
+        explore = float(rng.choice([0.0, 0.0, 0.1, 0.35])) if kind != "random" else 0.0
+        sd = int(rng.integers(0, 1 << 30))
+        base = int(rng.integers(0, 1 << 20))
+        label = (f"fuzz round {r}: {[(i.jobs, i.machines) for i in insts]} x {batch}, kernel {kernel}, order {order}, {kind}, "
+                 f"explore {explore}, seed {sd}")
+        try:
+            env = BatchedJssEnv(insts if n_inst > 1 else insts[0], batch=batch, seed=sd, env_id_base=base, order=order, _backend=be)
+            env.reset()
+            done = 0
+            iters = int(rng.integers(1, max_iters))
+            while done < iters:
+                n = int(min(iters - done, rng.integers(1, 24)))
+                how = int(rng.integers(5))
+                if how == 0:
+                    env.rollout(kind, n_iter=n, explore=explore)
+                elif how == 1:
+                    for _ in range(n):
+                        env.rollout(kind, n_iter=1, explore=explore)
+                elif how == 2:
+                    env.rollout_steps(kind, steps=n, n_sub=int(rng.integers(1, 4)), explore=explore)
+                elif how == 3:
+                    env.trajectory(kind, steps=n, explore=explore, record=("action", "reward") if rng.integers(2) else
+                                   ("real_obs", "action_mask", "action", "reward", "done"))
+                else:
+                    for _ in range(n):
+                        env.step(env.policy(kind, explore=explore), autoreset=True)
+                done += n
+            env.synchronize()
+            assert_batch_equals_oracle(env, kind, sd, iters, label, explore=explore)
+        except AssertionError:
+            raise
+        except Exception as exc:
+            raise AssertionError(f"{label}: {type(exc).__name__}: {exc}") from exc
+        del env
+    del ragged

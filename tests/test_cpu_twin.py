@@ -285,3 +285,7 @@ def test_medium_records_at_the_limits(cpu):
 
 def test_policy_step_steps_equals_the_loop(cpu):
     P.case_policy_step_steps(cpu)
+
+
+def test_fuzz_mixed_calls_against_the_oracle(cpu):
+    P.case_fuzz_mixed_calls(lambda kernel: cpu, rounds=14, max_batch=90, max_iters=120, kernels=["auto"])

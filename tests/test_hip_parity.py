@@ -432,3 +432,14 @@ def test_one_env_per_wavefront_form_at_full_size(hip_auto, cfg):
     benchmarked sizes, every env against the oracle -- the A/B partner of the default."""
     label, kw, kind, iters, explore = P.FULL_SIZE_CONFIGS[cfg]
     P.case_every_env_vs_oracle(hip_auto, label + " [one env per wavefront]", dict(kw(), kernel="auto-1env"), kind, iters, explore=explore, form="free")
+
+
+def test_fuzz_mixed_calls_against_the_oracle():
+    """Random populations (1..128 jobs, 2..64 machines), deals, kernel forms and call mixes on the GPU, every env vs the oracle."""
+    from jssenv_amd.env import HipBackend
+
+    def factory(kernel):
+        be = HipBackend("cuda:0")
+        be.default_kernel = kernel
+        return be
+    P.case_fuzz_mixed_calls(factory, rounds=40, max_batch=700, max_iters=260)

@@ -200,3 +200,10 @@ def test_two_envs_per_wavefront():
     """jss_kernel_two under the emulator (small batches take the form on request)."""
     from emu_backend import EmuBackend
     P.case_two_envs_per_wavefront(EmuBackend(default_kernel="wave-2env"), EmuBackend(default_kernel="wave-1env"), steps=24, n_envs=5)
+
+
+def test_fuzz_mixed_calls_against_the_oracle():
+    """Random populations, deals, kernel forms and call mixes under the emulator (small: it runs ~250 env-steps/s)."""
+    from emu_backend import EmuBackend
+    P.case_fuzz_mixed_calls(lambda kernel: EmuBackend(default_kernel=kernel), rounds=5, max_batch=8, max_iters=14, seed=7,
+                            shapes=[(3, 3), (9, 5), (17, 4), (20, 20), (40, 6), (66, 3)])
