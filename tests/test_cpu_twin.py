@@ -288,4 +288,4 @@ def test_policy_step_steps_equals_the_loop(cpu):
 
 
 def test_fuzz_mixed_calls_against_the_oracle(cpu):
-    P.case_fuzz_mixed_calls(lambda kernel: cpu, rounds=14, max_batch=90, max_iters=120, kernels=["auto"])
+    P.case_fuzz_mixed_calls(lambda kernel: cpu, rounds=40, max_batch=90, max_iters=120, kernels=["auto"])

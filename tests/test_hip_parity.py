@@ -442,4 +442,4 @@ def test_fuzz_mixed_calls_against_the_oracle():
         be = HipBackend("cuda:0")
         be.default_kernel = kernel
         return be
-    P.case_fuzz_mixed_calls(factory, rounds=40, max_batch=700, max_iters=260)
+    P.case_fuzz_mixed_calls(factory, rounds=150, max_batch=700, max_iters=260)
