@@ -382,7 +382,10 @@ def main():
     # its CPU baselines).  JSS_BENCH_NO_PIN=1: A/B.
     numa = {}
     if world > 1 and not args.share_device and os.environ.get("JSS_BENCH_NO_PIN", "0") != "1":
-        numa = pin_to_gpu_numa_node(local_rank, int(os.environ.get("LOCAL_RANK", "0")), local_world_size(world))
+        try:
+            numa = pin_to_gpu_numa_node(local_rank, int(os.environ.get("LOCAL_RANK", "0")), local_world_size(world))
+        except Exception as exc:               # (a box whose sysfs looks different must not cost the measurement)
+            numa = {"pinned": False, "error": f"{type(exc).__name__}: {exc}"[:120]}
     dev = torch.device("cuda", local_rank)
     backend = args.dist_backend or "nccl"   # "nccl" is RCCL on ROCm
     use_pg = world > 1 or args.force_process_group

@@ -83,6 +83,21 @@ def gpu_numa_node(device_index: int, sysfs: str = "/sys") -> Optional[int]:
     return None
 
 
+def physical_device_index(device_index: int) -> Optional[int]:
+    """The index in the node's own enumeration (KFD topology order) of the GPU this process sees as `device_index`:
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES renumber the devices.  None when the list is not plain
+    indices (UUIDs) or does not reach that far."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is None or val.strip() == "":
+            continue
+        items = [x.strip() for x in val.split(",")]
+        if not all(x.isdigit() for x in items) or device_index >= len(items):
+            return None
+        return int(items[device_index])
+    return device_index
+
+
 def numa_cpus(node: int, sysfs: str = "/sys"):
     """CPUs of NUMA node `node` (`<sysfs>/devices/system/node/node<N>/cpulist`, e.g. "0-47,96-143"); empty set when unknown."""
     cpus = set()
@@ -108,7 +123,11 @@ def pin_to_gpu_numa_node(device_index: int, local_rank: int = 0, local_world: in
     info: Dict[str, object] = {"numa_node": None, "cpus": None, "pinned": False}
     if not hasattr(os, "sched_setaffinity"):
         return info
-    node = gpu_numa_node(device_index, sysfs)
+    phys = physical_device_index(device_index)
+    if phys is None:                                   # the visible-devices list names GPUs by UUID: no index to look up
+        return info
+    mates_phys = [physical_device_index(r) for r in range(max(1, local_world))]
+    node = gpu_numa_node(phys, sysfs)
     if node is None:
         return info
     info["numa_node"] = node
@@ -116,7 +135,7 @@ def pin_to_gpu_numa_node(device_index: int, local_rank: int = 0, local_world: in
     if not allowed:
         return info
     # ranks on the same NUMA node: those whose GPU reports the same node
-    mates = [r for r in range(max(1, local_world)) if gpu_numa_node(r, sysfs) == node] or [local_rank]
+    mates = [r for r, ph in enumerate(mates_phys) if ph is not None and gpu_numa_node(ph, sysfs) == node] or [local_rank]
     if local_rank in mates and len(allowed) >= 2 * len(mates):
         per = len(allowed) // len(mates)
         k = mates.index(local_rank)

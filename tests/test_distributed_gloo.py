@@ -167,12 +167,14 @@ def _fake_sysfs(root, gpu_nodes, cpulists, cpu_only_nodes=2):
             fh.write(cl + "\n")
 
 
-def test_rank_pins_its_host_thread_to_its_gpus_numa_node(tmp_path):
+def test_rank_pins_its_host_thread_to_its_gpus_numa_node(tmp_path, monkeypatch):
     """8 GPUs on 2 sockets (GPUs 0-3 on node 0, 4-7 on node 1), 8 ranks: every rank ends up on CPUs of ITS GPU's socket, the
     four ranks of a socket on disjoint slices of it; a topology that cannot be read changes nothing (sysfs mocked, the
     affinity calls mocked: this container has 8 CPUs)."""
     from unittest import mock
     from jssenv_amd import distributed as D
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
     root = str(tmp_path)
     _fake_sysfs(root, [0, 0, 0, 0, 1, 1, 1, 1], ["0-47,96-143", "48-95,144-191"])
     assert [D.gpu_numa_node(g, root) for g in range(8)] == [0, 0, 0, 0, 1, 1, 1, 1] and D.gpu_numa_node(8, root) is None
@@ -190,6 +192,14 @@ def test_rank_pins_its_host_thread_to_its_gpus_numa_node(tmp_path):
     with mock.patch("os.sched_getaffinity", return_value={0, 1, 2, 3, 50}), mock.patch("os.sched_setaffinity") as setaff:
         info = D.pin_to_gpu_numa_node(2, 2, 8, sysfs=root)
     assert setaff.call_args[0] == (0, [0, 1, 2, 3]) and info["cpus"] == 4
+    # a visible-devices list renumbers the GPUs: this process's device 1 is the node's GPU 6 (socket 1); UUIDs: hands off
+    with mock.patch.dict(os.environ, {"HIP_VISIBLE_DEVICES": "2,6"}), mock.patch("os.sched_getaffinity", return_value=set(range(192))), \
+            mock.patch("os.sched_setaffinity") as setaff:
+        assert D.physical_device_index(1) == 6 and D.physical_device_index(2) is None
+        assert D.pin_to_gpu_numa_node(1, 1, 2, sysfs=root)["numa_node"] == 1 and set(setaff.call_args[0][1]) <= D.numa_cpus(1, root)
+    with mock.patch.dict(os.environ, {"ROCR_VISIBLE_DEVICES": "GPU-abc,GPU-def"}), mock.patch("os.sched_setaffinity") as setaff:
+        assert D.pin_to_gpu_numa_node(0, 0, 2, sysfs=root)["pinned"] is False
+        setaff.assert_not_called()
     # unknown topology / a GPU without a NUMA node (-1) / no allowed CPU on the node: nothing is touched
     with mock.patch("os.sched_setaffinity") as setaff:
         assert D.pin_to_gpu_numa_node(0, 0, 1, sysfs=os.path.join(root, "nowhere"))["pinned"] is False
