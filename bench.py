@@ -310,9 +310,10 @@ def parse_args():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch envs per GPU; strong: --batch envs in total, split by shard_bounds")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager", "sub2", "sub3", "sub4"],
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager", "sub1", "sub2", "sub3", "sub4"],
                     help="how a step is issued: eager = one ctypes launch; graph = hipGraph replay of the K launches; "
-                         "subN = N sub-batches on N streams (jss_rollout_steps); auto = fastest on a probe")
+                         "subN = N sub-batches on N streams (jss_rollout_steps; sub1 = one launch per step from the library's C "
+                         "loop); auto = fastest on a probe")
     ap.add_argument("--bucketed", action="store_true",
                     help="mixed workload only: one compact sub-batch per shape class (BucketedJssEnv) instead of "
                          "padding every env to 100x20")
@@ -463,7 +464,7 @@ def main():
         return e
 
     # ---- timing ---------------------------------------------------------------------------------------------
-    def window(env, policy, n_launch, n_iter, mode, graph=None, run=None, prep=None, events=False):
+    def window(env, policy, n_launch, n_iter, mode, graph=None, run=None, prep=None, events=False, bound=None):
         """Time n_launch steps.  Returns (wall seconds, GPU ms per step from HIP events on the launch stream -- only in
         the windows that ask for them: the windows behind `value` carry nothing but the steps)."""
         if events:
@@ -475,7 +476,9 @@ def main():
         t0 = time.perf_counter()
         if events:
             ev0.record()
-        if run is not None:
+        if bound is not None and not events:
+            bound()                            # the window's ONE C call, resolved outside the timed region (measure)
+        elif run is not None:
             run(n_launch)
         elif graph is not None:
             graph.replay()
@@ -552,8 +555,13 @@ def main():
         MIN_WINDOWS and MAX_WINDOWS; every rank takes the same number).  Returns the median window and all windows,
         already reduced over ranks.  `run(n)` overrides what a window executes (extras)."""
         graph = capture(env, policy, steps) if mode == "graph" else None
+        bound = None
+        if run is None and graph is None and mode.startswith("sub") and hasattr(env, "bind_rollout_steps") and not hasattr(env, "buckets") \
+                and os.environ.get("JSS_BENCH_FORK_JOIN", "0") != "1":
+            # every argument of the window's launch loop resolved here: the timed region holds the call and nothing else
+            bound = env.bind_rollout_steps(policy, steps=steps, n_sub=int(mode[3:]), autoreset=True, caller_orders_streams=True)
         window(env, policy, steps, n_iter, mode, graph, run, prep)           # untimed: side streams / graph exist before the first window
-        first = min(window(env, policy, steps, n_iter, mode, graph, run, prep)[0] for _ in range(3))   # untimed: sizes the count
+        first = min(window(env, policy, steps, n_iter, mode, graph, run, prep, bound=bound)[0] for _ in range(3))   # untimed: sizes the count
         if windows is None:
             t_win = agree_max([first])[0]
             windows = int(min(MAX_WINDOWS, max(MIN_WINDOWS, math.ceil(min_seconds / max(t_win, 1e-6)))))
@@ -566,7 +574,7 @@ def main():
         gc.disable()
         for _ in range(windows):
             env.zero_counters()
-            dt, _ = window(env, policy, steps, n_iter, mode, graph, run, prep)
+            dt, _ = window(env, policy, steps, n_iter, mode, graph, run, prep, bound=bound)
             tot = reduce_counters(env.counter_totals().cpu() if on_host else env.counter_totals(), dt, force_collectives=use_pg)
             rows.append({"steps": tot["steps"], "seconds": tot["seconds"], "rate": tot["steps"] / tot["seconds"],
                          "episodes": tot["episodes"], "makespan_sum": tot["makespan_sum"], "reward_num": tot["reward_num_sum"],
@@ -590,6 +598,8 @@ def main():
                 "p10": rows[len(rows) // 10]["rate"], "timed_seconds_total": sum(r["seconds"] for r in rows)}
 
     def launch_label(mode):
+        if mode == "sub1":
+            return "one launch per step, issued by the library's C loop (jss_rollout_steps, one stream)"
         if mode.startswith("sub"):
             return f"{mode[3:]} sub-batches on {mode[3:]} HIP streams per step (jss_rollout_steps)"
         return {"eager": "one launch per step (ctypes, eager)",
@@ -839,7 +849,7 @@ def main():
                 pass
         return out
 
-    def side_run(workload, batch, policy, label_extra="", instance="ta01", bucketed=False, modes=("eager", "graph", "sub2", "sub3"),
+    def side_run(workload, batch, policy, label_extra="", instance="ta01", bucketed=False, modes=("eager", "graph", "sub1", "sub2", "sub3"),
                  first_env=None, keep=False, with_trajectory=False, with_external=False, order=None, with_step_only=False):
         """One extra workload on this GPU, same timing discipline as the headline."""
         alg, label, key = describe(workload, instance)
@@ -894,7 +904,7 @@ def main():
     for _ in range(args.warmup):
         env.rollout(args.policy, n_iter=1, autoreset=True)
     torch.cuda.synchronize()
-    mode = pick_mode(env, args.policy, ["eager", "sub2", "sub3"] if getattr(env, "_classes", None) is not None else ["eager", "graph", "sub2", "sub3"])
+    mode = pick_mode(env, args.policy, ["eager", "sub1", "sub2", "sub3"] if getattr(env, "_classes", None) is not None else ["eager", "graph", "sub1", "sub2", "sub3"])
     med, rows = measure(env, args.policy, args.steps, mode, min_seconds=MIN_TIMED_SECONDS_HEADLINE)
     # The probe is five short windows per form: when the runner-up is within 15 % of the winner the two are too close to
     # call from that, so both get the full measurement and the better median is the headline (every rank takes the same
@@ -951,9 +961,9 @@ def main():
     }
 
     if not args.no_extras and not hasattr(env, "buckets"):
-        if mode != "eager" and mode != "graph":
+        if mode not in ("eager", "graph", "sub1"):
             # the plain form: ONE launch per step over the whole batch (the kernel duration rocprofv3 reports)
-            m1 = pick_mode(env, args.policy, ["eager", "graph"]) if args.launch == "auto" else "eager"
+            m1 = pick_mode(env, args.policy, ["eager", "graph", "sub1"]) if args.launch == "auto" else "eager"
             med1, rows1 = measure(env, args.policy, args.steps, m1)
             out["single_launch_per_step"] = {"value": med1["rate"], "min": rows1[0]["rate"], "max": rows1[-1]["rate"],
                                              "gpu_ms_per_step_events": med1["gpu_ms_per_step_events"], "launch": launch_label(m1),
@@ -1033,7 +1043,7 @@ def main():
         x = bool(args.extras)                 # trajectory mode and the external-action forms of a config: --extras only
         so = dict(with_step_only=not x)       # jss_step with the caller's actions next to every fused figure (light leg; --extras: the full one)
         extras = [
-            ("config2_ta01_batch4096_random", dict(workload="shared", batch=4096, policy="random", modes=("eager", "graph"),
+            ("config2_ta01_batch4096_random", dict(workload="shared", batch=4096, policy="random", modes=("eager", "graph", "sub1"),
                                                    with_trajectory=x, with_external=x, **so)),
             ("config3_ta41_spt_batch16384", dict(workload="shared", batch=16384, policy="SPT", instance="ta41", with_trajectory=x,
                                                  with_external=x, **so)),
@@ -1043,7 +1053,7 @@ def main():
                                                                label_extra=" -- all of config 4 on one GPU")),
             # config 5 as a caller gets it: BatchedJssEnv([ta01 .. ta80], batch=32768) -- the constructor deals a ragged list out by
             # shape class (order=None) -- and, next to it, the i % 80 order of rounds 1-5 (every env on the padded extents' kernel)
-            ("config5_mixed_padded_batch32768", dict(workload="mixed", batch=32768, policy="random", modes=("eager", "sub2", "sub3"),
+            ("config5_mixed_padded_batch32768", dict(workload="mixed", batch=32768, policy="random", modes=("eager", "sub1", "sub2", "sub3"),
                                                      label_extra=", padded 100x20, default constructor (envs dealt out by shape class: "
                                                                  "class-specialised bodies on the padded rows)",
                                                      with_trajectory=x, with_external=x, **so)),
