@@ -833,15 +833,13 @@ def main():
                                                                f"mask of the last step only")
             restore()
             try:
-                probe = env.session(depth=K)
-                probe.close(check=False)
+                opened = env.session(depth=K)
             except RuntimeError as exc:            # JSS_E_RESIDENT: the batch does not fit the chip as one round of resident workgroups
                 out["session_posted_ahead"] = out["session_lockstep"] = {"value": None, "note": f"no session for this batch: {exc}"[:200]}
                 restore()
                 del snap, acts
                 return out
-            restore()
-            with env.session(depth=K) as sess:
+            with opened as sess:
                 out["session_posted_ahead"] = timed(lambda w: (sess.post(acts[w * K:(w + 1) * K]), sess.wait()))
             st = sess.host_status()
             out["session_posted_ahead"].update(launch=f"step session: {K} steps posted per wait (one post + one wait kernel per window), "
