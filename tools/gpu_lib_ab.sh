@@ -11,7 +11,9 @@ for lib in $LIBS; do
   if [ "$lib" = shipped ]; then unset JSSENV_AMD_LIB; else export JSSENV_AMD_LIB=$R/variants/$lib.so; fi
   for w in "head_s20 --launch sub2 --steps 20 --warmup 5" "head_s200 --launch sub2 --steps 200 --warmup 10" "head_e200 --launch eager --steps 200 --warmup 10" \
            "c3_s200 --instance ta41 --policy SPT --batch 16384 --launch sub2 --steps 200 --warmup 10" \
-           "syn15_s200 --workload synthetic15x15 --launch sub2 --steps 200 --warmup 10"; do
+           "syn15_s200 --workload synthetic15x15 --launch sub2 --steps 200 --warmup 10" \
+           "c4_s200 --workload synthetic50x20 --batch 8192 --launch sub2 --steps 200 --warmup 10" \
+           "c5_s200 --workload mixed --batch 32768 --launch sub2 --steps 200 --warmup 10"; do
     set -- $w; name=$1; shift
     timeout 300 python bench.py --no-extras --no-cpu-baseline --detail $O/${lib}_${name}_$rep.json "$@" > /dev/null 2>&1
   done
