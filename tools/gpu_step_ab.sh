@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06w
+for rep in 1 2; do for lib in shipped mstep6 mstep7; do
+  if [ $lib = shipped ]; then unset JSSENV_AMD_LIB; else export JSSENV_AMD_LIB=$PWD/variants/$lib.so; fi
+  timeout 600 python tools/gpu_step_probe.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/r06w/step_probe.txt
+done; done
+sort gpurun_out/r06w/step_probe.txt
