@@ -9,16 +9,19 @@ One "step" = one pass of the hot path over the batch: for every env, pick a rand
 device, execute step() and write the full gym outputs (real_obs, action_mask, reward, done) to HBM -- exactly
 what a reference ``obs, r, done, _, _ = env.step(policy(obs))`` iteration produces, fused in one kernel
 (jss_rollout with n_iter = 1).  Envs found done are reset by that pass instead (the iteration is not counted as
-an env step).  A pass is ONE launch over the batch, or -- whichever a short probe finds faster -- n_sub launches
-over n_sub contiguous sub-batches on n_sub HIP streams (jss_rollout_steps): step s of a sub-batch depends only on
-its own step s-1, so one sub-batch's drain overlaps another's fill; results are identical either way.
+an env step).  A pass is ONE launch over the batch (issued by a Python loop, a hipGraph replay or the library's C loop), or
+n_sub launches over n_sub contiguous sub-batches on n_sub HIP streams (jss_rollout_steps): step s of a sub-batch depends only
+on its own step s-1, so one sub-batch's drain overlaps another's fill; results are identical either way.  Which form: a short
+probe ranks them, every contender within 15 % of the best probe gets the full measurement, the best median is reported
+(best_form).
 
 Timing: W untimed warm-up steps, then windows of EXACTLY K steps, each bracketed by barrier +
 torch.cuda.synchronize() on both sides; per window the wall time is the MAX over ranks and the env steps the SUM
 over ranks (one RCCL all-reduce each, outside the timed region).  As many windows as it takes for the timed total to
-reach 0.5 s for the headline (0.1 s for the other configs; at least 5, at most 4 000 windows): the driver's K = 20 makes a
-window 0.3 ms, and a few of those are noise.  value = median window; n / min / p10 / max are printed too.  roofline.frac is value x algorithmic bytes / peak -- the
-wall-clock number anybody can recompute from the line; the HIP-event figure is kept as roofline.frac_gpu_time.
+reach 0.55 s for the headline (0.1 s for the other configs; at least 5, at most 4 000 windows): the driver's K = 20 makes a
+window 0.3 ms, and a few of those are noise.  value = median window; n / min / p10 / max are printed too.  roofline.frac is
+value x algorithmic bytes / peak -- the wall-clock number anybody can recompute from the line; the HIP-event figure is kept
+as roofline.frac_gpu_time.
 
 Workload: BASELINE.json configs[1] shape (ta01, 15x15, one shared instance, random masked policy) at the
 north_star's target batch of 65 536 envs per GPU (weak scaling: every rank owns its own 65 536 envs, no data-path
