@@ -116,7 +116,7 @@ struct Params {
 // LOOP over steps with the state in registers (kTraj, kRollout, kSteps): by value every field stays live through the whole
 // loop (the recorder's two-jobs-per-lane form even keeps 14-29 VGPRs in scratch memory), and there reading in place wins --
 // trajectory mode +6.5 % on config 4's share, +10 % on config 5 padded, the 64-iteration rollout +6 % / +3 %, jss_steps +2.5 %
-// (profiles/r05_misc/ab_params_in_place.txt); +-0 on the packed flavour, which stays by value.  The fused multi-set grid (jss_multi_kernel) copies its set's Params up front for the
+// (profiles/r05_misc/ab_params_in_place.txt).  The packed flavour's looping kernels: see jss_packed_kernel.  The fused multi-set grid (jss_multi_kernel) copies its set's Params up front for the
 // same reason the one-step kernels take them by value (+3 % over in place).
 // The explicit arguments start at offset 0 of the segment.  (Host pass and the test emulator: the argument itself.
 // -DJSS_PARAMS_ALL_IN_PLACE: A/B builds.)

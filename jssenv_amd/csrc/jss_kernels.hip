@@ -398,7 +398,10 @@ struct MultiParams {
     int32_t n_sets;
 };
 
-constexpr int multi_min_blocks(int mode) { return mode == kStep ? 5 : mode == kRollout1 ? 7 : mode == kReset ? 6 : 8; }
+#ifndef JSS_MULTI_STEP_MIN_BLOCKS
+#define JSS_MULTI_STEP_MIN_BLOCKS 5
+#endif
+constexpr int multi_min_blocks(int mode) { return mode == kStep ? JSS_MULTI_STEP_MIN_BLOCKS : mode == kRollout1 ? 7 : mode == kReset ? 6 : 8; }
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock, multi_min_blocks(MODE)) void jss_multi_kernel(MultiParams mp) {
@@ -417,7 +420,11 @@ __global__ __launch_bounds__(kBlock, multi_min_blocks(MODE)) void jss_multi_kern
 #else
     const Params p = mp.p[k];
 #endif
+#ifdef JSS_EXP_MULTI_ONLY
+    switch (JSS_EXP_MULTI_ONLY) {
+#else
     switch (mp.flavour[k]) {
+#endif
     case kMfW2G: wave_block<2, MODE, kTabGlobal, false>(p, block, lds); break;   // (one body: 66 VGPRs, no spills at 7 waves / SIMD)
     case kMfW1G: wave_block<1, MODE, kTabGlobal>(p, block, lds); break;
     case kMfP32G: packed_block<32, MODE, kTabGlobal, true>(p, block, lds); break;   // (full records: also classes inside padded rows)

@@ -826,6 +826,9 @@ __device__ __forceinline__ void p_store_obs(const PEnv<G> &e, const PCtx<G, TAB>
             else st_nt(dst, (unsigned)i * 16u, reinterpret_cast<const float4 *>(scratch)[i]);
         }
     } else if (c.alive) {
+        // (the last wavefront of a ragged batch only: left to itself the compiler unrolls this 16 times with a 64-bit address
+        // per store -- the register peak of the fused grid's step kernel)
+#pragma unroll 1
         for (int i = c.gl; i < row_floats; i += G) st_out<WT, float>(dst, (c.rel * row_floats + i) * 4u, mine[i]);
     }
     wave_lds_sync();
@@ -1022,8 +1025,11 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
 // With kTabGlobal the instance (tid, J, M, max_time_op) is group-uniform data in VGPRs instead of SGPRs: the step
 // kernels need 66-70 VGPRs.  7 waves/SIMD (72 VGPRs) beats 8 with two VGPRs in scratch: 19.4 vs 21.5 us per step
 // on synthetic 15x15, B = 65 536 (profiles/README.md).  The medium-record one-step rollout needs 62: 8 waves per SIMD.
+// The recorders (kTraj / kSteps) on a shared table need 94-97 VGPRs since the ragged observation store is no longer unrolled
+// (p_store_obs): 5 waves per SIMD (96), +7.5 % on the headline's trajectory against 4; so do the medium-record ones with their
+// arguments read in place (93-95); full records with per-env tables need 101-102 (2 VGPRs in scratch at 5): 4.
 #ifndef JSS_PTRAJ_LDS_MIN_BLOCKS
-#define JSS_PTRAJ_LDS_MIN_BLOCKS 4
+#define JSS_PTRAJ_LDS_MIN_BLOCKS 5
 #endif
 #ifndef JSS_PTRAJ_GLOBAL_MIN_BLOCKS
 #define JSS_PTRAJ_GLOBAL_MIN_BLOCKS 4
@@ -1138,14 +1144,20 @@ __device__ __forceinline__ void packed_block(const Params &p, int block, int32_t
 }
 
 template <int G, int MODE, int TAB>
-__global__ __launch_bounds__(kBlock, (MODE == kTraj || MODE == kSteps) ? (tab_global(TAB) ? JSS_PTRAJ_GLOBAL_MIN_BLOCKS : JSS_PTRAJ_LDS_MIN_BLOCKS)
+__global__ __launch_bounds__(kBlock, (MODE == kTraj || MODE == kSteps) ? (tab_global(TAB) && !tab_medium(TAB) ? JSS_PTRAJ_GLOBAL_MIN_BLOCKS : JSS_PTRAJ_LDS_MIN_BLOCKS)
                                      : MODE == kRollout ? (tab_global(TAB) ? 4 : 5)
                                      : (tab_medium(TAB) && MODE == kRollout1) ? JSS_PACKED_MEDIUM_MIN_BLOCKS
                                      : ((tab_global(TAB) && (MODE == kStep || MODE == kRollout1)) ? JSS_PACKED_GLOBAL_MIN_BLOCKS : 8))
-void jss_packed_kernel(Params p) {
+void jss_packed_kernel(Params p_arg) {
     HIP_DYNAMIC_SHARED(int32_t, lds)
-    // (by value on purpose: these kernels fit their SGPR budget, and with every argument loaded up front -- behind the state
-    //  loads -- no scalar load waits in the middle of the dependent chain: JSS_PARAMS_OF in jss_common.hpp)
+    // By value for the one-step kernels: they fit their SGPR budget, and with every argument loaded up front -- behind the state
+    // loads -- no scalar load waits in the middle of the dependent chain (JSS_PARAMS_OF in jss_common.hpp).  The kernels that
+    // LOOP over steps read them in place where that measured faster (round 6, same-box A/B, profiles/r06_misc/
+    // packed_params_in_place.txt): with per-env tables (23-31 fewer SGPR values parked in VGPR lanes; the medium-record recorders
+    // drop from 100-107 to 93-95 VGPRs, i.e. from 4 to 5 wavefronts per SIMD: trajectory +8 %, jss_steps +3 %, the rollout +2 %
+    // on 15x15 x 65 536) and the shared-table recorder (+3 %); the shared-table rollout / jss_steps stay by value (+1 % at
+    // 65 536 envs, -2..-3 % at 4 096).
+    JSS_PARAMS_OF(p, p_arg, (MODE == kTraj || MODE == kSteps || MODE == kRollout) && (tab_global(TAB) || MODE == kTraj));
     packed_block<G, MODE, TAB>(p, (int)blockIdx.x, lds);
 }
 

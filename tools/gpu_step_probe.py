@@ -1,5 +1,5 @@
 """One jss_step launch per env step, actions resident (a recorded behaviour trajectory), hipGraph replay of K launches:
-microseconds per step for BASELINE config 4's share, config 5 padded and config 3 -- the A/B harness for kernel-library
+microseconds per step for BASELINE config 4's share, config 5 padded, config 3, per-env 15x15 tables and the headline -- the A/B harness for kernel-library
 builds (JSSENV_AMD_LIB=variants/<x>/libjss_hip.so python tools/gpu_step_probe.py).  GPU box."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,9 @@ K = 100
 dev = torch.device("cuda", 0)
 for label, src, batch, pol in (("c4 syn50x20 x 8192", lambda: synthetic_packed(8192, 50, 20), 8192, "random"),
                                ("c5 mixed padded x 32768", lambda: [builtin_instance(f"ta{k:02d}") for k in range(1, 81)], 32768, "random"),
-                               ("c3 ta41 x 16384", lambda: builtin_instance("ta41"), 16384, "SPT")):
+                               ("c3 ta41 x 16384", lambda: builtin_instance("ta41"), 16384, "SPT"),
+                               ("syn15x15 x 65536", lambda: synthetic_packed(65536, 15, 15), 65536, "random"),
+                               ("c1 ta01 x 65536", lambda: builtin_instance("ta01"), 65536, "random")):
     env = BatchedJssEnv(src(), batch=batch, device=dev, seed=0)
     env.reset()
     env.rollout(pol, n_iter=150)

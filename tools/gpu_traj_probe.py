@@ -51,4 +51,16 @@ for what, B in (("ta01", 65536), ("ta01", 4096), ("synthetic50x20", 8192), ("mix
         torch.cuda.synchronize()
         best = max(best, n_steps / (time.perf_counter() - t0))
     print(f"steps K={K} {what} B={B}: {best / 1e9:.3f} G env-steps/s  lib={lib}", flush=True)
+    # the fused rollout: K steps per launch, nothing but the final state and the counters written
+    best = 0.0
+    for rep in range(4):
+        env.zero_counters()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            env.rollout("random", n_iter=K)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = max(best, env.stats()["steps"] / dt)
+    print(f"fused K={K} {what} B={B}: {best / 1e9:.3f} G env-steps/s  lib={lib}", flush=True)
     del env, bufs, sb
