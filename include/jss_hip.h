@@ -129,7 +129,8 @@ extern "C" {
  * (mmax <= 32, any number of jobs, either kernel flavour; JSS_E_SHAPE otherwise).  With machines <= 32 an op is 21
  * bits (machine << 16 | duration, 0 = none), todo <= 32 is 6 bits, total_perform_op_time_jobs <= 32 x 65535 < 2^21: 189
  * of the 192 bits.  No machine clocks in memory either (JssState.machine may be NULL), as with compact records.  Measured
- * faster than full records on the 16-lane packed shapes only (profiles/README.md): that is where the host uses it.  Words: */
+ * faster than full records on the 16-lane packed shapes (profiles/README.md) and on the one-job-per-lane shapes of the
+ * one-wavefront-per-env flavour (33..64 jobs; profiles/r06_misc/medium_records_wave.txt): that is where the host uses it.  Words: */
 #define JSS_FM_W0 0        /* bits 0-5 todo_time_step_job, bit 6 legal_actions[j], bit 7 action_illegal_no_op[j], bit 8 observation
                               feature 4 is "1.0", bits 9-29 the current op (0 = job finished)                              */
 #define JSS_FM_LEFT_F4 1   /* bits 0-15 time_until_finish_current_op_jobs, bits 16-31 the feature-4 numerator          */
@@ -245,7 +246,7 @@ extern "C" {
  * wavefront per env (A/B runs, tests).  JSS_KERNEL_ONE_ENV_PER_WAVE (a bit, OR-ed in): the one-wavefront-per-env launches
  * of the one-step calls (jss_step, jss_rollout(n_iter = 1), jss_rollout_steps, jss_multi_*) never let a wavefront serve two
  * envs in turn -- what they do by default when a launch covers JSS_TWO_PER_WAVE_MIN_BATCH envs or more (one job per lane,
- * per-env tables, full records; results identical either way: A/B runs, tests); JSS_KERNEL_TWO_ENVS_PER_WAVE: they do so
+ * per-env tables, full or medium records; results identical either way: A/B runs, tests); JSS_KERNEL_TWO_ENVS_PER_WAVE: they do so
  * whatever the size of the launch (tests on small batches).  Per call, not per process.  The CPU twin ignores the field. */
 #define JSS_KERNEL_AUTO 0
 #define JSS_KERNEL_WAVE 1

@@ -76,7 +76,8 @@ class BucketedJssEnv:
                 # a class with ONE instance would take the shared-table layout (op table staged in LDS, compact records),
                 # which has no body in the fused grid: listing the instance twice keeps the class on per-env tables
                 bucket_insts = bucket_insts * 2
-            sub = BatchedJssEnv(bucket_insts, batch=env_ids.size, device=device, seed=seed,
+            # (the one-wavefront-per-env classes on full records: the fused grid has no medium body for them)
+            sub = BatchedJssEnv(bucket_insts, batch=env_ids.size, device=device, seed=seed, records="full" if k >= 2 else None,
                                 table_of_env=[remap[t] for t in self.table_of_env[env_ids]], _backend=_backend)
             # RNG streams are keyed by the GLOBAL env id: give the bucket an explicit id list when its
             # members are not a contiguous range

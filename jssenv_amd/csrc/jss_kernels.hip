@@ -126,7 +126,7 @@ int wave_jpl(const JssDesc &d) {
 }
 
 // Two envs per wavefront, one after the other (jss_wave_env.hpp, wave_block2): the one-step modes of the one-wavefront-per-env
-// flavour with one job per lane, per-env tables and full records.  Measured (profiles/r06_misc/two_per_wave_ab.txt,
+// flavour with one job per lane and per-env tables (full or medium records).  Measured (profiles/r06_misc/two_per_wave_ab.txt,
 // wave_timeline_two_per_wave.txt): with half the wavefronts a launch of 8 192 envs is 15-18 % SLOWER (4 wavefronts per SIMD are
 // latency-bound: a wavefront's two steps take 26.7 k cycles where one took 16.3 k), 16 384 envs 9-10 % slower, and only from
 // about three rounds of resident wavefronts per launch on does the form come out ahead (65 536 envs in two or three
@@ -138,7 +138,7 @@ int wave_jpl(const JssDesc &d) {
 template <int MODE>
 bool two_per_wave(const JssDesc &d, int G, int class_j) {
     if (MODE != kRollout1 && MODE != kStep) return false;
-    if (G || class_j > kWave || d.n_tables == 1 || d.record_ints == JSS_NFM) return false;
+    if (G || class_j > kWave || d.n_tables == 1) return false;
     if (d.kernel & JSS_KERNEL_ONE_ENV_PER_WAVE) return false;
     return (d.kernel & JSS_KERNEL_TWO_ENVS_PER_WAVE) || d.batch >= JSS_TWO_PER_WAVE_MIN_BATCH;
 }
@@ -157,8 +157,9 @@ KernelFn pick(int G, int jpl, bool shared, int record_ints) {
 }
 
 template <int MODE>
-KernelFn pick_two() {       // (instantiated for the one-step modes only)
-    if constexpr (MODE == kRollout1 || MODE == kStep) return jss_kernel_two<MODE, kTabGlobal>;
+KernelFn pick_two(int record_ints) {       // (instantiated for the one-step modes only)
+    if constexpr (MODE == kRollout1 || MODE == kStep)
+        return record_ints == JSS_NFM ? jss_kernel_two<MODE, kTabGlobalM> : jss_kernel_two<MODE, kTabGlobal>;
     else return nullptr;
 }
 
@@ -200,7 +201,7 @@ int plan(Params &p, LaunchPlan &lp, bool by_class = false) {
     lp.shmem += g_lds_pad;
 #endif
     if (lp.shmem > kMaxDynamicLds) return JSS_E_LDS;
-    lp.fn = by_class ? nullptr : lp.two ? pick_two<MODE>() : pick<MODE>(G, wave_jpl(p.d), shared, p.d.record_ints);   // (the grid has its own kernel)
+    lp.fn = by_class ? nullptr : lp.two ? pick_two<MODE>(p.d.record_ints) : pick<MODE>(G, wave_jpl(p.d), shared, p.d.record_ints);   // (the grid has its own kernel)
     return 0;
 }
 
@@ -775,6 +776,13 @@ int jss_sync_check(void *stream) {
     return (int)(rc != hipSuccess ? rc : sticky);
 }
 
+#ifdef JSS_EXP_STAGGER   // A/B builds: sub-batch i starts i x JSS_EXP_STAGGER_NS later (a spinning one-lane kernel in front of its first step)
+__global__ void jss_delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+#endif
+
 int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
                       uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub, void *const *streams) {
     int rc = check_args(desc, state, out, true);
@@ -801,6 +809,12 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
     const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n > 1;
     ForkJoinEvents *ev = nullptr;
     if (fork_join && ((rc = events_for(streams[0], &ev)) || (rc = fork_streams(*ev, streams, n)))) return rc;
+#ifdef JSS_EXP_STAGGER
+    if (const char *ns = getenv("JSS_EXP_STAGGER_NS"))
+        for (int i = 1; i < n; ++i)
+            hipLaunchKernelGGL(jss_delay_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(streams[i]),
+                               (unsigned long long)(atoll(ns) * i / 10));      // wall_clock64: 100 MHz
+#endif
     for (int s = 0; s < n_steps && !rc; ++s)
         for (int i = 0; i < n && !rc; ++i) rc = fire(sub[i], lp, streams[i]);
     const int jrc = fork_join ? join_streams(*ev, streams, n) : 0;

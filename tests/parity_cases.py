@@ -1054,7 +1054,8 @@ def case_hip_equals_twin_full_size(hip_backend, configs=None):
     ]
     for what, kw, policy, n_iter in configs:
         a = BatchedJssEnv(seed=5, env_id_base=123, _backend=hip_backend, **kw)
-        b = BatchedJssEnv(seed=5, env_id_base=123, _backend=cpu, **kw)
+        # (the same `kernel` on both sides: the default record layout of a batch goes by it, and the tensors are compared as stored)
+        b = BatchedJssEnv(seed=5, env_id_base=123, _backend=cpu, kernel=a.kernel, **kw)
         a.reset()
         b.reset()
         a.rollout(policy, n_iter=n_iter)                 # one launch, state in registers

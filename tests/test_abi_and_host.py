@@ -203,8 +203,8 @@ def test_kernels_keep_the_occupancy_the_design_counts_on():
             "jss::jss_packed_kernel<32, 5, 2>": 8,      # config 3
             "jss::jss_packed_kernel<16, 5, 3>": 8,      # per-env 15x15 tables, medium records
             "jss::jss_packed_kernel<16, 1, 2>": 8,      # jss_step on the headline
-            "jss::jss_kernel<1, 5, 1>": 8,              # config 4
-            "jss::jss_kernel<1, 1, 1>": 8,
+            "jss::jss_kernel<1, 5, 3>": 8,              # config 4 (medium records)
+            "jss::jss_kernel<1, 1, 3>": 8, "jss::jss_kernel<1, 5, 1>": 8, "jss::jss_kernel<1, 1, 1>": 8,
             "jss::jss_kernel<2, 5, 1>": 7,              # config 5, interleaved deal
             "jss::jss_packed_kernel<16, 6, 2>": 5, "jss::jss_packed_kernel<16, 7, 2>": 5,     # recorders, shared table
             "jss::jss_packed_kernel<32, 6, 2>": 5, "jss::jss_packed_kernel<32, 7, 2>": 5,

@@ -417,12 +417,14 @@ def test_integration_level2_stub_as_printed():
     P.case_integration_level2_stub(_abi.library_path(), on_gpu=True)
 
 
-def test_two_envs_per_wavefront_small_batches():
-    """jss_kernel_two on request (JSS_KERNEL_TWO_ENVS_PER_WAVE) on small, odd, ragged batches;
+@pytest.mark.parametrize("records", [None, "medium"])
+def test_two_envs_per_wavefront_small_batches(records):
+    """jss_kernel_two on request (JSS_KERNEL_TWO_ENVS_PER_WAVE) on small, odd, ragged batches, full and medium job records;
     at the benchmarked sizes the form is the default and FULL_SIZE_CONFIGS[2, 6, 7] hold every env of it to the oracle."""
     from jssenv_amd.env import HipBackend
     two, one = HipBackend("cuda:0"), HipBackend("cuda:0")
     two.default_kernel, one.default_kernel = "wave-2env", "wave-1env"
+    two.default_records = one.default_records = records
     P.case_two_envs_per_wavefront(two, one, steps=200, n_envs=131)
 
 

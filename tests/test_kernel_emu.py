@@ -196,10 +196,13 @@ def test_policy_step_steps_equals_the_loop(emu):
     P.case_policy_step_steps(emu, batch=66, steps=3, warm=12)
 
 
-def test_two_envs_per_wavefront():
-    """jss_kernel_two under the emulator (small batches take the form on request)."""
+@pytest.mark.parametrize("records", [None, "medium"])
+def test_two_envs_per_wavefront(records):
+    """jss_kernel_two under the emulator (small batches take the form on request), on full and on medium job records."""
     from emu_backend import EmuBackend
-    P.case_two_envs_per_wavefront(EmuBackend(default_kernel="wave-2env"), EmuBackend(default_kernel="wave-1env"), steps=24, n_envs=5)
+    two, one = EmuBackend(default_kernel="wave-2env"), EmuBackend(default_kernel="wave-1env")
+    two.default_records = one.default_records = records
+    P.case_two_envs_per_wavefront(two, one, steps=24, n_envs=5)
 
 
 def test_fuzz_mixed_calls_against_the_oracle():

@@ -12,12 +12,15 @@ from jssenv_amd import BatchedJssEnv, builtin_instance  # noqa: E402
 from jssenv_amd.instances import synthetic_packed  # noqa: E402
 
 K = int(os.environ.get("JSS_KT", "32"))
+ONLY = os.environ.get("JSS_PROBE_ONLY", "")                     # e.g. "synthetic50x20"; JSS_PROBE_RECORDS = full | medium for the synthetic ones
 for what, B in (("ta01", 65536), ("ta01", 4096), ("synthetic50x20", 8192), ("mixed", 32768), ("synthetic15x15", 65536), ("ta41", 16384)):
+    if ONLY and what != ONLY:
+        continue
     if what == "mixed":
         env = BatchedJssEnv([builtin_instance(f"ta{k:02d}") for k in range(1, 81)], batch=B, device="cuda:0")
     elif what.startswith("synthetic"):
         J, M = (int(x) for x in what[len("synthetic"):].split("x"))
-        env = BatchedJssEnv(synthetic_packed(B, J, M), device="cuda:0")
+        env = BatchedJssEnv(synthetic_packed(B, J, M), device="cuda:0", records=os.environ.get("JSS_PROBE_RECORDS") or None)
     else:
         env = BatchedJssEnv(what, batch=B, device="cuda:0")
     env.reset()
@@ -33,7 +36,7 @@ for what, B in (("ta01", 65536), ("ta01", 4096), ("synthetic50x20", 8192), ("mix
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         best = max(best, env.stats()["steps"] / dt)
-    lib = os.path.basename(os.environ.get('JSSENV_AMD_LIB', 'shipped'))
+    lib = os.path.basename(os.environ.get('JSSENV_AMD_LIB', 'shipped')) + (" records=" + os.environ["JSS_PROBE_RECORDS"] if os.environ.get("JSS_PROBE_RECORDS") else "")
     print(f"traj  K={K} {what} B={B}: {best / 1e9:.3f} G env-steps/s  lib={lib}", flush=True)
     # jss_steps: the recorded actions of one trajectory launch, replayed from the state they were recorded in
     snap = env._arena.clone(), env.solution.clone()

@@ -21,11 +21,11 @@ WORKLOADS = {
     "ta01_b4096": ("ta01_b4096", "jss_packed_kernel<16, 5, 2>", "jss_packed_kernel<16,kRollout1,kTabLdsC>", b_alg(15, 15), 4096),
     "syn15x15_b65536": ("syn15x15", "jss_packed_kernel<16, 5, 3>", "jss_packed_kernel<16,kRollout1,kTabGlobalM> (24-byte medium records)", b_alg(15, 15), 65536),
     "ta41_b16384": ("ta41", "jss_packed_kernel<32, 5, 2>", "jss_packed_kernel<32,kRollout1,kTabLdsC>", b_alg(30, 20), 16384),
-    "syn50x20_b8192": ("syn50x20", "jss_kernel<1, 5, 1>", "jss_kernel<1,kRollout1,kTabGlobal>", b_alg(50, 20), 8192),
+    "syn50x20_b8192": ("syn50x20", "jss_kernel<1, 5, 3>", "jss_kernel<1,kRollout1,kTabGlobalM> (24-byte medium records)", b_alg(50, 20), 8192),
     "mixed_b32768": ("mixed", "jss_kernel<2, 5, 1>", "jss_kernel<2,kRollout1,kTabGlobal> (order='interleaved'; one-job-per-lane body for J <= 64)", None, 32768),
     "mixed_bucketed_b32768": ("mixed_bucketed", "jss_multi_kernel<5>", "jss_multi_kernel<kRollout1>: one grid over the four shape classes", None, 32768),
     "mixed_by_shape_b32768": ("mixed_by_shape", "jss_multi_kernel<5>", "jss_multi_kernel<kRollout1>: class-specialised bodies on the padded rows", None, 32768),
-    "syn50x20_b65536": ("syn50x20_b65536", "jss_kernel_two<5, 1>", "jss_kernel_two<kRollout1,kTabGlobal> (two envs per wavefront, one after the other)", b_alg(50, 20), 65536),
+    "syn50x20_b65536": ("syn50x20_b65536", "jss_kernel_two<5, 3>", "jss_kernel_two<kRollout1,kTabGlobalM> (two envs per wavefront, one after the other; medium records)", b_alg(50, 20), 65536),
 }
 
 
