@@ -776,13 +776,6 @@ int jss_sync_check(void *stream) {
     return (int)(rc != hipSuccess ? rc : sticky);
 }
 
-#ifdef JSS_EXP_STAGGER   // A/B builds: sub-batch i starts i x JSS_EXP_STAGGER_NS later (a spinning one-lane kernel in front of its first step)
-__global__ void jss_delay_kernel(unsigned long long ticks) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-#endif
-
 int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *out, int kind, uint64_t seed,
                       uint32_t explore_q16, int32_t n_steps, int32_t flags, int32_t n_sub, void *const *streams) {
     int rc = check_args(desc, state, out, true);
@@ -809,12 +802,6 @@ int jss_rollout_steps(const JssDesc *desc, const JssState *state, const JssOut *
     const bool fork_join = (flags & JSS_ROLLOUT_FORK_JOIN) != 0 && n > 1;
     ForkJoinEvents *ev = nullptr;
     if (fork_join && ((rc = events_for(streams[0], &ev)) || (rc = fork_streams(*ev, streams, n)))) return rc;
-#ifdef JSS_EXP_STAGGER
-    if (const char *ns = getenv("JSS_EXP_STAGGER_NS"))
-        for (int i = 1; i < n; ++i)
-            hipLaunchKernelGGL(jss_delay_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(streams[i]),
-                               (unsigned long long)(atoll(ns) * i / 10));      // wall_clock64: 100 MHz
-#endif
     for (int s = 0; s < n_steps && !rc; ++s)
         for (int i = 0; i < n && !rc; ++i) rc = fire(sub[i], lp, streams[i]);
     const int jrc = fork_join ? join_streams(*ev, streams, n) : 0;

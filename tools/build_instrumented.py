@@ -25,7 +25,6 @@ VARIANTS = {"profiling": ["-DJSS_PROFILING"], "occ7": ["-DJSS_WAVE_MIN_BLOCKS=7"
             "nodeepwalk": ["-DJSS_EXP_NO_DEEP_WALK"], "w2occ8": ["-DJSS_WAVE2_MIN_BLOCKS=8"],
             "plaincounters": ["-DJSS_COUNTERS_PLAIN"], "nocounters": ["-DJSS_EXP_NO_COUNTERS"],
             "mstep6": ["-DJSS_MULTI_STEP_MIN_BLOCKS=6"], "mstep7": ["-DJSS_MULTI_STEP_MIN_BLOCKS=7"],
-            "stagger": ["-DJSS_EXP_STAGGER"],
             "ptraj5": ["-DJSS_PTRAJ_LDS_MIN_BLOCKS=5", "-DJSS_PTRAJ_GLOBAL_MIN_BLOCKS=5"],
             "ptraj6": ["-DJSS_PTRAJ_LDS_MIN_BLOCKS=6", "-DJSS_PTRAJ_GLOBAL_MIN_BLOCKS=6"]}
 
