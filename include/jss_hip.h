@@ -130,7 +130,7 @@ extern "C" {
  * bits (machine << 16 | duration, 0 = none), todo <= 32 is 6 bits, total_perform_op_time_jobs <= 32 x 65535 < 2^21: 189
  * of the 192 bits.  No machine clocks in memory either (JssState.machine may be NULL), as with compact records.  Measured
  * faster than full records on the 16-lane packed shapes (profiles/README.md) and on the one-job-per-lane shapes of the
- * one-wavefront-per-env flavour (33..64 jobs; profiles/r06_misc/medium_records_wave.txt): that is where the host uses it.  Words: */
+ * one-wavefront-per-env flavour (profiles/r06_misc/medium_records_wave.txt): that is where the host uses it.  Words: */
 #define JSS_FM_W0 0        /* bits 0-5 todo_time_step_job, bit 6 legal_actions[j], bit 7 action_illegal_no_op[j], bit 8 observation
                               feature 4 is "1.0", bits 9-29 the current op (0 = job finished)                              */
 #define JSS_FM_LEFT_F4 1   /* bits 0-15 time_until_finish_current_op_jobs, bits 16-31 the feature-4 numerator          */

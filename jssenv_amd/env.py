@@ -117,16 +117,16 @@ class BatchedJssEnv:
         # The library takes them for every shape with machines <= 32 (both kernel flavours); by default they are used
         # where they measure faster than full records: the 16-lane groups (jobs, machines <= 16: +8-10 % on 15 x 15; with 32-lane
         # groups the three 8-byte accesses and the unpacking cost more than the bytes save, -2 % on 20 x 20 --
-        # profiles/README.md) and the one-job-per-lane shapes of the one-wavefront-per-env flavour (33..64 jobs, every instance of
-        # the batch: 50 x 20 x 65 536 +7 %, x 8 192 +-0 -- profiles/r06_misc/medium_records_wave.txt; a batch that mixes shape
-        # classes keeps full records, the fused grid has no medium body for these shapes).  `compact=False` / records="full"
-        # asks for full records everywhere.
+        # profiles/README.md) and the shapes of the one-wavefront-per-env flavour when every instance of the batch is of the same
+        # class (33..64 jobs: 50 x 20 x 65 536 +7 %, x 8 192 +-0; more than 64: ta71-80 x 4 096 +6-9 % --
+        # profiles/r06_misc/medium_records_wave.txt; a batch that mixes shape classes keeps full records, the fused grid has no
+        # medium body for these shapes).  `compact=False` / records="full" asks for full records everywhere.
         fits = n != 1 and pk.mmax <= 32                 # 21-bit ops: machines <= 32, any number of jobs, either kernel flavour
         if records == "medium" and not fits:
             raise ValueError("medium job records need a batch of different instances with machines <= 32")
         if records is None and compact is None and fits and getattr(be, "default_records", None) == "medium":
             records = "medium"                         # (test backends: the layout travels with the backend like default_kernel)
-        one_wave_class = set(cls.tolist()) == {2} and pk.jmax <= 64
+        one_wave_class = set(cls.tolist()) in ({2}, {3})
         self.medium = records == "medium" or (records is None and compact is None and fits and self.kernel.startswith("auto")
                                               and ((pk.jmax <= 16 and pk.mmax <= 16) or one_wave_class))
         self.record_ints = _abi.NFC if self.compact else _abi.NFM if self.medium else _abi.NF

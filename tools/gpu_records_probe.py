@@ -11,10 +11,16 @@ from jssenv_amd.instances import synthetic_packed
 
 K = 100
 dev = torch.device("cuda", 0)
-for B in (8192, 65536):
-    src = synthetic_packed(B, 50, 20)
-    for records, kernel in ((None, "auto"), ("medium", "auto"), ("medium", "auto-1env"), (None, "auto"), ("medium", "auto"), ("medium", "auto-1env")):
-        env = BatchedJssEnv(src, device=dev, seed=0, records=records, kernel=kernel)
+from jssenv_amd import builtin_instance
+ta = lambda a, b: [builtin_instance(f"ta{k:02d}") for k in range(a, b + 1)]
+CASES = {"c4": [("syn50x20 x 8192", lambda: synthetic_packed(8192, 50, 20), None), ("syn50x20 x 65536", lambda: synthetic_packed(65536, 50, 20), None)],
+         # config 5's one-wavefront-per-env classes on their own, and its 32-lane class
+         "c5": [("ta51-70 x 8192 (50 jobs)", lambda: ta(51, 70), 8192), ("ta71-80 x 4096 (100 jobs)", lambda: ta(71, 80), 4096),
+                ("ta11-50 x 12288 (20-30 jobs)", lambda: ta(11, 50), 12288)]}
+for label, make, batch in CASES[sys.argv[1] if len(sys.argv) > 1 else "c4"]:
+    src = make()
+    for records, kernel in (("full", "auto"), ("medium", "auto"), ("medium", "auto-1env"), ("full", "auto"), ("medium", "auto"), ("medium", "auto-1env")):
+        env = BatchedJssEnv(src, batch=batch, device=dev, seed=0, records=records, kernel=kernel)
         env.reset()
         env.rollout("random", n_iter=100)
         side = torch.cuda.Stream(device=dev)
@@ -39,5 +45,5 @@ for B in (8192, 65536):
             torch.cuda.synchronize()
             t2.append((time.perf_counter() - t0) / K * 1e6)
         ts.sort(); t2.sort()
-        print(f"syn50x20 x {B:6d} records={str(records):6s} kernel={kernel:9s}: graph replay {ts[len(ts)//2]:6.2f} us/step   2 sub-batches {t2[len(t2)//2]:6.2f} us/step", flush=True)
+        print(f"{label:30s} records={records:6s} kernel={kernel:9s}: graph replay {ts[len(ts)//2]:6.2f} us/step   2 sub-batches {t2[len(t2)//2]:6.2f} us/step", flush=True)
         del g, env
