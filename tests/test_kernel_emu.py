@@ -202,7 +202,8 @@ def test_two_envs_per_wavefront(records):
     from emu_backend import EmuBackend
     two, one = EmuBackend(default_kernel="wave-2env"), EmuBackend(default_kernel="wave-1env")
     two.default_records = one.default_records = records
-    P.case_two_envs_per_wavefront(two, one, steps=24 if records is None else 10, n_envs=5 if records is None else 3)
+    P.case_two_envs_per_wavefront(two, one, steps=24 if records is None else 10, n_envs=5 if records is None else 3,
+                                  pair_rounds=90 if records is None else 30)
 
 
 def test_fuzz_mixed_calls_against_the_oracle():
