@@ -10,6 +10,11 @@ JSSENV_AMD_LIB points somewhere else.
     variants/plaincounters.so  -DJSS_COUNTERS_PLAIN: packed fused rollouts load / store their env's counter row with the state
                                instead of bumping it with atomics (round 6 A/B); nocounters.so: no counters at all (a ceiling)
 
+    variants/mstep6.so, mstep7.so   -DJSS_MULTI_STEP_MIN_BLOCKS=6 / 7: the fused grid's step kernel declared for 6 / 7 wavefronts per SIMD
+    variants/ptraj5.so, ptraj6.so   the packed recorders (kTraj / kSteps) declared for 5 / 6 (6: 10-23 VGPRs in scratch)
+    (any other -D of the sources, e.g. -DJSS_EXP_MULTI_ONLY=<flavour>: the fused grid with one body, for per-body register
+     counts -- jssenv_amd.build.build_extension(force=True, extra=[...], out=...))
+
 One-off experiments whose findings are recorded in profiles/README.md (streaming hints on other streams, rewriting
 every record, the walk without op table reads) were compile-time variants of the same sources at the commits named
 there; they are not kept in the tree.
