@@ -718,10 +718,24 @@ __device__ __forceinline__ PRaw<G> p_pack(const PEnv<G> &e, const PCtx<G, TAB> &
 // DIFF = false (the modes that loop over steps with the state in registers: one store per K steps): every row of a job is
 // written without comparing it with what was loaded, so that `raw` -- 9 VGPRs -- is dead from the unpack on instead of live
 // through the whole loop.
-template <int G, int TAB, bool DIFF = true>
+// DIFF: which records of a stepped env go back to memory.
+//   kStoreAll      every row of a job, nothing compared (the modes that loop over steps: `raw` is dead after the unpack);
+//   kStoreCompare  the halves / thirds of a record that differ from what was loaded;
+//   kStoreCause    (the one-step modes) by what the step did instead of by comparing eight words per job: word 0 -- flags, todo --
+//                  is compared; the rest of a record changes only for the job that was scheduled (time left) and, when the clock
+//                  moved, for every job that is not complete already (a complete job: no current op, word 0 unchanged).  A
+//                  superset of the compared set by a few records per episode; of `raw` only word 0 of each record stays live
+//                  through the step -- 7 VGPRs per job slot less (`moved` = the clock differs from the one loaded, or the env
+//                  was restarted in the kernel; `a_sched` = the job the step scheduled, -1 if none).
+enum { kStoreAll = 0, kStoreCompare = 1, kStoreCause = 2 };
+#ifndef JSS_ONE_STEP_STORES
+#define JSS_ONE_STEP_STORES kStoreCause      // (-DJSS_ONE_STEP_STORES=kStoreCompare: the A/B partner)
+#endif
+template <int G, int TAB, int DIFF = kStoreCompare>
 __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c, const Params &p, const PHeader &hd,
-                                        const PRaw<G> &raw, bool fresh) {
+                                        const PRaw<G> &raw, bool fresh, bool moved = false, int a_sched = -1) {
     if (!c.alive) return;
+    const bool adv = DIFF == kStoreCause && moved;
     const unsigned jm = (unsigned)p.d.jmax, mm = (unsigned)p.d.mmax;
     const size_t fe = (size_t)c.first_env;
     const PRaw<G> now = p_pack(e, c, hd);
@@ -738,31 +752,50 @@ __device__ __forceinline__ void p_store(const PEnv<G> &e, const PCtx<G, TAB> &c,
     }
     if (tab_no_clocks(TAB)) {
         // no machine clocks in memory (p_unpack)
-    } else if (fresh ? (unsigned)c.gl < mm : (c.mvalid && (!DIFF || e.tm != raw.tm)))      // idle machines stay 0
+    } else if (fresh ? (unsigned)c.gl < mm : (c.mvalid && (DIFF == kStoreAll || e.tm != raw.tm)))      // idle machines stay 0
         st_off(p.s.machine + fe * mm, (c.rel * mm + c.gl) * 4u, e.tm);
+    // kStoreCause: the part of a record that holds word 0 / the time left, and the parts only a clock move touches
+    const bool w0_changed = now.lo.x != raw.lo.x;
+    const bool head_dirty = w0_changed || c.gl == a_sched || (adv && e.cur >= 0);
+    const bool rest_dirty = adv && (e.cur >= 0 || w0_changed);
     if (tab_medium(TAB)) {
         if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {   // the thirds of the record that changed
             int32_t *jb = p.s.job + fe * jm * JSS_NFM;
             const unsigned jo = (c.rel * jm + c.gl) * (JSS_NFM * 4u);
             const int4 lo = now.lo, hi = now.hi;
-            if (!DIFF || fresh || lo.x != raw.lo.x || lo.y != raw.lo.y) st_off(jb, jo, make_int2(lo.x, lo.y));
-            if (!DIFF || fresh || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo + 8u, make_int2(lo.z, lo.w));
-            if (!DIFF || fresh || hi.x != raw.hi.x || hi.y != raw.hi.y) st_off(jb, jo + 16u, make_int2(hi.x, hi.y));
+            if (DIFF == kStoreCause && !fresh) {
+                if (head_dirty) st_off(jb, jo, make_int2(lo.x, lo.y));
+                if (rest_dirty) {
+                    st_off(jb, jo + 8u, make_int2(lo.z, lo.w));
+                    st_off(jb, jo + 16u, make_int2(hi.x, hi.y));
+                }
+            } else {
+                if (DIFF == kStoreAll || fresh || lo.x != raw.lo.x || lo.y != raw.lo.y) st_off(jb, jo, make_int2(lo.x, lo.y));
+                if (DIFF == kStoreAll || fresh || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo + 8u, make_int2(lo.z, lo.w));
+                if (DIFF == kStoreAll || fresh || hi.x != raw.hi.x || hi.y != raw.hi.y) st_off(jb, jo + 16u, make_int2(hi.x, hi.y));
+            }
         }
     } else if (tab_compact(TAB)) {
         if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
             const int4 lo = now.lo;
             // an unchanged record is not rewritten (steps without a time advance touch few jobs)
-            if (!DIFF || fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w)
-                st_off(p.s.job + fe * jm * JSS_NFC, (c.rel * jm + c.gl) * (JSS_NFC * 4u), lo);
+            bool dirty;
+            if (DIFF == kStoreCause) dirty = head_dirty || rest_dirty;
+            else dirty = DIFF == kStoreAll || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w;
+            if (fresh || dirty) st_off(p.s.job + fe * jm * JSS_NFC, (c.rel * jm + c.gl) * (JSS_NFC * 4u), lo);
         }
     } else if (c.jvalid || (fresh && (unsigned)c.gl < jm)) {
         int32_t *jb = p.s.job + fe * jm * JSS_NF;
         const unsigned jo = (c.rel * jm + c.gl) * 32u;
         const int4 lo = now.lo, hi = now.hi;
         // unchanged halves of the record are not rewritten (steps without a time advance touch few jobs)
-        if (!DIFF || fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
-        if (!DIFF || fresh || hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) st_off(jb, jo + 16u, hi);
+        if (DIFF == kStoreCause && !fresh) {
+            if (head_dirty) st_off(jb, jo, lo);
+            if (rest_dirty) st_off(jb, jo + 16u, hi);
+        } else {
+            if (DIFF == kStoreAll || fresh || lo.x != raw.lo.x || lo.y != raw.lo.y || lo.z != raw.lo.z || lo.w != raw.lo.w) st_off(jb, jo, lo);
+            if (DIFF == kStoreAll || fresh || hi.x != raw.hi.x || hi.y != raw.hi.y || hi.z != raw.hi.z || hi.w != raw.hi.w) st_off(jb, jo + 16u, hi);
+        }
         // A class of small instances inside wider padded rows (jmax > G: the fused grid's PADDED bodies): a reset leaves the rows
         // behind the lane group as "no job" records too, like the reset of the padded extents' kernel, the session's write-back
         // and the host twin do -- whichever path (re)initialised an env, its padded block holds the same bytes (a few KB per
@@ -909,11 +942,14 @@ __device__ __forceinline__ bool p_step_call(PEnv<G> &e, PHeader &hd, PCtx<G, TAB
     return r.restart;
 }
 
+// (a_sched / restarted: what the one step of kStep / kRollout1 did to my env -- p_store, kStoreCause)
 template <int G, int MODE, int TAB>
 __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c, const Params &p, int a_in, bool selected,
-                                       int32_t *mvtab, float *scratch, bool wave_whole, int cw = 0) {
+                                       int32_t *mvtab, float *scratch, bool wave_whole, int &a_sched, bool &restarted, int cw = 0) {
     const size_t fe = (size_t)c.first_env;
     bool fresh = false;
+    a_sched = -1;
+    restarted = false;
     if (MODE == kReset) {
         const bool on = c.alive && selected;          // untouched groups are written back unchanged
         p_reset(e, c, p, on);
@@ -930,6 +966,7 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
         int rn;
         bool called;
         fresh = p_step_call<G, TAB, false>(e, hd, c, p, a_in, mvtab, rn, called);
+        a_sched = a_in;
     } else if (MODE == kSteps) {
         // n_iter x jss_step with the actions given up front: the state stays in registers, every step optionally recorded
         for (int it = 0; it < p.n_iter; ++it) {
@@ -982,6 +1019,10 @@ __device__ __forceinline__ bool p_body(PEnv<G> &e, PHeader &hd, PCtx<G, TAB> &c,
             int a = JSS_ABLATED(p, JSS_ABLATE_SELECT) ? __ffs(grp_ballot<G>(e.legal, c.gbase)) - 1
                                                       : p_select(e, c, p, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
             if (!do_step) a = JSS_ACTION_SKIP;
+            if (MODE == kRollout1) {
+                a_sched = a;
+                restarted = do_reset;
+            }
             const int rn = p_step(e, c, p, a, mvtab);
             const bool done1 = !grp_any<G>(e.legal, c.gbase);            // collective: outside the divergent branch
             if (do_step) {
@@ -1131,13 +1172,19 @@ __device__ __forceinline__ void packed_block(const Params &p, int block, int32_t
     // an env that was never reset (episode counter 0: every reset bumps it) is left alone by the step-type calls, like
     // the one-wavefront-per-env kernel and the host twin do (J == 0 in its constants record): no stores, no counters
     if (MODE != kReset && hd.episode == 0) c.alive = false;
+    int a_sched;
+    bool restarted;
 #ifdef JSS_COUNTERS_PLAIN
-    const bool fresh = p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab, scratch, wave_whole, raw.cw);
+    const bool fresh = p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab, scratch, wave_whole, a_sched, restarted, raw.cw);
 #else
-    const bool fresh = p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab, scratch, wave_whole);
+    const bool fresh = p_body<G, MODE, TAB>(e, hd, c, p, a_in, selected, mvtab, scratch, wave_whole, a_sched, restarted);
 #endif
     if (MODE == kPolicy) return;
-    p_store<G, TAB, !(MODE == kRollout || MODE == kTraj || MODE == kSteps)>(e, c, p, hd, raw, fresh);
+    // (by cause with per-env tables only: +1.6 % on 15x15 x 65 536, full records 67 -> 61 VGPRs = 8 wavefronts per SIMD; on a
+    //  shared table -- 16-byte records, four words to compare -- it measured 0..2 % SLOWER: profiles/r06_misc/stores_by_cause_ab.txt)
+    constexpr int kDiffStores = (MODE == kRollout || MODE == kTraj || MODE == kSteps) ? kStoreAll
+                                : ((MODE == kStep || MODE == kRollout1) && tab_global(TAB)) ? JSS_ONE_STEP_STORES : kStoreCompare;
+    p_store<G, TAB, kDiffStores>(e, c, p, hd, raw, fresh, restarted || e.t != raw.h.x, a_sched);
     p_store_mask<G, TAB, false, PADDED>(e, c, p, p.o.action_mask + fe * (p.d.jmax + 1));
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
         p_store_obs<G, TAB, false, PADDED>(e, c, p, p.o.real_obs + fe * p.d.jmax * 7, scratch, wave_whole);

@@ -750,9 +750,11 @@ __device__ __forceinline__ RawEnv<JPL> pack_env(const Env<JPL> &e, const Ctx &c)
 // DIFF = false (the modes that loop over steps with the state in registers: one store per K steps): every row of a job is
 // written without comparing it with what was loaded -- `raw` is dead from the unpack on instead of live through the whole
 // loop (9 VGPRs per job slot: what kept the two-jobs-per-lane recorder in scratch memory).
-template <int JPL, int TAB, bool DIFF = true>
+// DIFF: kStoreAll / kStoreCompare / kStoreCause (jss_packed_env.hpp, p_store)
+template <int JPL, int TAB, int DIFF = kStoreCompare>
 __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const Params &p, const Header &hd,
-                                          const RawEnv<JPL> &raw, bool all_rows) {
+                                          const RawEnv<JPL> &raw, bool all_rows, bool moved = false, int a_sched = -1) {
+    const bool adv = DIFF == kStoreCause && moved;
     const int jm = p.d.jmax;
     int32_t *jb = p.s.job + (size_t)c.b * jm * tab_record_ints(TAB);
     if (c.lane == 0) {
@@ -769,7 +771,7 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
         // no machine clocks in memory (unpack_env)
     } else if (all_rows) {
         if (c.lane < p.d.mmax) st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
-    } else if (c.lane < c.M && (!DIFF || e.tm != raw.tm)) {              // idle machines stay 0
+    } else if (c.lane < c.M && (DIFF == kStoreAll || e.tm != raw.tm)) {  // idle machines stay 0
         st_off<int>(p.s.machine + (size_t)c.b * p.d.mmax, (unsigned)c.lane * 4u, e.tm);
     }
     const RawEnv<JPL> now = pack_env<JPL, TAB>(e, c);
@@ -777,20 +779,37 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
     for (int s = 0; s < JPL; ++s) {
         const int j = s * kWave + c.lane;
         const int4 lo = now.lo[s], hi = now.hi[s];
+        // kStoreCause: the part of a record that holds word 0 / the time left, and the parts only a clock move touches
+        const bool w0_changed = lo.x != raw.lo[s].x;
+        const bool head_dirty = w0_changed || j == a_sched || (adv && e.cur[s] >= 0);
+        const bool rest_dirty = adv && (e.cur[s] >= 0 || w0_changed);
         if (tab_medium(TAB)) {           // the thirds of the record that changed
             const unsigned jo = (unsigned)j * (JSS_NFM * 4u);
-            const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
             if (all_rows ? j < jm : j < c.J) {
-                if (!DIFF || all_rows || lo.x != lo0.x || lo.y != lo0.y) st_off<int2>(jb, jo, make_int2(lo.x, lo.y));
-                if (!DIFF || all_rows || lo.z != lo0.z || lo.w != lo0.w) st_off<int2>(jb, jo + 8u, make_int2(lo.z, lo.w));
-                if (!DIFF || all_rows || hi.x != hi0.x || hi.y != hi0.y) st_off<int2>(jb, jo + 16u, make_int2(hi.x, hi.y));
+                if (DIFF == kStoreCause && !all_rows) {
+                    if (head_dirty) st_off<int2>(jb, jo, make_int2(lo.x, lo.y));
+                    if (rest_dirty) {
+                        st_off<int2>(jb, jo + 8u, make_int2(lo.z, lo.w));
+                        st_off<int2>(jb, jo + 16u, make_int2(hi.x, hi.y));
+                    }
+                } else {
+                    const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
+                    if (DIFF == kStoreAll || all_rows || lo.x != lo0.x || lo.y != lo0.y) st_off<int2>(jb, jo, make_int2(lo.x, lo.y));
+                    if (DIFF == kStoreAll || all_rows || lo.z != lo0.z || lo.w != lo0.w) st_off<int2>(jb, jo + 8u, make_int2(lo.z, lo.w));
+                    if (DIFF == kStoreAll || all_rows || hi.x != hi0.x || hi.y != hi0.y) st_off<int2>(jb, jo + 16u, make_int2(hi.x, hi.y));
+                }
             }
             continue;
         }
         if (tab_compact(TAB)) {
             const unsigned jo = (unsigned)j * (JSS_NFC * 4u);
-            const int4 lo0 = raw.lo[s];
-            if (all_rows ? j < jm : (j < c.J && (!DIFF || lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w))) st_off<int4>(jb, jo, lo);
+            bool dirty;
+            if (DIFF == kStoreCause) dirty = head_dirty || rest_dirty;
+            else {
+                const int4 lo0 = raw.lo[s];
+                dirty = DIFF == kStoreAll || lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w;
+            }
+            if (all_rows ? j < jm : (j < c.J && dirty)) st_off<int4>(jb, jo, lo);
             continue;
         }
         if (all_rows) {
@@ -806,9 +825,14 @@ __device__ __forceinline__ void store_env(const Env<JPL> &e, const Ctx &c, const
                     st_off<int4>(jb, (unsigned)r * 32u + 16u, make_int4(0, 0, 0, -1));
                 }
         } else if (j < c.J) {   // steps without a time advance touch few jobs
-            const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
-            if (!DIFF || lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w) st_off<int4>(jb, (unsigned)j * 32u, lo);
-            if (!DIFF || hi.x != hi0.x || hi.y != hi0.y || hi.z != hi0.z || hi.w != hi0.w) st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
+            if (DIFF == kStoreCause) {
+                if (head_dirty) st_off<int4>(jb, (unsigned)j * 32u, lo);
+                if (rest_dirty) st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
+            } else {
+                const int4 lo0 = raw.lo[s], hi0 = raw.hi[s];
+                if (DIFF == kStoreAll || lo.x != lo0.x || lo.y != lo0.y || lo.z != lo0.z || lo.w != lo0.w) st_off<int4>(jb, (unsigned)j * 32u, lo);
+                if (DIFF == kStoreAll || hi.x != hi0.x || hi.y != hi0.y || hi.z != hi0.z || hi.w != hi0.w) st_off<int4>(jb, (unsigned)j * 32u + 16u, hi);
+            }
         }
     }
 }
@@ -1051,10 +1075,13 @@ __device__ __forceinline__ void wave_finish(const Params &p, Ctx &c, const Heade
 
     StepResult sr = {0, false, false, false};                            // kStep
     int n_steps = 0, n_done = 0, sum_makespan = 0, sum_rn = 0, last_rn = 0, last_makespan = -1;   // the rollouts
+    int a_sched = -1;                                                    // the job the (one) step scheduled: store_env, kStoreCause
+    bool restarted = false;                                              // ... and "reset inside the rollout": every record changes
     if (!live) {
         // nothing
     } else if (MODE == kStep) {                                          // (JSS_ACTION_RESET never gets here: jss_kernel)
         sr = step_compute<JPL, TAB, false, false>(e, hd, c, p, lds, a_in);
+        a_sched = a_in;
     } else if (MODE == kSteps) {
         // n_iter x jss_step with the actions given up front: the state stays in registers, every step optionally recorded
         for (int it = 0; it < p.n_iter; ++it) {
@@ -1104,10 +1131,12 @@ __device__ __forceinline__ void wave_finish(const Params &p, Ctx &c, const Heade
                 reset_env(e, c, p);
                 hd.episode += 1;
                 hd.step = 0;
+                restarted = true;
                 continue;
             }
             const int a = select_action(e, c, p, env_id, (uint32_t)hd.episode, (uint32_t)hd.step);
             JSS_STAMP(p, b, 3, a);
+            if (MODE == kRollout1) a_sched = a;
             last_rn = step_env(e, c, p, a);
             JSS_STAMP(p, b, 4, last_rn + e.fill[0]);
             hd.step += 1;
@@ -1142,8 +1171,12 @@ __device__ __forceinline__ void wave_finish(const Params &p, Ctx &c, const Heade
     // (the one-job-per-lane recorder keeps comparing: without `raw` it needs 61 VGPRs instead of 78, runs 8 wavefronts per
     //  SIMD instead of 6 and is 5 % SLOWER on 8 192 envs -- one round of wavefronts in lock step instead of two that overlap;
     //  profiles/r06_misc/looping_stores_ab.txt)
-    constexpr bool kDiffStores = !(MODE == kRollout || MODE == kSteps || (MODE == kTraj && JPL == 2));
-    store_env<JPL, TAB, kDiffStores>(e, c, p, hd, raw, fresh);
+    // (the one-step modes with per-env tables store by cause: config 5 by shape class +3 %, config 4's share +1.6 %, its jss_step
+    //  +3 %; on a shared table -- four words per record to compare -- by cause measured 1-2 % slower:
+    //  profiles/r06_misc/stores_by_cause_ab.txt)
+    constexpr int kDiffStores = (MODE == kRollout || MODE == kSteps || (MODE == kTraj && JPL == 2)) ? kStoreAll
+                                : ((MODE == kStep || MODE == kRollout1) && tab_global(TAB)) ? JSS_ONE_STEP_STORES : kStoreCompare;
+    store_env<JPL, TAB, kDiffStores>(e, c, p, hd, raw, fresh, restarted || e.t != __builtin_amdgcn_readfirstlane(h.clock), a_sched);
     store_mask(e, c, p.o.action_mask + (size_t)b * (p.d.jmax + 1), p.d.jmax);
     JSS_STAMP(p, b, 5, e.t);
     if (!JSS_ABLATED(p, JSS_ABLATE_OBS))
